@@ -1,0 +1,51 @@
+"""Compact tensor summaries used by the golden fixtures (tests/golden/*.npz).
+
+A tensor is stored either whole (<= FULL_LIMIT elements) or as
+(shape, l2 norm, sum, values at NSAMPLE fixed pseudo-random flat indices).
+"""
+import numpy as np
+
+FULL_LIMIT = 4096
+NSAMPLE = 96
+
+
+def sample_indices(n, tag=0):
+    rng = np.random.Generator(np.random.PCG64(1000003 + tag))
+    return (rng.random(NSAMPLE) * n).astype(np.int64)
+
+
+def summarize(prefix, arr, out):
+    a = np.asarray(arr, dtype=np.float64)
+    out[prefix + "/shape"] = np.array(a.shape, dtype=np.int64)
+    if a.size <= FULL_LIMIT:
+        out[prefix + "/full"] = a.astype(np.float32)
+    else:
+        flat = a.reshape(-1)
+        out[prefix + "/l2"] = np.array(np.sqrt((flat ** 2).sum()))
+        out[prefix + "/sum"] = np.array(flat.sum())
+        out[prefix + "/samples"] = flat[sample_indices(flat.size)].astype(np.float32)
+
+
+def check(prefix, arr, gold, rtol, atol_frac=1e-6, what=""):
+    """Assert ``arr`` matches the stored summary.  ``rtol`` is relative to the
+    tensor's overall scale (l2/sqrt(n) or max|.|), which is the meaningful
+    measure for conv outputs/gradients."""
+    a = np.asarray(arr, dtype=np.float64)
+    shape = tuple(int(v) for v in gold[prefix + "/shape"])
+    assert a.shape == shape, f"{what}{prefix}: shape {a.shape} vs golden {shape}"
+    if prefix + "/full" in gold:
+        g = gold[prefix + "/full"].astype(np.float64)
+        scale = max(np.abs(g).max(), 1e-30)
+        err = np.abs(a - g).max() / scale
+        assert err <= rtol, f"{what}{prefix}: max err/scale {err:.3e} > {rtol:.1e}"
+        return err
+    flat = a.reshape(-1)
+    gl2 = float(gold[prefix + "/l2"])
+    rms = max(gl2 / np.sqrt(flat.size), 1e-30)
+    l2 = np.sqrt((flat ** 2).sum())
+    e1 = abs(l2 - gl2) / max(gl2, 1e-30)
+    gs = gold[prefix + "/samples"].astype(np.float64)
+    e2 = np.abs(flat[sample_indices(flat.size)] - gs).max() / max(np.abs(gs).max(), rms)
+    assert e1 <= rtol, f"{what}{prefix}: l2 rel err {e1:.3e} > {rtol:.1e}"
+    assert e2 <= rtol * 4, f"{what}{prefix}: sample err/scale {e2:.3e} > {4*rtol:.1e}"
+    return max(e1, e2)
