@@ -1,0 +1,133 @@
+// C ABI of the convolution entry points (include/bp_hip.h): shape validation on the host, then
+// dispatch to the MFMA kernels (conv_igemm.hip / conv_wgrad.hip) or the direct ones.
+#include "common.hpp"
+
+int64_t bp_igemm_packed_floats(const ConvGeom& g);
+int bp_igemm_pack(const ConvGeom& g, const WeightMap& wm, const float* w_torch, float* packed, hipStream_t st);
+int bp_igemm_run(const ConvGeom& g, const bp_view* in, const PW& pw, const float* packed, const float* bias,
+                 const bp_view* out, hipStream_t st);
+int bp_direct_gather(const ConvGeom& g, const WeightMap& wm, const bp_view* in, const PW& pw, const float* w_torch,
+                     const float* bias, const bp_view* out, hipStream_t st);
+int bp_direct_wgrad(const bp_conv* cv, const bp_view* X, const PW& pwx, const bp_view* Y, const PW& pwy, float* dst,
+                    hipStream_t st);
+size_t bp_wgrad_mfma_workspace(const bp_conv* cv, const bp_view* X, const bp_view* Y);
+int bp_wgrad_mfma(const bp_conv* cv, const bp_view* X, const PW& pwx, const bp_view* Y, const PW& pwy, float* dst,
+                  void* workspace, size_t workspace_bytes, hipStream_t st);
+extern "C" int bp_sums_to_float(const double* sums, int32_t c, float* dst, void* stream);
+
+namespace {
+
+bool conv_ok(const bp_conv* cv) {
+  return cv && cv->cin > 0 && cv->cout > 0 && cv->k > 0 && cv->stride > 0 && cv->pad >= 0 && cv->out_pad >= 0 &&
+         (cv->transposed == 0 || cv->transposed == 1) && (cv->transposed || cv->out_pad == 0) &&
+         cv->out_pad < cv->stride + (cv->stride == 1);
+}
+
+// x: module input, y: module output
+bool shapes_ok(const bp_conv* cv, const bp_view* x, const bp_view* y) {
+  if (!bp_view_ok(x) || !bp_view_ok(y)) return false;
+  if (x->n != y->n || x->c != cv->cin || y->c != cv->cout) return false;
+  return y->h == bp_conv_out_extent(cv, x->h) && y->w == bp_conv_out_extent(cv, x->w) && y->h > 0 && y->w > 0;
+}
+
+size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+}  // namespace
+
+extern "C" {
+
+int bp_version(void) { return 100; }
+
+const char* bp_strerror(int code) {
+  switch (code) {
+    case BP_OK: return "ok";
+    case BP_EINVAL: return "invalid argument (null pointer or inconsistent shapes)";
+    case BP_EUNSUPPORTED: return "shape not supported by the gfx950 kernels";
+    case BP_ELAUNCH: return "kernel launch failed";
+    case BP_EWORKSPACE: return "workspace missing or too small";
+  }
+  return "unknown error";
+}
+
+int64_t bp_conv_packed_floats(const bp_conv* cv, int dir) {
+  if (!conv_ok(cv) || (dir != BP_PACK_FWD && dir != BP_PACK_BWD)) return -1;
+  const ConvGeom g = dir == BP_PACK_FWD ? bp_geom_forward(cv) : bp_geom_backward_data(cv);
+  return bp_igemm_packed_floats(g);
+}
+
+int bp_conv_pack(const bp_conv* cv, int dir, const float* w_torch, float* packed, void* stream) {
+  if (!conv_ok(cv) || !w_torch || !packed || (dir != BP_PACK_FWD && dir != BP_PACK_BWD)) return BP_EINVAL;
+  const ConvGeom g = dir == BP_PACK_FWD ? bp_geom_forward(cv) : bp_geom_backward_data(cv);
+  return bp_igemm_pack(g, bp_wmap(cv, dir), w_torch, packed, bp_stream(stream));
+}
+
+int bp_conv_forward(const bp_conv* cv, const bp_view* x, const bp_pointwise* x_pw, const float* packed_fwd,
+                    const float* w_torch, const float* bias, const bp_view* y, int impl, void* stream) {
+  if (!conv_ok(cv) || !shapes_ok(cv, x, y)) return BP_EINVAL;
+  const ConvGeom g = bp_geom_forward(cv);
+  if (impl == BP_IMPL_AUTO) impl = packed_fwd ? BP_IMPL_MFMA : BP_IMPL_DIRECT;
+  if (impl == BP_IMPL_MFMA) {
+    if (!packed_fwd) return BP_EINVAL;
+    return bp_igemm_run(g, x, bp_pw(x_pw), packed_fwd, bias, y, bp_stream(stream));
+  }
+  if (!w_torch) return BP_EINVAL;
+  return bp_direct_gather(g, bp_wmap(cv, BP_PACK_FWD), x, bp_pw(x_pw), w_torch, bias, y, bp_stream(stream));
+}
+
+int bp_conv_backward_data(const bp_conv* cv, const bp_view* dy, const float* packed_bwd, const float* w_torch,
+                          const bp_view* dx, int impl, void* stream) {
+  if (!conv_ok(cv) || !shapes_ok(cv, dx, dy)) return BP_EINVAL;
+  const ConvGeom g = bp_geom_backward_data(cv);
+  if (impl == BP_IMPL_AUTO) impl = packed_bwd ? BP_IMPL_MFMA : BP_IMPL_DIRECT;
+  if (impl == BP_IMPL_MFMA) {
+    if (!packed_bwd) return BP_EINVAL;
+    return bp_igemm_run(g, dy, PW{nullptr, nullptr, nullptr}, packed_bwd, nullptr, dx, bp_stream(stream));
+  }
+  if (!w_torch) return BP_EINVAL;
+  return bp_direct_gather(g, bp_wmap(cv, BP_PACK_BWD), dy, PW{nullptr, nullptr, nullptr}, w_torch, nullptr, dx,
+                          bp_stream(stream));
+}
+
+size_t bp_conv_backward_weight_workspace(const bp_conv* cv, const bp_view* x, const bp_view* dy) {
+  if (!conv_ok(cv) || !shapes_ok(cv, x, dy)) return 0;
+  const bp_view* X = cv->transposed ? dy : x;
+  const bp_view* Y = cv->transposed ? x : dy;
+  return align256(bp_wgrad_mfma_workspace(cv, X, Y)) + align256(bp_channel_sums_workspace(dy)) +
+         align256((size_t)2 * dy->c * sizeof(double));
+}
+
+int bp_conv_backward_weight(const bp_conv* cv, const bp_view* x, const bp_pointwise* x_pw, const bp_view* dy,
+                            float* dw_torch, float* dbias, void* workspace, size_t workspace_bytes, int impl,
+                            void* stream) {
+  if (!conv_ok(cv) || !shapes_ok(cv, x, dy) || !dw_torch) return BP_EINVAL;
+  const bp_view* X = cv->transposed ? dy : x;
+  const bp_view* Y = cv->transposed ? x : dy;
+  const PW none{nullptr, nullptr, nullptr};
+  const PW pwx = cv->transposed ? none : bp_pw(x_pw);
+  const PW pwy = cv->transposed ? bp_pw(x_pw) : none;
+  hipStream_t st = bp_stream(stream);
+  const size_t ws_main = align256(bp_wgrad_mfma_workspace(cv, X, Y));
+  if (impl == BP_IMPL_AUTO) impl = ws_main ? BP_IMPL_MFMA : BP_IMPL_DIRECT;
+  if (impl == BP_IMPL_MFMA || dbias) {
+    if (!workspace || workspace_bytes < bp_conv_backward_weight_workspace(cv, x, dy)) return BP_EWORKSPACE;
+  }
+  int rc;
+  if (impl == BP_IMPL_MFMA) {
+    if (!ws_main) return BP_EUNSUPPORTED;
+    rc = bp_wgrad_mfma(cv, X, pwx, Y, pwy, dw_torch, workspace, ws_main, st);
+  } else {
+    rc = bp_direct_wgrad(cv, X, pwx, Y, pwy, dw_torch, st);
+  }
+  if (rc != BP_OK) return rc;
+  if (dbias) {
+    char* base = reinterpret_cast<char*>(workspace) + ws_main;
+    const size_t ws_sums = align256(bp_channel_sums_workspace(dy));
+    double* sums = reinterpret_cast<double*>(base + ws_sums);
+    rc = bp_channel_sums(dy, sums, base, ws_sums, stream);
+    if (rc != BP_OK) return rc;
+    rc = bp_sums_to_float(sums, dy->c, dbias, stream);
+  }
+  return rc;
+}
+
+}  // extern "C"

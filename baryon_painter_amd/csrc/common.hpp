@@ -1,0 +1,117 @@
+// Shared host/device helpers for the gfx950 kernels (see include/bp_hip.h for the ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/bp_hip.h"
+
+#define BP_CHECK_LAUNCH()                                   \
+  do {                                                      \
+    if (hipGetLastError() != hipSuccess) return BP_ELAUNCH; \
+  } while (0)
+
+static inline hipStream_t bp_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+static inline bool bp_view_ok(const bp_view* v) {
+  return v && v->ptr && v->n > 0 && v->h > 0 && v->w > 0 && v->c > 0 && v->cstride >= v->c &&
+         v->coff >= 0 && v->coff + v->c <= v->cstride;
+}
+
+static inline int64_t bp_view_pixels(const bp_view* v) { return (int64_t)v->n * v->h * v->w; }
+
+static inline int bp_ceil_div(int a, int b) { return (a + b - 1) / b; }
+static inline int bp_round_up(int a, int b) { return bp_ceil_div(a, b) * b; }
+
+// Device copy of a pointwise; scale == nullptr -> identity.
+struct PW {
+  const float* scale;
+  const float* shift;
+  const float* slope;
+};
+static inline PW bp_pw(const bp_pointwise* p) {
+  PW r{nullptr, nullptr, nullptr};
+  if (p && p->scale) r = PW{p->scale, p->shift, p->slope};
+  return r;
+}
+
+__device__ __forceinline__ float pw_apply(const PW& pw, int ch, float x) {
+  if (pw.scale == nullptr) return x;
+  float t = fmaf(x, pw.scale[ch], pw.shift[ch]);
+  return t > 0.f ? t : t * pw.slope[ch];
+}
+
+// Geometry of one (transposed) convolution expressed as a stride-IS correlation over an output
+// sub-grid ("phase").  Conv2d: one phase, IS = stride, taps = k.  ConvTranspose2d / data-gradient
+// of a strided Conv2d: stride^2 phases with ceil(k/stride) taps each and IS = 1.
+//   out[n, oy0 + OS*qy, ox0 + OS*qx, :] = sum_{ty,tx,ci} in[n, IS*qy + iy0 + ty, IS*qx + ix0 + tx, ci]
+//                                                        * Wp[phase][ty][tx][ci][:]
+struct ConvGeom {
+  int gather_transposed;  // 0: conv form (F), 1: transposed form (T)
+  int k, stride, pad;
+  int cin_g, cout_g;      // channels of the gathered tensor / of the produced tensor
+  int nphase;             // phases per dimension (1 or stride)
+  int taps;               // taps per dimension per phase
+  int IS, OS;
+};
+
+// Which torch-layout weight element feeds gemm element (a = gathered channel, b = produced
+// channel, ky, kx):  w[a*sa + b*sb + ky*k + kx].
+struct WeightMap {
+  int64_t sa, sb;
+};
+
+// Forward of Conv2d or ConvTranspose2d.
+static inline ConvGeom bp_geom_forward(const bp_conv* cv) {
+  ConvGeom g{};
+  g.k = cv->k; g.stride = cv->stride; g.pad = cv->pad;
+  g.cin_g = cv->cin; g.cout_g = cv->cout;
+  if (!cv->transposed) {
+    g.gather_transposed = 0; g.nphase = 1; g.taps = cv->k; g.IS = cv->stride; g.OS = 1;
+  } else {
+    g.gather_transposed = 1; g.nphase = cv->stride; g.taps = (cv->k + cv->stride - 1) / cv->stride;
+    g.IS = 1; g.OS = cv->stride;
+  }
+  return g;
+}
+// Data gradient: the roles of the channel counts swap and the form flips.
+static inline ConvGeom bp_geom_backward_data(const bp_conv* cv) {
+  ConvGeom g{};
+  g.k = cv->k; g.stride = cv->stride; g.pad = cv->pad;
+  g.cin_g = cv->cout; g.cout_g = cv->cin;
+  if (!cv->transposed) {
+    g.gather_transposed = 1; g.nphase = cv->stride; g.taps = (cv->k + cv->stride - 1) / cv->stride;
+    g.IS = 1; g.OS = cv->stride;
+  } else {
+    g.gather_transposed = 0; g.nphase = 1; g.taps = cv->k; g.IS = cv->stride; g.OS = 1;
+  }
+  return g;
+}
+static inline WeightMap bp_wmap(const bp_conv* cv, int dir) {
+  const int64_t K = (int64_t)cv->k * cv->k;
+  WeightMap m{};
+  if (!cv->transposed) {           // [cout][cin][k][k]
+    if (dir == BP_PACK_FWD) { m.sa = K; m.sb = (int64_t)cv->cin * K; }   // a = ci, b = co
+    else { m.sa = (int64_t)cv->cin * K; m.sb = K; }                      // a = co, b = ci
+  } else {                         // [cin][cout][k][k]
+    if (dir == BP_PACK_FWD) { m.sa = (int64_t)cv->cout * K; m.sb = K; }  // a = ci, b = co
+    else { m.sa = K; m.sb = (int64_t)cv->cout * K; }                     // a = co, b = ci
+  }
+  return m;
+}
+
+// Output extent of the module's forward.
+static inline int bp_conv_out_extent(const bp_conv* cv, int in) {
+  if (!cv->transposed) return (in + 2 * cv->pad - cv->k) / cv->stride + 1;
+  return (in - 1) * cv->stride - 2 * cv->pad + cv->k + cv->out_pad;
+}
+
+// For the transposed form, phase p (0..stride-1) of the produced grid:
+//   residue r = (p + pad) % stride selects taps ky = r + stride*j (j = 0..taps-1, ky < k),
+//   gathered row = q + c - j with c = (p + pad) / stride.
+// Written as a correlation with ascending tap index t = taps-1-j:
+//   gathered row = q + (c - (taps-1)) + t,  ky(t) = r + stride*(taps-1-t).
+__host__ __device__ __forceinline__ int bp_t_i0(int p, int pad, int stride, int taps) {
+  return (p + pad) / stride - (taps - 1);
+}
+__host__ __device__ __forceinline__ int bp_t_ky(int p, int pad, int stride, int taps, int t) {
+  return (p + pad) % stride + stride * (taps - 1 - t);
+}

@@ -1,0 +1,220 @@
+// Weight gradient on the fp32 matrix cores (v_mfma_f32_16x16x4_f32), NHWC.
+//
+//   dst[cy][cx][ky][kx] = sum_{n,q} act(X)[n, q*s + k - p, cx] * act(Y)[n, q, cy]
+// X is the tensor on the fine grid (Conv2d: the layer input; ConvTranspose2d: the output
+// gradient), Y the one on the coarse grid (Conv2d: dy; ConvTranspose2d: the layer input); the
+// result is exactly the torch weight layout in both cases.
+//   GEMM view: M = 16 X-channels, N = 16 Y-channels, K = pixels (4 per MFMA).
+// A workgroup owns one kernel row ky, one 16-channel X tile and 16*NTY Y channels, and walks a
+// strided subset ("split") of the BH x 16 pixel tiles; its 4 waves take different pixel rows and
+// are summed through LDS at the end.  Partial results per split go to a workspace and a second
+// kernel adds them in a fixed order, so the gradient is bitwise reproducible (no float atomics).
+#include "common.hpp"
+
+namespace {
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+constexpr int WG_BH = 8;    // pixel rows per tile (2 per wave)
+constexpr int WG_BW = 16;   // pixel columns per tile
+constexpr int KW_MAX = 9;
+
+struct WgradArgs {
+  const float* X; int xh, xw, xcs, xco, cx;
+  const float* Y; int yh, yw, ycs, yco, cy;
+  int n, k, stride, pad;
+  PW pwx, pwy;
+  float* ws;
+  int ncxt, ncyg, nsplit, tiles_x, tiles_y, IW, IWq, CXP, CYP;
+};
+
+template <int NTY>
+__global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
+  constexpr int CYB = 16 * NTY;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int s = a.stride;
+  float* lds_x = smem;                                   // [BH][s][IWq][16]
+  float* lds_y = smem + (size_t)WG_BH * s * a.IWq * 16;  // [NTY][BH][BW][16]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, kq = lane >> 4;
+
+  const int cxt = blockIdx.x % a.ncxt;
+  const int cyg = blockIdx.x / a.ncxt;
+  const int ky = blockIdx.y;
+  const int split = blockIdx.z;
+  const int cx0 = cxt * 16, cy0 = cyg * CYB;
+
+  v4f acc[KW_MAX][NTY];
+#pragma unroll
+  for (int t = 0; t < KW_MAX; ++t)
+#pragma unroll
+    for (int nt = 0; nt < NTY; ++nt) acc[t][nt] = v4f{0.f, 0.f, 0.f, 0.f};
+
+  const int tiles_per_img = a.tiles_x * a.tiles_y;
+  const int ntiles = a.n * tiles_per_img;
+  for (int tile = split; tile < ntiles; tile += a.nsplit) {
+    const int n = tile / tiles_per_img;
+    const int ty_ = (tile % tiles_per_img) / a.tiles_x, tx_ = tile % a.tiles_x;
+    const int qy0 = ty_ * WG_BH, qx0 = tx_ * WG_BW;
+    __syncthreads();
+    // ---- stage X rows: row r <-> iy = (qy0+r)*s + ky - p, col c <-> ix = qx0*s - p + c
+    const float* Xn = a.X + (int64_t)n * a.xh * a.xw * a.xcs + a.xco;
+    for (int e = tid; e < WG_BH * a.IW * 16; e += 256) {
+      const int ch = e & 15;
+      const int c = (e >> 4) % a.IW;
+      const int r = (e >> 4) / a.IW;
+      const int iy = (qy0 + r) * s + ky - a.pad, ix = qx0 * s - a.pad + c;
+      float v = 0.f;
+      if (iy >= 0 && iy < a.xh && ix >= 0 && ix < a.xw && (qy0 + r) < a.yh && cx0 + ch < a.cx)
+        v = pw_apply(a.pwx, cx0 + ch, Xn[((int64_t)iy * a.xw + ix) * a.xcs + cx0 + ch]);
+      lds_x[((r * s + c % s) * a.IWq + c / s) * 16 + ch] = v;
+    }
+    // ---- stage Y tile
+    const float* Yn = a.Y + (int64_t)n * a.yh * a.yw * a.ycs + a.yco;
+    for (int e = tid; e < WG_BH * WG_BW * CYB; e += 256) {
+      const int ch = e % CYB;
+      const int c = (e / CYB) % WG_BW;
+      const int r = e / (CYB * WG_BW);
+      const int qy = qy0 + r, qx = qx0 + c;
+      float v = 0.f;
+      if (qy < a.yh && qx < a.yw && cy0 + ch < a.cy)
+        v = pw_apply(a.pwy, cy0 + ch, Yn[((int64_t)qy * a.yw + qx) * a.ycs + cy0 + ch]);
+      lds_y[(((ch >> 4) * WG_BH + r) * WG_BW + c) * 16 + (ch & 15)] = v;
+    }
+    __syncthreads();
+    // ---- this wave's rows: 2 rows x 4 pixel groups
+#pragma unroll
+    for (int rr = 0; rr < WG_BH / 4; ++rr) {
+      const int r = wave * (WG_BH / 4) + rr;
+#pragma unroll
+      for (int g = 0; g < WG_BW / 4; ++g) {
+        const int qxl = 4 * g + kq;
+        float bf[NTY];
+#pragma unroll
+        for (int nt = 0; nt < NTY; ++nt) bf[nt] = lds_y[((nt * WG_BH + r) * WG_BW + qxl) * 16 + li];
+#pragma unroll
+        for (int t = 0; t < KW_MAX; ++t) {
+          if (t < a.k) {
+            const float af = lds_x[((r * s + t % s) * a.IWq + qxl + t / s) * 16 + li];
+#pragma unroll
+            for (int nt = 0; nt < NTY; ++nt)
+              acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af, bf[nt], acc[t][nt], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+
+  // ---- sum the 4 waves through LDS and write this split's partial tile
+  //      D[row = 4*(lane>>4)+r : X channel][col = lane&15 : Y channel]
+  float* red = smem;  // [4 waves][NTY][64 lanes][4]
+#pragma unroll
+  for (int t = 0; t < KW_MAX; ++t) {
+    if (t < a.k) {
+      __syncthreads();
+#pragma unroll
+      for (int nt = 0; nt < NTY; ++nt)
+        *reinterpret_cast<float4*>(red + ((wave * NTY + nt) * 64 + lane) * 4) =
+            make_float4(acc[t][nt][0], acc[t][nt][1], acc[t][nt][2], acc[t][nt][3]);
+      __syncthreads();
+      for (int e = tid; e < NTY * 256; e += 256) {
+        const int nt = e / 256, l = (e % 256) / 4, r = e % 4;
+        float sum = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) sum += red[((w * NTY + nt) * 64 + l) * 4 + r];
+        const int cx = cx0 + 4 * (l >> 4) + r, cy = cy0 + nt * 16 + (l & 15);
+        a.ws[((((int64_t)split * a.k + ky) * a.k + t) * a.CYP + cy) * a.CXP + cx] = sum;
+      }
+    }
+  }
+}
+
+struct WreduceArgs {
+  const float* ws; float* dst;
+  int k, cx, cy, CXP, CYP, nsplit;
+};
+
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(WreduceArgs a) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t total = (int64_t)a.cy * a.cx * a.k * a.k;
+  if (i >= total) return;
+  const int kx = i % a.k;
+  const int ky = (i / a.k) % a.k;
+  const int cx = (i / (a.k * a.k)) % a.cx;
+  const int cy = i / ((int64_t)a.k * a.k * a.cx);
+  const int64_t stride = (int64_t)a.k * a.k * a.CYP * a.CXP;
+  const float* p = a.ws + (((int64_t)ky * a.k + kx) * a.CYP + cy) * a.CXP + cx;
+  double s = 0.0;
+  for (int sp = 0; sp < a.nsplit; ++sp) s += (double)p[sp * stride];
+  a.dst[i] = (float)s;
+}
+
+struct WgradPlan {
+  int NTY, ncxt, ncyg, nsplit, tiles_x, tiles_y, IW, IWq, CXP, CYP;
+  size_t lds_bytes, ws_bytes;
+  bool ok;
+};
+
+WgradPlan wgrad_plan(const bp_conv* cv, const bp_view* X, const bp_view* Y) {
+  WgradPlan p{};
+  if (cv->k > KW_MAX) return p;
+  p.NTY = (Y->c > 16) ? 2 : 1;
+  const int CYB = 16 * p.NTY;
+  p.ncxt = bp_ceil_div(X->c, 16);
+  p.ncyg = bp_ceil_div(Y->c, CYB);
+  p.CXP = p.ncxt * 16;
+  p.CYP = p.ncyg * CYB;
+  p.tiles_x = bp_ceil_div(Y->w, WG_BW);
+  p.tiles_y = bp_ceil_div(Y->h, WG_BH);
+  const int64_t ntiles = (int64_t)Y->n * p.tiles_x * p.tiles_y;
+  const int64_t base = (int64_t)p.ncxt * p.ncyg * cv->k;
+  int64_t ns = (2048 + base - 1) / base;
+  if (ns > ntiles) ns = ntiles;
+  if (ns < 1) ns = 1;
+  if (ns > 65535) ns = 65535;
+  p.nsplit = (int)ns;
+  p.IW = (WG_BW - 1) * cv->stride + cv->k;
+  p.IWq = bp_ceil_div(p.IW, cv->stride);
+  const size_t lds_main = ((size_t)WG_BH * cv->stride * p.IWq * 16 + (size_t)p.NTY * WG_BH * WG_BW * 16) * 4;
+  const size_t lds_red = (size_t)4 * p.NTY * 64 * 4 * 4;
+  p.lds_bytes = lds_main > lds_red ? lds_main : lds_red;
+  p.ws_bytes = (size_t)p.nsplit * cv->k * cv->k * p.CYP * p.CXP * sizeof(float);
+  p.ok = p.lds_bytes <= 64 * 1024;
+  return p;
+}
+
+}  // namespace
+
+size_t bp_wgrad_mfma_workspace(const bp_conv* cv, const bp_view* X, const bp_view* Y) {
+  const WgradPlan p = wgrad_plan(cv, X, Y);
+  return p.ok ? p.ws_bytes : 0;
+}
+
+int bp_wgrad_mfma(const bp_conv* cv, const bp_view* X, const PW& pwx, const bp_view* Y, const PW& pwy,
+                  float* dst, void* workspace, size_t workspace_bytes, hipStream_t st) {
+  const WgradPlan p = wgrad_plan(cv, X, Y);
+  if (!p.ok) return BP_EUNSUPPORTED;
+  if (!workspace || workspace_bytes < p.ws_bytes) return BP_EWORKSPACE;
+  WgradArgs a{};
+  a.X = X->ptr; a.xh = X->h; a.xw = X->w; a.xcs = X->cstride; a.xco = X->coff; a.cx = X->c;
+  a.Y = Y->ptr; a.yh = Y->h; a.yw = Y->w; a.ycs = Y->cstride; a.yco = Y->coff; a.cy = Y->c;
+  a.n = X->n; a.k = cv->k; a.stride = cv->stride; a.pad = cv->pad; a.pwx = pwx; a.pwy = pwy;
+  a.ws = reinterpret_cast<float*>(workspace);
+  a.ncxt = p.ncxt; a.ncyg = p.ncyg; a.nsplit = p.nsplit; a.tiles_x = p.tiles_x; a.tiles_y = p.tiles_y;
+  a.IW = p.IW; a.IWq = p.IWq; a.CXP = p.CXP; a.CYP = p.CYP;
+  dim3 grid((unsigned)(p.ncxt * p.ncyg), (unsigned)cv->k, (unsigned)p.nsplit);
+  if (p.NTY == 2)
+    hipLaunchKernelGGL((wgrad_kernel<2>), grid, dim3(256), p.lds_bytes, st, a);
+  else
+    hipLaunchKernelGGL((wgrad_kernel<1>), grid, dim3(256), p.lds_bytes, st, a);
+  BP_CHECK_LAUNCH();
+  WreduceArgs r{};
+  r.ws = a.ws; r.dst = dst; r.k = cv->k; r.cx = X->c; r.cy = Y->c; r.CXP = p.CXP; r.CYP = p.CYP;
+  r.nsplit = p.nsplit;
+  const int64_t total = (int64_t)Y->c * X->c * cv->k * cv->k;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, r);
+  BP_CHECK_LAUNCH();
+  return BP_OK;
+}

@@ -1,0 +1,723 @@
+// HBM-bound kernels of the path: per-channel reductions (batch-norm statistics, activation /
+// batch-norm backward sums), the residual tail, layout glue, the latent sampler + KL, the Gaussian
+// log-likelihood head and Adam.  All reductions are two-stage (per-block partials in a caller
+// workspace, then a fixed-order sum in double), so results are bitwise reproducible.
+#include "common.hpp"
+#include <math.h>
+
+namespace {
+
+constexpr int RB = 256;          // threads per block
+constexpr int MAX_RBLOCKS = 1024;  // stage-1 blocks of a reduction
+
+static inline int h_next_pow2(int c) {
+  int p = 1;
+  while (p < c) p <<= 1;
+  return p;
+}
+
+struct ViewD {
+  float* p; int h, w, c, cs, co; int64_t npix;
+};
+static inline ViewD vd(const bp_view* v) {
+  ViewD d{};
+  if (v) { d.p = v->ptr; d.h = v->h; d.w = v->w; d.c = v->c; d.cs = v->cstride; d.co = v->coff; d.npix = bp_view_pixels(v); }
+  return d;
+}
+
+// ---------------------------------------------------------------- channel sums {sum x, sum x^2}
+__global__ __launch_bounds__(RB) void channel_sums_kernel(ViewD x, int cbase, int CP, int64_t pix_per_block,
+                                                          double* partial /* [nblk][2][c] */) {
+  __shared__ double sh[RB];
+  const int tid = threadIdx.x;
+  const int ch = cbase + tid % CP, slot = tid / CP, slots = RB / CP;
+  const int64_t p0 = (int64_t)blockIdx.x * pix_per_block;
+  int64_t p1 = p0 + pix_per_block;
+  if (p1 > x.npix) p1 = x.npix;
+  double v[2] = {0.0, 0.0};
+  if (ch < x.c) {
+    for (int64_t p = p0 + slot; p < p1; p += slots) {
+      const double t = x.p[p * x.cs + x.co + ch];
+      v[0] += t;
+      v[1] += t * t;
+    }
+  }
+  // channels of this pass are [cbase, cbase+CP); write at their absolute index
+  __syncthreads();
+  for (int s = 0; s < 2; ++s) {
+    __syncthreads();
+    sh[tid] = v[s];
+    __syncthreads();
+    if (slot == 0 && ch < x.c) {
+      double t = 0.0;
+      for (int k = 0; k < slots; ++k) t += sh[k * CP + tid % CP];
+      partial[((int64_t)blockIdx.x * 2 + s) * x.c + ch] = t;
+    }
+  }
+}
+
+__global__ __launch_bounds__(RB) void sum_partials_kernel(const double* partial, int nblk, int n, double* out) {
+  const int i = blockIdx.x * RB + threadIdx.x;
+  if (i >= n) return;
+  double t = 0.0;
+  for (int b = 0; b < nblk; ++b) t += partial[(int64_t)b * n + i];
+  out[i] = t;
+}
+
+// ---------------------------------------------------------------- batch-norm finalize
+__global__ void bn_finalize_kernel(const double* sums, double count, int c, const float* gamma,
+                                   const float* beta, float eps, float momentum, float* rm, float* rv,
+                                   int64_t* nbt, float* scale, float* shift, float* smean, float* sinv) {
+  const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ch == 0 && nbt) *nbt += 1;
+  if (ch >= c) return;
+  const double mean = sums[ch] / count;
+  double var = sums[c + ch] / count - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const double invstd = 1.0 / sqrt(var + (double)eps);
+  const double g = gamma ? (double)gamma[ch] : 1.0, b = beta ? (double)beta[ch] : 0.0;
+  scale[ch] = (float)(g * invstd);
+  shift[ch] = (float)(b - mean * g * invstd);
+  if (smean) smean[ch] = (float)mean;
+  if (sinv) sinv[ch] = (float)invstd;
+  if (rm) rm[ch] = (float)((1.0 - momentum) * rm[ch] + momentum * mean);
+  if (rv) {
+    const double unb = count > 1.0 ? var * (count / (count - 1.0)) : var;
+    rv[ch] = (float)((1.0 - momentum) * rv[ch] + momentum * unb);
+  }
+}
+
+__global__ void bn_eval_kernel(int c, const float* gamma, const float* beta, const float* rm,
+                               const float* rv, float eps, float* scale, float* shift) {
+  const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ch >= c) return;
+  const float g = gamma ? gamma[ch] : 1.f, b = beta ? beta[ch] : 0.f;
+  const float s = g / sqrtf(rv[ch] + eps);
+  scale[ch] = s;
+  shift[ch] = b - rm[ch] * s;
+}
+
+// ---------------------------------------------------------------- activation backward + sums
+struct ActBwdArgs {
+  ViewD dout, dout2, raw, aout, g;
+  PW pw;
+  int cbase, CP;
+  int64_t pix_per_block;
+  double* partial;  // [nblk][3][c]
+};
+
+__global__ __launch_bounds__(RB) void act_backward_kernel(ActBwdArgs a) {
+  __shared__ double sh[RB];
+  const int tid = threadIdx.x;
+  const int CP = a.CP;
+  const int ch = a.cbase + tid % CP, slot = tid / CP, slots = RB / CP;
+  const int c = a.raw.c;
+  const int64_t p0 = (int64_t)blockIdx.x * a.pix_per_block;
+  int64_t p1 = p0 + a.pix_per_block;
+  if (p1 > a.raw.npix) p1 = a.raw.npix;
+  double v[3] = {0.0, 0.0, 0.0};
+  if (ch < c) {
+    float sc = 1.f, sf = 0.f, sl = 1.f;
+    if (a.pw.scale) { sc = a.pw.scale[ch]; sf = a.pw.shift[ch]; sl = a.pw.slope[ch]; }
+    for (int64_t p = p0 + slot; p < p1; p += slots) {
+      float d = a.dout.p[p * a.dout.cs + a.dout.co + ch];
+      if (a.dout2.p) d += a.dout2.p[p * a.dout2.cs + a.dout2.co + ch];
+      const float r = a.raw.p[p * a.raw.cs + a.raw.co + ch];
+      const float t = fmaf(r, sc, sf);
+      const float sgn = a.aout.p ? a.aout.p[p * a.aout.cs + a.aout.co + ch] : t;
+      const bool pos = sgn > 0.f;
+      const float g = pos ? d : d * sl;
+      a.g.p[p * a.g.cs + a.g.co + ch] = g;
+      v[0] += g;
+      v[1] += (double)g * r;
+      if (!pos) v[2] += (double)d * t;
+    }
+  }
+  for (int s = 0; s < 3; ++s) {
+    __syncthreads();
+    sh[tid] = v[s];
+    __syncthreads();
+    if (slot == 0 && ch < c) {
+      double t = 0.0;
+      for (int k = 0; k < slots; ++k) t += sh[k * CP + tid % CP];
+      a.partial[((int64_t)blockIdx.x * 3 + s) * c + ch] = t;
+    }
+  }
+}
+
+__global__ void bn_backward_finalize_kernel(const double* sums, double count, int c, const float* gamma,
+                                            const float* smean, const float* sinv, float* dgamma,
+                                            float* dbeta, float* abc) {
+  const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ch >= c) return;
+  const double S0 = sums[ch], S1 = sums[c + ch];
+  const double mean = smean[ch], inv = sinv[ch], g = gamma ? (double)gamma[ch] : 1.0;
+  const double dg = inv * (S1 - mean * S0);
+  if (dgamma) dgamma[ch] = (float)dg;
+  if (dbeta) dbeta[ch] = (float)S0;
+  // d_raw = g*inv*(gr - S0/n - xhat*dg/n),  xhat = (raw-mean)*inv
+  const double A = g * inv;
+  const double B = -g * inv * inv * dg / count;
+  const double C = -g * inv * S0 / count + g * inv * inv * mean * dg / count;
+  abc[ch] = (float)A;
+  abc[c + ch] = (float)B;
+  abc[2 * c + ch] = (float)C;
+}
+
+__global__ __launch_bounds__(RB) void bn_backward_apply_kernel(ViewD g, ViewD raw, const float* abc, ViewD out,
+                                                               int64_t total) {
+  const int64_t i = (int64_t)blockIdx.x * RB + threadIdx.x;
+  if (i >= total) return;
+  const int c = g.c;
+  const int ch = i % c;
+  const int64_t p = i / c;
+  const float gv = g.p[p * g.cs + g.co + ch];
+  const float r = raw.p[p * raw.cs + raw.co + ch];
+  out.p[p * out.cs + out.co + ch] = fmaf(abc[ch], gv, fmaf(abc[c + ch], r, abc[2 * c + ch]));
+}
+
+__global__ void prelu_slope_grad_kernel(const double* sums, int c, float* dslope) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    double t = 0.0;
+    for (int ch = 0; ch < c; ++ch) t += sums[2 * c + ch];
+    *dslope = (float)t;
+  }
+}
+
+__global__ void sums_to_float_kernel(const double* sums, int c, float* dst) {
+  const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ch < c) dst[ch] = (float)sums[ch];
+}
+
+// ---------------------------------------------------------------- residual tail
+__global__ __launch_bounds__(RB) void residual_forward_kernel(ViewD raw, PW pw, ViewD skip, PW spw, float slope,
+                                                              ViewD out, int64_t total) {
+  const int64_t i = (int64_t)blockIdx.x * RB + threadIdx.x;
+  if (i >= total) return;
+  const int c = raw.c;
+  const int ch = i % c;
+  const int64_t p = i / c;
+  float t = raw.p[p * raw.cs + raw.co + ch];
+  if (pw.scale) t = fmaf(t, pw.scale[ch], pw.shift[ch]);
+  t += pw_apply(spw, ch, skip.p[p * skip.cs + skip.co + ch]);
+  out.p[p * out.cs + out.co + ch] = t > 0.f ? t : t * slope;
+}
+
+// ---------------------------------------------------------------- layout glue
+__global__ __launch_bounds__(RB) void nchw_to_view_kernel(const float* src, int c, const float* aux, int caux,
+                                                          ViewD out, int n, int64_t total) {
+  const int64_t i = (int64_t)blockIdx.x * RB + threadIdx.x;
+  if (i >= total) return;
+  const int ct = c + caux;
+  const int ch = i % ct;
+  const int64_t p = i / ct;
+  const int64_t hw = (int64_t)out.h * out.w;
+  const int64_t nn = p / hw, yx = p % hw;
+  float v;
+  if (ch < c) v = src[(nn * c + ch) * hw + yx];
+  else v = aux[nn * caux + (ch - c)];
+  out.p[p * out.cs + out.co + ch] = v;
+}
+
+__device__ __forceinline__ float softplus_f(float x) { return x > 20.f ? x : log1pf(expf(x)); }
+__device__ __forceinline__ float softplus_grad_f(float x) { return x > 20.f ? 1.f : 1.f / (1.f + expf(-x)); }
+
+__global__ __launch_bounds__(RB) void view_to_nchw_kernel(ViewD src, PW pw, int softplus, float* dst, int64_t total) {
+  const int64_t i = (int64_t)blockIdx.x * RB + threadIdx.x;
+  if (i >= total) return;
+  const int c = src.c;
+  const int64_t hw = (int64_t)src.h * src.w;
+  // i indexes the NCHW destination (coalesced writes)
+  const int64_t yx = i % hw;
+  const int ch = (i / hw) % c;
+  const int64_t nn = i / (hw * c);
+  const float v = pw_apply(pw, ch, src.p[(nn * hw + yx) * src.cs + src.co + ch]);
+  dst[i] = softplus ? softplus_f(v) : v;
+}
+
+__global__ __launch_bounds__(RB) void fill_kernel(float* dst, int64_t n, float v) {
+  const int64_t i = (int64_t)blockIdx.x * RB + threadIdx.x;
+  if (i < n) dst[i] = v;
+}
+
+// ---------------------------------------------------------------- latent sampler + KL
+struct LatentArgs {
+  bp_latent lt;
+  ViewD q, p, z;
+  PW qpw, ppw;
+  const float* eps;
+  float* stats4;
+  double* partial;
+  int64_t nelem;  // N*zc*zh*zw
+};
+
+__global__ __launch_bounds__(RB) void latent_forward_kernel(LatentArgs a) {
+  __shared__ double sh[RB];
+  const int zc = a.lt.zc, zh = a.lt.zh, zw = a.lt.zw;
+  const int64_t hw = (int64_t)zh * zw;
+  double kl = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * RB + threadIdx.x; i < a.nelem; i += (int64_t)gridDim.x * RB) {
+    // i indexes (n, c, h, w)
+    const int64_t yx = i % hw;
+    const int c = (i / hw) % zc;
+    const int64_t n = i / (hw * zc);
+    const int64_t pix = n * hw + yx;
+    const float mu = pw_apply(a.qpw, c, a.q.p[pix * a.q.cs + a.q.co + c]);
+    const float lv = pw_apply(a.qpw, zc + c, a.q.p[pix * a.q.cs + a.q.co + zc + c]);
+    float pm = 0.f, plv = 0.f;
+    if (a.p.p) {
+      pm = pw_apply(a.ppw, c, a.p.p[pix * a.p.cs + a.p.co + c]);
+      plv = pw_apply(a.ppw, zc + c, a.p.p[pix * a.p.cs + a.p.co + zc + c]);
+    }
+    a.stats4[i] = mu;
+    a.stats4[a.nelem + i] = lv;
+    a.stats4[2 * a.nelem + i] = pm;
+    a.stats4[3 * a.nelem + i] = plv;
+    const float pvar = expf(plv);
+    const float dm = pm - mu;
+    kl += (double)(dm * dm / pvar + expf(lv) / pvar + plv - lv - 1.f);
+    const float sd = expf(lv * 0.5f) + a.lt.min_z_var;
+    for (int l = 0; l < a.lt.L; ++l) {
+      const float e = a.eps[(int64_t)l * a.nelem + i];
+      const int64_t zp = ((int64_t)l * a.lt.n + n) * hw + yx;
+      a.z.p[zp * a.z.cs + a.z.co + c] = fmaf(e, sd, mu);
+    }
+  }
+  sh[threadIdx.x] = kl;
+  __syncthreads();
+  for (int s = RB / 2; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) a.partial[blockIdx.x] = sh[0];
+}
+
+struct LatentBwdArgs {
+  bp_latent lt;
+  ViewD dz, dq, dp;
+  const float* stats4; const float* eps; const float* seed;
+  float beta_kl;
+  int64_t nelem;
+};
+
+__global__ __launch_bounds__(RB) void latent_backward_kernel(LatentBwdArgs a) {
+  const int64_t i = (int64_t)blockIdx.x * RB + threadIdx.x;
+  if (i >= a.nelem) return;
+  const int zc = a.lt.zc;
+  const int64_t hw = (int64_t)a.lt.zh * a.lt.zw;
+  const int64_t yx = i % hw;
+  const int c = (i / hw) % zc;
+  const int64_t n = i / (hw * zc);
+  const int64_t pix = n * hw + yx;
+  const float mu = a.stats4[i], lv = a.stats4[a.nelem + i];
+  const float pm = a.stats4[2 * a.nelem + i], plv = a.stats4[3 * a.nelem + i];
+  const float sd = expf(lv * 0.5f);
+  float dmu = 0.f, dlv = 0.f;
+  for (int l = 0; l < a.lt.L; ++l) {
+    const int64_t zp = ((int64_t)l * a.lt.n + n) * hw + yx;
+    const float d = a.dz.p[zp * a.dz.cs + a.dz.co + c];
+    dmu += d;
+    dlv += d * a.eps[(int64_t)l * a.nelem + i];
+  }
+  dlv *= 0.5f * sd;
+  const float k = -(*a.seed) * a.beta_kl * 0.5f / (float)a.lt.n;
+  const float pvar = expf(plv), dm = pm - mu, ev = expf(lv);
+  dmu += k * (-2.f * dm / pvar);
+  dlv += k * (ev / pvar - 1.f);
+  a.dq.p[pix * a.dq.cs + a.dq.co + c] = dmu;
+  a.dq.p[pix * a.dq.cs + a.dq.co + zc + c] = dlv;
+  if (a.dp.p) {
+    a.dp.p[pix * a.dp.cs + a.dp.co + c] = k * (2.f * dm / pvar);
+    a.dp.p[pix * a.dp.cs + a.dp.co + zc + c] = k * (-dm * dm / pvar - ev / pvar + 1.f);
+  }
+}
+
+// ---------------------------------------------------------------- Gaussian log-likelihood head
+
+struct LoglikArgs {
+  bp_loglik ll;
+  const float* x;
+  ViewD mu, var;
+  float* x_mu; float* x_lv;
+  double* partial;  // [nblk][2][c]
+  int CP;
+  int64_t pix_per_block, npix;  // pixels of the (L*M,H,W) grid
+};
+
+__global__ __launch_bounds__(RB) void loglik_forward_kernel(LoglikArgs a) {
+  __shared__ double sh[RB];
+  const int tid = threadIdx.x;
+  const int CP = a.CP, c = a.ll.c;
+  const int ch = tid % CP, slot = tid / CP, slots = RB / CP;
+  const int64_t hw = (int64_t)a.ll.h * a.ll.w;
+  const int64_t p0 = (int64_t)blockIdx.x * a.pix_per_block;
+  int64_t p1 = p0 + a.pix_per_block;
+  if (p1 > a.npix) p1 = a.npix;
+  double v[2] = {0.0, 0.0};
+  if (ch < c) {
+    for (int64_t p = p0 + slot; p < p1; p += slots) {
+      const int64_t lm = p / hw, yx = p % hw;
+      const int64_t m = lm % a.ll.n;
+      const float raw = a.mu.p[p * a.mu.cs + a.mu.co + ch];
+      const float xm = a.ll.mu_softplus ? softplus_f(raw) : raw;
+      a.x_mu[(lm * c + ch) * hw + yx] = xm;
+      const float d = a.x[(m * c + ch) * hw + yx] - xm;
+      v[0] += (double)(-0.5f * d * d);
+      if (a.ll.predict_var) {
+        const float lv = a.var.p[p * a.var.cs + a.var.co + ch];
+        if (a.x_lv) a.x_lv[(lm * c + ch) * hw + yx] = lv;
+        v[1] += (double)(-0.5f * lv - 0.5f * d * d / expf(lv));
+      }
+    }
+  }
+  for (int s = 0; s < 2; ++s) {
+    __syncthreads();
+    sh[tid] = v[s];
+    __syncthreads();
+    if (slot == 0 && ch < c) {
+      double t = 0.0;
+      for (int k = 0; k < slots; ++k) t += sh[k * CP + ch];
+      a.partial[((int64_t)blockIdx.x * 2 + s) * c + ch] = t;
+    }
+  }
+}
+
+__global__ void loglik_finalize_kernel(bp_loglik ll, const double* partial, int nblk, const double* kl_sum,
+                                       float* stats) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const int c = ll.c;
+  const double norm = (double)ll.n * ll.L;
+  const double c0 = -0.5 * log(2.0 * M_PI);
+  double total = 0.0;
+  for (int ch = 0; ch < c; ++ch) {
+    double sf = 0.0, sv = 0.0;
+    for (int b = 0; b < nblk; ++b) {
+      sf += partial[((int64_t)b * 2 + 0) * c + ch];
+      sv += partial[((int64_t)b * 2 + 1) * c + ch];
+    }
+    const double fixed = c0 + sf / norm;
+    const double freev = c0 + sv / norm;
+    const double llk = ll.predict_var ? (1.0 - ll.alpha_var) * fixed + ll.alpha_var * freev : fixed;
+    stats[2 + ch] = (float)llk;
+    stats[2 + c + ch] = (float)fixed;
+    stats[2 + 2 * c + ch] = (float)(ll.predict_var ? freev : 0.0);
+    total += llk;
+  }
+  const double kl = kl_sum ? 0.5 / (double)ll.n * (*kl_sum) : 0.0;
+  stats[1] = (float)kl;
+  stats[0] = (float)(-kl * ll.beta_kl + ll.likelihood_scaling * total);
+}
+
+struct LoglikBwdArgs {
+  bp_loglik ll;
+  const float* x; const float* seed;
+  ViewD mu, var, dmu, dvar;
+  int64_t total;
+};
+
+__global__ __launch_bounds__(RB) void loglik_backward_kernel(LoglikBwdArgs a) {
+  const int64_t i = (int64_t)blockIdx.x * RB + threadIdx.x;
+  if (i >= a.total) return;
+  const int c = a.ll.c;
+  const int ch = i % c;
+  const int64_t p = i / c;
+  const int64_t hw = (int64_t)a.ll.h * a.ll.w;
+  const int64_t lm = p / hw, yx = p % hw, m = lm % a.ll.n;
+  const float raw = a.mu.p[p * a.mu.cs + a.mu.co + ch];
+  const float xm = a.ll.mu_softplus ? softplus_f(raw) : raw;
+  const float dact = a.ll.mu_softplus ? softplus_grad_f(raw) : 1.f;
+  const float d = a.x[(m * c + ch) * hw + yx] - xm;
+  const float s = (*a.seed) * a.ll.likelihood_scaling / ((float)a.ll.n * (float)a.ll.L);
+  if (a.ll.predict_var) {
+    const float lv = a.var.p[p * a.var.cs + a.var.co + ch];
+    const float xv = expf(lv);
+    const float al = a.ll.alpha_var;
+    a.dmu.p[p * a.dmu.cs + a.dmu.co + ch] = s * ((1.f - al) * d + al * d / xv) * dact;
+    a.dvar.p[p * a.dvar.cs + a.dvar.co + ch] = s * al * (-0.5f + 0.5f * d * d / xv);
+  } else {
+    a.dmu.p[p * a.dmu.cs + a.dmu.co + ch] = s * d * dact;
+  }
+}
+
+// ---------------------------------------------------------------- Adam
+__global__ __launch_bounds__(RB) void adam_kernel(float* p, const float* g, float* m, float* v, int64_t n,
+                                                  float lr, float b1, float b2, float eps, float bc1,
+                                                  float bc2_sqrt) {
+  const int64_t i = (int64_t)blockIdx.x * RB + threadIdx.x;
+  if (i >= n) return;
+  const float gi = g[i];
+  const float mi = b1 * m[i] + (1.f - b1) * gi;      // exp_avg.lerp_(grad, 1-beta1)
+  const float vi = b2 * v[i] + (1.f - b2) * gi * gi;  // exp_avg_sq.mul_(b2).addcmul_(g,g,1-b2)
+  m[i] = mi;
+  v[i] = vi;
+  const float denom = sqrtf(vi) / bc2_sqrt + eps;
+  p[i] -= (lr / bc1) * (mi / denom);
+}
+
+struct RedPlan { int CP, npass, nblk; int64_t ppb; };
+static inline RedPlan red_plan(int c, int64_t npix) {
+  RedPlan r{};
+  r.CP = h_next_pow2(c < RB ? c : RB);
+  r.npass = bp_ceil_div(c, r.CP);
+  int64_t nb = (npix + 2047) / 2048;
+  if (nb > MAX_RBLOCKS) nb = MAX_RBLOCKS;
+  if (nb < 1) nb = 1;
+  r.ppb = (npix + nb - 1) / nb;
+  r.nblk = (int)((npix + r.ppb - 1) / r.ppb);
+  return r;
+}
+static inline unsigned nblocks(int64_t total) { return (unsigned)((total + RB - 1) / RB); }
+
+}  // namespace
+
+extern "C" {
+
+size_t bp_channel_sums_workspace(const bp_view* x) {
+  if (!bp_view_ok(x)) return 0;
+  const RedPlan r = red_plan(x->c, bp_view_pixels(x));
+  return (size_t)r.nblk * 2 * x->c * sizeof(double);
+}
+
+int bp_channel_sums(const bp_view* x, double* sums, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!bp_view_ok(x) || !sums) return BP_EINVAL;
+  if (!workspace || workspace_bytes < bp_channel_sums_workspace(x)) return BP_EWORKSPACE;
+  const RedPlan r = red_plan(x->c, bp_view_pixels(x));
+  hipStream_t st = bp_stream(stream);
+  double* partial = reinterpret_cast<double*>(workspace);
+  for (int pass = 0; pass < r.npass; ++pass) {
+    hipLaunchKernelGGL(channel_sums_kernel, dim3(r.nblk), dim3(RB), 0, st, vd(x), pass * r.CP, r.CP, r.ppb, partial);
+    BP_CHECK_LAUNCH();
+  }
+  hipLaunchKernelGGL(sum_partials_kernel, dim3(bp_ceil_div(2 * x->c, RB)), dim3(RB), 0, st, partial, r.nblk,
+                     2 * x->c, sums);
+  BP_CHECK_LAUNCH();
+  return BP_OK;
+}
+
+int bp_bn_finalize(const double* sums, double count, int32_t c, const float* gamma, const float* beta, float eps,
+                   float momentum, float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                   float* scale, float* shift, float* save_mean, float* save_invstd, void* stream) {
+  if (!sums || c <= 0 || count <= 0 || !scale || !shift) return BP_EINVAL;
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(bp_ceil_div(c, 64)), dim3(64), 0, bp_stream(stream), sums, count, c,
+                     gamma, beta, eps, momentum, running_mean, running_var, num_batches_tracked, scale, shift,
+                     save_mean, save_invstd);
+  BP_CHECK_LAUNCH();
+  return BP_OK;
+}
+
+int bp_bn_eval_pointwise(int32_t c, const float* gamma, const float* beta, const float* running_mean,
+                         const float* running_var, float eps, float* scale, float* shift, void* stream) {
+  if (c <= 0 || !running_mean || !running_var || !scale || !shift) return BP_EINVAL;
+  hipLaunchKernelGGL(bn_eval_kernel, dim3(bp_ceil_div(c, 64)), dim3(64), 0, bp_stream(stream), c, gamma, beta,
+                     running_mean, running_var, eps, scale, shift);
+  BP_CHECK_LAUNCH();
+  return BP_OK;
+}
+
+size_t bp_act_backward_workspace(const bp_view* raw) {
+  if (!bp_view_ok(raw)) return 0;
+  const RedPlan r = red_plan(raw->c, bp_view_pixels(raw));
+  return (size_t)r.nblk * 3 * raw->c * sizeof(double);
+}
+
+static bool same_grid(const bp_view* a, const bp_view* b) {
+  return a->n == b->n && a->h == b->h && a->w == b->w && a->c == b->c;
+}
+
+int bp_act_backward(const bp_view* dout, const bp_view* dout2, const bp_view* raw, const bp_pointwise* pw,
+                    const bp_view* act_out, const bp_view* g, double* sums, void* workspace,
+                    size_t workspace_bytes, void* stream) {
+  if (!bp_view_ok(dout) || !bp_view_ok(raw) || !bp_view_ok(g) || !sums) return BP_EINVAL;
+  if (!same_grid(dout, raw) || !same_grid(g, raw)) return BP_EINVAL;
+  if (dout2 && (!bp_view_ok(dout2) || !same_grid(dout2, raw))) return BP_EINVAL;
+  if (act_out && (!bp_view_ok(act_out) || !same_grid(act_out, raw))) return BP_EINVAL;
+  if (!workspace || workspace_bytes < bp_act_backward_workspace(raw)) return BP_EWORKSPACE;
+  const RedPlan r = red_plan(raw->c, bp_view_pixels(raw));
+  hipStream_t st = bp_stream(stream);
+  ActBwdArgs a{};
+  a.dout = vd(dout); a.dout2 = vd(dout2); a.raw = vd(raw); a.aout = vd(act_out); a.g = vd(g);
+  a.pw = bp_pw(pw); a.CP = r.CP; a.pix_per_block = r.ppb; a.partial = reinterpret_cast<double*>(workspace);
+  for (int pass = 0; pass < r.npass; ++pass) {
+    a.cbase = pass * r.CP;
+    hipLaunchKernelGGL(act_backward_kernel, dim3(r.nblk), dim3(RB), 0, st, a);
+    BP_CHECK_LAUNCH();
+  }
+  hipLaunchKernelGGL(sum_partials_kernel, dim3(bp_ceil_div(3 * raw->c, RB)), dim3(RB), 0, st, a.partial, r.nblk,
+                     3 * raw->c, sums);
+  BP_CHECK_LAUNCH();
+  return BP_OK;
+}
+
+int bp_bn_backward_finalize(const double* sums, double count, int32_t c, const float* gamma,
+                            const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta,
+                            float* coef_abc, void* stream) {
+  if (!sums || c <= 0 || count <= 0 || !save_mean || !save_invstd || !coef_abc) return BP_EINVAL;
+  hipLaunchKernelGGL(bn_backward_finalize_kernel, dim3(bp_ceil_div(c, 64)), dim3(64), 0, bp_stream(stream), sums,
+                     count, c, gamma, save_mean, save_invstd, dgamma, dbeta, coef_abc);
+  BP_CHECK_LAUNCH();
+  return BP_OK;
+}
+
+int bp_bn_backward_apply(const bp_view* g, const bp_view* raw, const float* coef_abc, const bp_view* out,
+                         void* stream) {
+  if (!bp_view_ok(g) || !bp_view_ok(raw) || !bp_view_ok(out) || !same_grid(g, raw) || !same_grid(g, out) ||
+      !coef_abc)
+    return BP_EINVAL;
+  const int64_t total = bp_view_pixels(g) * g->c;
+  hipLaunchKernelGGL(bn_backward_apply_kernel, dim3(nblocks(total)), dim3(RB), 0, bp_stream(stream), vd(g), vd(raw),
+                     coef_abc, vd(out), total);
+  BP_CHECK_LAUNCH();
+  return BP_OK;
+}
+
+int bp_prelu_slope_grad(const double* sums, int32_t c, float* dslope, void* stream) {
+  if (!sums || c <= 0 || !dslope) return BP_EINVAL;
+  hipLaunchKernelGGL(prelu_slope_grad_kernel, dim3(1), dim3(64), 0, bp_stream(stream), sums, c, dslope);
+  BP_CHECK_LAUNCH();
+  return BP_OK;
+}
+
+int bp_sums_to_float(const double* sums, int32_t c, float* dst, void* stream) {
+  if (!sums || c <= 0 || !dst) return BP_EINVAL;
+  hipLaunchKernelGGL(sums_to_float_kernel, dim3(bp_ceil_div(c, 64)), dim3(64), 0, bp_stream(stream), sums, c, dst);
+  BP_CHECK_LAUNCH();
+  return BP_OK;
+}
+
+int bp_residual_forward(const bp_view* raw, const bp_pointwise* pw, const bp_view* skip,
+                        const bp_pointwise* skip_pw, float slope, const bp_view* out, void* stream) {
+  if (!bp_view_ok(raw) || !bp_view_ok(skip) || !bp_view_ok(out)) return BP_EINVAL;
+  if (!same_grid(raw, skip) || !same_grid(raw, out)) return BP_EINVAL;
+  const int64_t total = bp_view_pixels(raw) * raw->c;
+  hipLaunchKernelGGL(residual_forward_kernel, dim3(nblocks(total)), dim3(RB), 0, bp_stream(stream), vd(raw),
+                     bp_pw(pw), vd(skip), bp_pw(skip_pw), slope, vd(out), total);
+  BP_CHECK_LAUNCH();
+  return BP_OK;
+}
+
+int bp_nchw_to_view(const float* src_nchw, int32_t c, const float* aux, int32_t caux, const bp_view* out,
+                    void* stream) {
+  if (!src_nchw || c <= 0 || caux < 0 || (caux > 0 && !aux) || !out || !out->ptr) return BP_EINVAL;
+  if (out->coff < 0 || out->coff + c + caux > out->cstride) return BP_EINVAL;
+  const int64_t total = bp_view_pixels(out) * (c + caux);
+  hipLaunchKernelGGL(nchw_to_view_kernel, dim3(nblocks(total)), dim3(RB), 0, bp_stream(stream), src_nchw, c, aux,
+                     caux, vd(out), out->n, total);
+  BP_CHECK_LAUNCH();
+  return BP_OK;
+}
+
+int bp_view_to_nchw(const bp_view* src, const bp_pointwise* pw, int32_t softplus, float* dst_nchw, void* stream) {
+  if (!bp_view_ok(src) || !dst_nchw) return BP_EINVAL;
+  const int64_t total = bp_view_pixels(src) * src->c;
+  hipLaunchKernelGGL(view_to_nchw_kernel, dim3(nblocks(total)), dim3(RB), 0, bp_stream(stream), vd(src), bp_pw(pw),
+                     softplus, dst_nchw, total);
+  BP_CHECK_LAUNCH();
+  return BP_OK;
+}
+
+int bp_fill(float* dst, int64_t n, float value, void* stream) {
+  if (!dst || n < 0) return BP_EINVAL;
+  if (n == 0) return BP_OK;
+  hipLaunchKernelGGL(fill_kernel, dim3(nblocks(n)), dim3(RB), 0, bp_stream(stream), dst, n, value);
+  BP_CHECK_LAUNCH();
+  return BP_OK;
+}
+
+static bool latent_view_ok(const bp_latent* lt, const bp_view* v, int n, int c) {
+  return bp_view_ok(v) && v->n == n && v->h == lt->zh && v->w == lt->zw && v->c == c;
+}
+
+int bp_latent_forward(const bp_latent* lt, const bp_view* q_raw, const bp_pointwise* q_pw, const bp_view* p_raw,
+                      const bp_pointwise* p_pw, const float* eps, float* stats4, const bp_view* z,
+                      double* kl_sum, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!lt || lt->n <= 0 || lt->L <= 0 || lt->zc <= 0 || !eps || !stats4 || !kl_sum) return BP_EINVAL;
+  if (!latent_view_ok(lt, q_raw, lt->n, 2 * lt->zc)) return BP_EINVAL;
+  if (p_raw && !latent_view_ok(lt, p_raw, lt->n, 2 * lt->zc)) return BP_EINVAL;
+  if (!latent_view_ok(lt, z, lt->n * lt->L, lt->zc)) return BP_EINVAL;
+  LatentArgs a{};
+  a.lt = *lt; a.q = vd(q_raw); a.p = vd(p_raw); a.z = vd(z); a.qpw = bp_pw(q_pw); a.ppw = bp_pw(p_pw);
+  a.eps = eps; a.stats4 = stats4; a.nelem = (int64_t)lt->n * lt->zc * lt->zh * lt->zw;
+  int nblk = (int)((a.nelem + RB - 1) / RB);
+  if (nblk > 256) nblk = 256;
+  if (!workspace || workspace_bytes < (size_t)nblk * sizeof(double)) return BP_EWORKSPACE;
+  a.partial = reinterpret_cast<double*>(workspace);
+  hipStream_t st = bp_stream(stream);
+  hipLaunchKernelGGL(latent_forward_kernel, dim3(nblk), dim3(RB), 0, st, a);
+  BP_CHECK_LAUNCH();
+  hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(RB), 0, st, a.partial, nblk, 1, kl_sum);
+  BP_CHECK_LAUNCH();
+  return BP_OK;
+}
+
+int bp_latent_backward(const bp_latent* lt, const bp_view* dz, const float* stats4, const float* eps,
+                       const float* seed, float beta_kl, const bp_view* dq_act, const bp_view* dp_act,
+                       void* stream) {
+  if (!lt || !stats4 || !eps || !seed) return BP_EINVAL;
+  if (!latent_view_ok(lt, dz, lt->n * lt->L, lt->zc) || !latent_view_ok(lt, dq_act, lt->n, 2 * lt->zc))
+    return BP_EINVAL;
+  if (dp_act && !latent_view_ok(lt, dp_act, lt->n, 2 * lt->zc)) return BP_EINVAL;
+  LatentBwdArgs a{};
+  a.lt = *lt; a.dz = vd(dz); a.dq = vd(dq_act); a.dp = vd(dp_act); a.stats4 = stats4; a.eps = eps; a.seed = seed;
+  a.beta_kl = beta_kl; a.nelem = (int64_t)lt->n * lt->zc * lt->zh * lt->zw;
+  hipLaunchKernelGGL(latent_backward_kernel, dim3(nblocks(a.nelem)), dim3(RB), 0, bp_stream(stream), a);
+  BP_CHECK_LAUNCH();
+  return BP_OK;
+}
+
+size_t bp_loglik_workspace(const bp_loglik* ll) {
+  if (!ll) return 0;
+  const RedPlan r = red_plan(ll->c, (int64_t)ll->n * ll->L * ll->h * ll->w);
+  return (size_t)r.nblk * 2 * ll->c * sizeof(double);
+}
+
+static bool ll_view_ok(const bp_loglik* ll, const bp_view* v) {
+  return bp_view_ok(v) && v->n == ll->n * ll->L && v->h == ll->h && v->w == ll->w && v->c == ll->c;
+}
+
+int bp_loglik_forward(const bp_loglik* ll, const float* x_nchw, const bp_view* mu_raw, const bp_view* var_raw,
+                      const double* kl_sum, float* x_mu_nchw, float* x_log_var_nchw, float* stats,
+                      void* workspace, size_t workspace_bytes, void* stream) {
+  if (!ll || !x_nchw || !x_mu_nchw || !stats || !ll_view_ok(ll, mu_raw)) return BP_EINVAL;
+  if (ll->c > RB) return BP_EUNSUPPORTED;
+  if (ll->predict_var && !ll_view_ok(ll, var_raw)) return BP_EINVAL;
+  if (!workspace || workspace_bytes < bp_loglik_workspace(ll)) return BP_EWORKSPACE;
+  LoglikArgs a{};
+  a.ll = *ll; a.x = x_nchw; a.mu = vd(mu_raw); a.var = vd(ll->predict_var ? var_raw : nullptr);
+  a.x_mu = x_mu_nchw; a.x_lv = x_log_var_nchw; a.partial = reinterpret_cast<double*>(workspace);
+  a.npix = (int64_t)ll->n * ll->L * ll->h * ll->w;
+  const RedPlan r = red_plan(ll->c, a.npix);
+  a.CP = r.CP; a.pix_per_block = r.ppb;
+  hipStream_t st = bp_stream(stream);
+  hipLaunchKernelGGL(loglik_forward_kernel, dim3(r.nblk), dim3(RB), 0, st, a);
+  BP_CHECK_LAUNCH();
+  hipLaunchKernelGGL(loglik_finalize_kernel, dim3(1), dim3(64), 0, st, *ll, a.partial, r.nblk, kl_sum, stats);
+  BP_CHECK_LAUNCH();
+  return BP_OK;
+}
+
+int bp_loglik_backward(const bp_loglik* ll, const float* x_nchw, const bp_view* mu_raw, const bp_view* var_raw,
+                       const float* seed, const bp_view* d_mu_raw, const bp_view* d_var_raw, void* stream) {
+  if (!ll || !x_nchw || !seed || !ll_view_ok(ll, mu_raw) || !ll_view_ok(ll, d_mu_raw)) return BP_EINVAL;
+  if (ll->predict_var && (!ll_view_ok(ll, var_raw) || !ll_view_ok(ll, d_var_raw))) return BP_EINVAL;
+  LoglikBwdArgs a{};
+  a.ll = *ll; a.x = x_nchw; a.seed = seed; a.mu = vd(mu_raw); a.var = vd(ll->predict_var ? var_raw : nullptr);
+  a.dmu = vd(d_mu_raw); a.dvar = vd(ll->predict_var ? d_var_raw : nullptr);
+  a.total = (int64_t)ll->n * ll->L * ll->h * ll->w * ll->c;
+  hipLaunchKernelGGL(loglik_backward_kernel, dim3(nblocks(a.total)), dim3(RB), 0, bp_stream(stream), a);
+  BP_CHECK_LAUNCH();
+  return BP_OK;
+}
+
+int bp_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                 float beta1, float beta2, float eps, int32_t step, void* stream) {
+  if (!param || !grad || !exp_avg || !exp_avg_sq || n < 0 || step < 1) return BP_EINVAL;
+  if (n == 0) return BP_OK;
+  const double bc1 = 1.0 - pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  hipLaunchKernelGGL(adam_kernel, dim3(nblocks(n)), dim3(RB), 0, bp_stream(stream), param, grad, exp_avg,
+                     exp_avg_sq, n, lr, beta1, beta2, eps, (float)bc1, (float)sqrt(bc2));
+  BP_CHECK_LAUNCH();
+  return BP_OK;
+}
+
+}  // extern "C"

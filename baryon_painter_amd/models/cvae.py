@@ -1,0 +1,540 @@
+"""MI355X-native CVAE with the reference's interface.
+
+Mirrors ``baryon_painter.models.cvae.CVAE`` (/root/reference/baryon_painter/models/cvae.py:8-199):
+same constructor, attributes (``z_mu``, ``z_log_var``, ``KL_term``, ``log_likelihood``, ``ELBO``,
+``x_mu``, ``alpha_var``, ``beta_KL``, ``dim_*``, ``architecture``), methods and ``state_dict``
+keys -- but ``forward``/``sample_P`` run a launch plan of hand-written gfx950 kernels
+(``csrc/``) instead of ``torch.nn`` modules, and the backward pass is scheduled explicitly
+(one ``torch.autograd.Function`` for the whole network).
+
+There is no CPU implementation: constructing the model on a non-GPU device or without the
+built library raises.
+"""
+import ctypes as C
+import math
+
+import torch
+
+from .. import _lib as L
+from .arch import conv_block, conv_down, conv_up, res_block  # noqa: F401  (reference: ``from .utils import *``)
+from .graph import (PW, Slot, build_holders, compile_sequential, probe_output, _stream)
+
+pi = math.pi
+
+
+class _Plan:
+    """All device buffers and the launch schedule for one (batch, mode) signature."""
+
+    def __init__(self, model, n, with_grad, with_q=True):
+        self.model = model
+        self.lib = model._lib
+        self.device = model.device
+        self.impl = model.impl
+        self.sync = model.sync
+        self.n = n
+        self.with_grad = with_grad
+        self.with_q = with_q
+        self.ws_bytes = 0
+        self.ws = None
+        a = model.architecture
+        dev = self.device
+        Lr = model.L
+        cy, H, W = model.dim_y
+        cx = model.dim_x[0]
+        if tuple(model.dim_x[1:]) != (H, W):
+            raise NotImplementedError("dim_x and dim_y must share the spatial size")
+        caux = model.n_aux if model.use_aux_label else 0
+        zc, zh, zw = model.dim_z
+        self.caux = caux
+
+        # ---- inputs: y (+aux planes) as NHWC; x is read as NCHW by the loss and as NHWC by Q
+        self.y2 = Slot.new(n, H, W, cy + caux, dev)
+        self.x_in = Slot.new(n, H, W, cx, dev)
+
+        # ---- recognition network Q (cvae.py:68-80): cat[q_x_in(x), q_y_in(y)] -> q_out
+        self.q_units, self.q_head = [], None
+        if with_q:
+            cqx, hq, wq = probe_output(a["q_x_in"], cx, H, W)
+            cqy, hq2, wq2 = probe_output(a["q_y_in"], cy + caux, H, W)
+            if (hq, wq) != (hq2, wq2):
+                raise ValueError("q_x_in and q_y_in outputs differ in spatial size")
+            cat = Slot.new(n, hq, wq, cqx + cqy, dev)
+            cat.pw = PW.identity(cqx + cqy, dev)
+            sx0 = cat.sub(0, cqx, pw=cat.pw.slice(0, cqx))
+            sy0 = cat.sub(cqx, cqx + cqy, pw=cat.pw.slice(cqx, cqx + cqy))
+            ux, sx, tr = compile_sequential(self, "q_x_in.", a["q_x_in"], model.q_x_in, self.x_in,
+                                            out_slot=sx0, out_pw=sx0.pw, need_input_grad=False)
+            self._no_trailing(tr, "q_x_in")
+            uy, sy, tr = compile_sequential(self, "q_y_in.", a["q_y_in"], model.q_y_in, self.y2,
+                                            out_slot=sy0, out_pw=sy0.pw, need_input_grad=False)
+            self._no_trailing(tr, "q_y_in")
+            if sx is not sx0 or sy is not sy0:
+                raise NotImplementedError("q_x_in / q_y_in must end in a convolution")
+            uo, so, tr = compile_sequential(self, "q_out.", a["q_x_y_out"], model.q_out, cat)
+            self._latent_trailing(tr, "q_x_y_out")
+            self.q_units = [ux, uy, uo]
+            self.q_head = so
+            if so.shape() != (n, zh, zw, 2 * zc):
+                raise ValueError(f"q_x_y_out produces {so.shape()}, dim_z needs {(n, zh, zw, 2 * zc)}")
+
+        # ---- prior network (cvae.py:82-95)
+        self.p_units, self.p_head = [], None
+        if model.prior_network is not None:
+            up, sp, tr = compile_sequential(self, "prior_network.", a["prior_z_y"], model.prior_network,
+                                            self.y2, need_input_grad=False)
+            self._latent_trailing(tr, "prior_z_y")
+            self.p_units, self.p_head = up, sp
+            if sp.shape() != (n, zh, zw, 2 * zc):
+                raise ValueError(f"prior_z_y produces {sp.shape()}, dim_z needs {(n, zh, zw, 2 * zc)}")
+
+        # ---- latent
+        self.lat = L.Latent(n, Lr, zc, zh, zw, float(model.min_z_var))
+        self.z = Slot.new(n * Lr, zh, zw, zc, dev)
+        self.stats4 = torch.zeros((4, n, zc, zh, zw), device=dev)
+        self.kl_sum = torch.zeros(1, device=dev, dtype=torch.float64)
+        self.eps = None
+        self.need_ws(256 * 8)
+
+        # ---- generator P (cvae.py:103-120)
+        nL = n * Lr
+        # p_z_in output and p_y_in(y) are concatenated: [h_z, h_y.repeat(L)]
+        c_hz, hz_h, hz_w = probe_output(a["p_z_in"], zc, zh, zw)
+        if (hz_h, hz_w) != (H, W):
+            raise ValueError(f"p_z_in produces {hz_h}x{hz_w}, dim_y is {H}x{W}")
+        if model.p_y_in is not None:
+            raise NotImplementedError("p_y_in networks are not supported by the HIP path yet "
+                                      "(the reference configurations use p_y_in=None)")
+        c_hy = cy + caux
+        ccat = c_hz + c_hy
+        self.p_in = Slot.new(nL, H, W, ccat, dev, cstride=((ccat + 3) // 4) * 4)
+        self.p_in.pw = PW.identity(ccat, dev)
+        hz_slot = self.p_in.sub(0, c_hz, pw=self.p_in.pw.slice(0, c_hz))
+        self.hy_slot = self.p_in.sub(c_hz, ccat)
+        uz, sz, tr = compile_sequential(self, "p_z_in.", a["p_z_in"], model.p_z_in, self.z,
+                                        out_slot=hz_slot, out_pw=hz_slot.pw)
+        self._no_trailing(tr, "p_z_in")
+        if sz is not hz_slot:
+            raise NotImplementedError("p_z_in must end in a convolution")
+        ub, sb, tr = compile_sequential(self, "p_y_z_in.", a["p_y_z_in"], model.p_y_z_in, self.p_in)
+        self._no_trailing(tr, "p_y_z_in")
+        self.g_units = [uz, ub]
+        self.h = sb
+        um, sm, tr = compile_sequential(self, "p_mu_out.", a["p_y_z_out"][0], model.p_mu_out, sb)
+        self.mu_softplus = self._head_trailing(tr, "p_y_z_out[0]")
+        self.mu_units, self.mu_head = um, sm
+        self.var_units, self.var_head = [], None
+        if model.predict_var:
+            uv, sv, tr = compile_sequential(self, "p_var_out.", a["p_y_z_out"][1], model.p_var_out, sb)
+            if self._head_trailing(tr, "p_y_z_out[1]"):
+                raise NotImplementedError("softplus on the variance head")
+            self.var_units, self.var_head = uv, sv
+        if sm.shape() != (nL, H, W, cx):
+            raise ValueError(f"p_y_z_out produces {sm.shape()}, dim_x needs {(nL, H, W, cx)}")
+        for s in (sm, self.var_head):
+            if s is not None and s.pw is not None:
+                raise NotImplementedError("a head must end in conv (+softplus), without batch-norm/ReLU")
+
+        # ---- loss
+        self.ll = L.Loglik(n, Lr, cx, H, W, 1 if self.mu_softplus else 0, 1 if model.predict_var else 0,
+                           1.0, 1.0, float(model.likelihood_scaling))
+        self.x_nchw = torch.zeros((n, cx, H, W), device=dev)
+        self.x_mu = torch.zeros((nL, cx, H, W), device=dev)
+        self.x_log_var = torch.zeros((nL, cx, H, W), device=dev) if model.predict_var else None
+        self.stats = torch.zeros(2 + 3 * cx, device=dev)
+        self.need_ws(self.lib.bp_loglik_workspace(C.byref(self.ll)))
+
+        if with_grad:
+            self._prepare_backward()
+        self.ws = torch.zeros(max(self.ws_bytes, 256) // 8 + 32, device=dev, dtype=torch.float64)
+        self.ws_bytes = self.ws.numel() * 8
+
+    # ---- helpers
+    def need_ws(self, nbytes):
+        self.ws_bytes = max(self.ws_bytes, int(nbytes))
+
+    @staticmethod
+    def _no_trailing(tr, where):
+        if tr:
+            raise NotImplementedError(f"{where}: trailing layers {tr} are not supported by the HIP path")
+
+    @staticmethod
+    def _latent_trailing(tr, where):
+        for name, _ in tr:
+            if name != "unflatten":
+                raise NotImplementedError(f"{where}: trailing layer '{name}' is not supported by the HIP path")
+
+    @staticmethod
+    def _head_trailing(tr, where):
+        sp = False
+        for name, _ in tr:
+            if name == "softplus":
+                sp = True
+            else:
+                raise NotImplementedError(f"{where}: trailing layer '{name}' is not supported by the HIP path")
+        return sp
+
+    def _prepare_backward(self):
+        # consumers claim gradient views in reverse topological order
+        for us in (self.var_units, self.mu_units):
+            for u in reversed(us):
+                u.prepare_backward()
+        for us in reversed(self.g_units):
+            for u in reversed(us):
+                u.prepare_backward()
+        self.z.ensure_grad()
+        for u in reversed(self.p_units):
+            u.prepare_backward()
+        for us in reversed(self.q_units):
+            for u in reversed(us):
+                u.prepare_backward()
+        self.seed = torch.ones(1, device=self.device)
+
+    # ---- execution
+    def load_inputs(self, y, aux, x=None):
+        lib, st = self.lib, _stream()
+        m = self.model
+        cy = m.dim_y[0]
+        y = y.contiguous()
+        auxp = None
+        if self.caux:
+            aux = aux.reshape(self.n, self.caux).to(torch.float32).contiguous()
+            auxp = L.ptr(aux)
+        L.check(lib.bp_nchw_to_view(L.ptr(y), cy, auxp, self.caux, C.byref(self.y2.view), st), "merge_aux_label")
+        for l in range(m.L):
+            v = L.View(self.p_in.buf[l * self.n:].data_ptr(), self.n, self.hy_slot.h, self.hy_slot.w,
+                       self.hy_slot.c, self.hy_slot.cstride, self.hy_slot.coff)
+            L.check(lib.bp_nchw_to_view(L.ptr(y), cy, auxp, self.caux, C.byref(v), st), "merge_aux_label (P)")
+        self._keep = (y, aux)
+        if x is not None:
+            if not self.with_q:
+                raise RuntimeError("this plan was built without the recognition network")
+            self.x_nchw.copy_(x)
+            L.check(lib.bp_nchw_to_view(L.ptr(self.x_nchw), m.dim_x[0], None, 0, C.byref(self.x_in.view), st),
+                    "x layout")
+
+    def run_prior(self, training):
+        for u in self.p_units:
+            u.forward(training)
+
+    def run_latent(self, eps, use_q):
+        lib, st = self.lib, _stream()
+        self.eps = eps.to(torch.float32).contiguous()
+        q = self.q_head if use_q else self.p_head
+        if q is None:
+            raise NotImplementedError("sampling from the standard-normal prior (no prior_z_y) is not implemented")
+        p = self.p_head
+        L.check(lib.bp_latent_forward(C.byref(self.lat), C.byref(q.view), q.pw_struct(),
+                                      None if p is None else C.byref(p.view),
+                                      None if p is None else p.pw_struct(), L.ptr(self.eps),
+                                      L.ptr(self.stats4), C.byref(self.z.view), L.ptr(self.kl_sum),
+                                      L.ptr(self.ws), self.ws_bytes, st), "latent forward")
+
+    def run_generator(self, training):
+        for us in self.g_units:
+            for u in us:
+                u.forward(training)
+        for u in self.mu_units:
+            u.forward(training)
+        for u in self.var_units:
+            u.forward(training)
+
+    def forward_train(self, x, y, aux, eps, training=True):
+        m = self.model
+        self.load_inputs(y, aux, x)
+        for us in self.q_units:
+            for u in us:
+                u.forward(training)
+        self.run_prior(training)
+        self.run_latent(eps, use_q=True)
+        self.run_generator(training)
+        self.ll.alpha_var = float(m.alpha_var)
+        self.ll.beta_kl = float(m.beta_KL)
+        lib, st = self.lib, _stream()
+        L.check(lib.bp_loglik_forward(C.byref(self.ll), L.ptr(self.x_nchw), C.byref(self.mu_head.view),
+                                      None if self.var_head is None else C.byref(self.var_head.view),
+                                      L.ptr(self.kl_sum), L.ptr(self.x_mu), L.ptr(self.x_log_var),
+                                      L.ptr(self.stats), L.ptr(self.ws), self.ws_bytes, st), "log-likelihood")
+
+    def backward(self, seed, grads):
+        """d(seed*ELBO)/d(parameters) into ``grads`` (id(param) -> tensor)."""
+        lib, st = self.lib, _stream()
+        self.seed.copy_(seed.reshape(1))
+        self.mu_head.ensure_grad()
+        if self.var_head is not None:
+            self.var_head.ensure_grad()
+        L.check(lib.bp_loglik_backward(C.byref(self.ll), L.ptr(self.x_nchw), C.byref(self.mu_head.view),
+                                       None if self.var_head is None else C.byref(self.var_head.view),
+                                       L.ptr(self.seed), C.byref(self.mu_head.grad),
+                                       None if self.var_head is None else C.byref(self.var_head.grad), st),
+                "log-likelihood backward")
+        for us in (self.var_units, self.mu_units):
+            for u in reversed(us):
+                u.backward(grads)
+        for us in reversed(self.g_units):
+            for u in reversed(us):
+                u.backward(grads)
+        L.check(lib.bp_latent_backward(C.byref(self.lat), C.byref(self.z.grad), L.ptr(self.stats4),
+                                       L.ptr(self.eps), L.ptr(self.seed), float(self.model.beta_KL),
+                                       C.byref(self.q_head.grad),
+                                       None if self.p_head is None else C.byref(self.p_head.grad), st),
+                "latent backward")
+        for u in reversed(self.p_units):
+            u.backward(grads)
+        for us in reversed(self.q_units):
+            for u in reversed(us):
+                u.backward(grads)
+
+
+class _ELBOFunction(torch.autograd.Function):
+    """The whole network as one autograd node: forward launches the plan, backward launches
+    the hand-scheduled gradient plan and hands the parameter gradients back to autograd."""
+
+    @staticmethod
+    def forward(ctx, model, plan, x, y, aux, eps, *params):
+        plan.forward_train(x, y, aux, eps, training=model.training)
+        ctx.model, ctx.plan = model, plan
+        return plan.stats[0].clone()
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        model, plan = ctx.model, ctx.plan
+        if not plan.with_grad:
+            raise RuntimeError("this forward was run without gradient buffers")
+        flat = model._flat_grads
+        plan.backward(grad_out.detach().to(torch.float32), model._grad_views_by_id)
+        if model.sync is not None:
+            model.sync.all_reduce_mean(flat)
+        return (None, None, None, None, None, None) + tuple(model._grad_views)
+
+
+class CVAE(torch.nn.Module):
+    """Drop-in for ``baryon_painter.models.cvae.CVAE`` (cvae.py:8-61)."""
+
+    def __init__(self, architecture, device="cuda:0", impl="auto", sync=None):
+        super().__init__()
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("baryon_painter_amd.CVAE runs on an AMD GPU only (device='cuda:N'); "
+                               "there is no CPU implementation of the hot path.")
+        self._lib = L.load()
+        self.impl = {"auto": L.IMPL_AUTO, "direct": L.IMPL_DIRECT, "mfma": L.IMPL_MFMA}[impl]
+        self.sync = sync
+
+        print("CVAE with {} architecture.".format(architecture["type"]))
+        self.architecture = architecture
+        self.dim_x = tuple(architecture["dim_x"])
+        self.dim_y = tuple(architecture["dim_y"])
+        self.dim_z = tuple(architecture["dim_z"])
+        self.L = architecture["L"] if "L" in architecture else 1
+        self.n_x_features = architecture["n_x_features"]
+
+        if architecture["type"] == "Type-1":
+            self.q_x_in = build_holders(architecture["q_x_in"])
+            self.q_y_in = build_holders(architecture["q_y_in"])
+            self.q_out = build_holders(architecture["q_x_y_out"])
+            self.p_y_in = build_holders(architecture["p_y_in"])
+            self.p_z_in = build_holders(architecture["p_z_in"])
+            self.p_y_z_in = build_holders(architecture["p_y_z_in"])
+            self.p_mu_out = build_holders(architecture["p_y_z_out"][0])
+            if len(architecture["p_y_z_out"]) > 1:
+                self.predict_var = True
+                self.p_var_out = build_holders(architecture["p_y_z_out"][1])
+                self.x_var_init_std = architecture.get("x_var_init_std", 0.01)
+
+                def init_weight(m):        # cvae.py:37-40: every module with a .weight
+                    if hasattr(m, "weight") and isinstance(m.weight, torch.Tensor):
+                        torch.nn.init.normal_(m.weight, std=self.x_var_init_std)
+                self.p_var_out.apply(init_weight)
+                self.min_x_var = architecture.get("min_x_var", 1e-7)
+            else:
+                self.predict_var = False
+                self.p_var_out = None
+            self.use_aux_label = architecture["aux_label"]
+            if "prior_z_y" in architecture:
+                self.prior_network = build_holders(architecture["prior_z_y"])
+            else:
+                self.prior_network = None
+        else:
+            raise NotImplementedError("Architecture {} not supported yet!".format(architecture["type"]))
+
+        self.min_z_var = architecture.get("min_z_var", 1e-7)
+        self.likelihood_scaling = architecture.get("likelihood_scaling", 1.0)
+        self.alpha_var = 1.0
+        self.beta_KL = 1.0
+        self.n_aux = 1
+        self._plans = {}
+        self._eps_override = None
+        self.to(self.device)
+        self._flatten_parameters()
+
+    # ---- parameter storage: one flat buffer (single all-reduce / fused Adam), torch views on it
+    def _flatten_parameters(self):
+        params = list(self.parameters())
+        n = sum(p.numel() for p in params)
+        self._flat_params = torch.zeros(n, device=self.device)
+        self._flat_grads = torch.zeros(n, device=self.device)
+        off = 0
+        self._grad_views, self._grad_views_by_id = [], {}
+        for p in params:
+            k = p.numel()
+            self._flat_params[off:off + k].copy_(p.detach().reshape(-1))
+            p.data = self._flat_params[off:off + k].view_as(p)
+            gv = self._flat_grads[off:off + k].view_as(p)
+            self._grad_views.append(gv)
+            self._grad_views_by_id[id(p)] = gv
+            off += k
+        self._params = params
+
+    def _apply(self, fn, *a, **k):
+        out = super()._apply(fn, *a, **k)
+        if hasattr(self, "_flat_params"):
+            self._flatten_parameters()
+            self._plans = {}
+        return out
+
+    def load_state_dict(self, *a, **k):
+        out = super().load_state_dict(*a, **k)
+        return out
+
+    def _plan(self, n, with_grad, with_q=True):
+        """Plans are cached per (batch, gradients, recognition net); a richer plan serves a
+        poorer request."""
+        want_g, want_q = bool(with_grad), bool(with_q)
+        for (pn, g, q), plan in self._plans.items():
+            if pn == n and g >= want_g and q >= want_q:
+                return plan
+        plan = _Plan(self, n, want_g, want_q)
+        self._plans[(n, want_g, want_q)] = plan
+        return plan
+
+    def cuda(self, device=None):
+        return self
+
+    # ---- reference API --------------------------------------------------------------------
+    def _draw_eps(self, n):
+        if self._eps_override is not None:
+            e = torch.as_tensor(self._eps_override, device=self.device, dtype=torch.float32)
+            if tuple(e.shape) != (self.L, n, *self.dim_z):
+                raise ValueError(f"eps override has shape {tuple(e.shape)}, expected {(self.L, n, *self.dim_z)}")
+            return e
+        return torch.randn(size=(self.L, n, *self.dim_z), device=self.device)     # cvae.py:64
+
+    def _check_inputs(self, x, y):
+        if y.dim() != 4 or tuple(y.shape[1:]) != self.dim_y:
+            raise ValueError(f"y has shape {tuple(y.shape)}, model expects (N, {self.dim_y})")
+        if x is not None and (x.dim() != 4 or tuple(x.shape[1:]) != self.dim_x or x.shape[0] != y.shape[0]):
+            raise ValueError(f"x has shape {tuple(x.shape)}, model expects (N, {self.dim_x})")
+
+    def _aux(self, aux_label, n):
+        if not self.use_aux_label:
+            return None
+        if aux_label is None:
+            raise ValueError("this architecture needs an aux_label (redshift)")
+        a = torch.as_tensor(aux_label, device=self.device, dtype=torch.float32)
+        if a.dim() <= 1:
+            a = a.reshape(-1, 1)
+        if a.shape[0] != n:
+            raise ValueError("aux_label batch size needs to match that of y")        # utils.py:175-176
+        if a.shape[1] != self.n_aux:
+            raise NotImplementedError("one scalar aux label per sample")
+        return a
+
+    def forward(self, x, y, aux_label=None):
+        """ELBO of the batch (cvae.py:122-147); supports ``.backward()``."""
+        x = torch.as_tensor(x, device=self.device, dtype=torch.float32)
+        y = torch.as_tensor(y, device=self.device, dtype=torch.float32)
+        self._check_inputs(x, y)
+        n = y.shape[0]
+        aux = self._aux(aux_label, n)
+        need_grad = torch.is_grad_enabled()
+        plan = self._plan(n, need_grad)
+        eps = self._draw_eps(n)
+        elbo = _ELBOFunction.apply(self, plan, x, y, aux, eps, *self._params)
+        self._last = plan
+        cx = self.dim_x[0]
+        s = plan.stats
+        self.ELBO = elbo
+        self.KL_term = s[1]
+        self.log_likelihood = s[2:2 + cx]
+        if self.predict_var:
+            self.log_likelihood_fixed_var = s[2 + cx:2 + 2 * cx]
+            self.log_likelihood_free_var = s[2 + 2 * cx:2 + 3 * cx]
+            self.x_var = torch.exp(plan.x_log_var)
+        self.x_mu = plan.x_mu
+        self.z_mu = plan.stats4[0]
+        self.z_log_var = plan.stats4[1]
+        return elbo
+
+    def sample_P(self, y, return_var=False, aux_label=None, z=None):
+        """cvae.py:149-162 (always under no_grad)."""
+        with torch.no_grad():
+            y = torch.as_tensor(y, device=self.device, dtype=torch.float32)
+            self._check_inputs(None, y)
+            n = y.shape[0]
+            aux = self._aux(aux_label, n)
+            if self.L != 1:
+                raise NotImplementedError("sample_P with L != 1")
+            plan = self._plan(n, False, False)
+            plan.load_inputs(y, aux)
+            if z is None:
+                plan.run_prior(self.training)
+                plan.run_latent(self._draw_eps(n), use_q=False)
+            else:
+                zt = torch.as_tensor(z, device=self.device, dtype=torch.float32)
+                if tuple(zt.shape) != (n, *self.dim_z):
+                    raise ValueError(f"z has shape {tuple(zt.shape)}, expected {(n, *self.dim_z)}")
+                lib, st = self._lib, _stream()
+                zt = zt.contiguous()
+                L.check(lib.bp_nchw_to_view(L.ptr(zt), self.dim_z[0], None, 0, C.byref(plan.z.view), st), "z layout")
+            plan.run_generator(self.training)
+            lib, st = self._lib, _stream()
+            cx, H, W = self.dim_x
+            mu = torch.empty((n, cx, H, W), device=self.device)
+            self._head_to_nchw(plan.mu_head, plan.mu_softplus, mu)
+            if self.predict_var and return_var:
+                lv = torch.empty((n, cx, H, W), device=self.device)
+                self._head_to_nchw(plan.var_head, False, lv)
+                return mu, torch.exp(lv)
+            return mu
+
+    def _head_to_nchw(self, slot, softplus, dst):
+        L.check(self._lib.bp_view_to_nchw(C.byref(slot.view), None, 1 if softplus else 0, L.ptr(dst), _stream()),
+                "head layout")
+
+    def sample_prior(self, y, aux_label=None):
+        raise NotImplementedError("use sample_P; the latent sample lives on the device plan")
+
+    def get_stats(self):
+        """cvae.py:164-171: same tuple order; forces a device->host sync like the reference's .item()."""
+        s = self._last.stats.detach().cpu().numpy()
+        cx = self.dim_x[0]
+        if self.predict_var:
+            return (float(s[0]), -float(s[1]), *s[2:2 + cx], *s[2 + cx:2 + 2 * cx], *s[2 + 2 * cx:2 + 3 * cx])
+        return (float(s[0]), -float(s[1]), *s[2:2 + cx])
+
+    def get_stats_labels(self):
+        if self.predict_var:
+            return (["ELBO", "KL_term"]
+                    + ["log_likelihood_{}".format(i) for i in range(self.n_x_features)]
+                    + ["log_likelihood_fixed_var_{}".format(i) for i in range(self.n_x_features)]
+                    + ["log_likelihood_free_var_{}".format(i) for i in range(self.n_x_features)])
+        return ["ELBO", "KL_term"] + ["log_likelihood_{}".format(i) for i in range(self.n_x_features)]
+
+    def count_parameters(self):
+        return sum(p.numel() for p in self.parameters() if p.requires_grad)
+
+    def print_model_statistics(self, percentile=0.9):
+        params = sorted([(p.numel(), name) for name, p in self.named_parameters() if p.requires_grad], reverse=True)
+        total = sum(n for n, _ in params)
+        print("Total number of parameters: {}".format(total))
+        print("Top {}% of all parameters are in the following layers".format(percentile * 100))
+        run = 0
+        for n, name in params:
+            run += n
+            if run < total * percentile:
+                print("{:<40s}   {:>8}".format(name, n))
+
+    def check_gpu(self):
+        for name, p in self.named_parameters():
+            if "cuda" not in str(p.data.device):
+                print("{} is not on the GPU!".format(name))

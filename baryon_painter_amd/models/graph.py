@@ -1,0 +1,475 @@
+"""Architecture description -> HIP launch plan.
+
+The reference turns an architecture list into ``torch.nn`` modules with
+``build_sequential`` (/root/reference/baryon_painter/models/utils.py:114-157) and lets
+autograd derive the backward pass.  Here the same lists are compiled into *units*
+(convolution [+ batch-norm] [+ activation], residual block) that own pre-allocated NHWC
+device buffers and call the C ABI in ``include/bp_hip.h`` for forward and a hand-scheduled
+backward.  PyTorch supplies device memory, streams and the parameter containers only.
+
+Conventions
+  * a ``Slot`` is an activation tensor: a RAW buffer view plus the pending per-channel
+    affine+leaky-ReLU (``PW``) that its consumers apply while loading it;
+  * every slot has at most two gradient contributions (``grad`` and ``grad2``), which the
+    producer's backward adds while it applies the activation derivative.
+"""
+import ctypes as C
+
+import torch
+
+from .. import _lib as L
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+# ------------------------------------------------------------------ parameter containers
+class _NoForward:
+    def forward(self, *a, **k):  # pragma: no cover - guard
+        raise RuntimeError("parameter container only: the arithmetic runs in libbp_hip.so")
+
+
+class ParamConv2d(_NoForward, torch.nn.Conv2d):
+    """Holds ``weight``/``bias`` with torch's own initialisation (same seed -> same initial
+    weights as the reference's nn.Conv2d, utils.py:129).  Never called."""
+
+
+class ParamConvTranspose2d(_NoForward, torch.nn.ConvTranspose2d):
+    pass
+
+
+class ParamBatchNorm2d(_NoForward, torch.nn.BatchNorm2d):
+    pass
+
+
+class ParamPReLU(_NoForward, torch.nn.PReLU):
+    pass
+
+
+class ParamLinear(_NoForward, torch.nn.Linear):
+    pass
+
+
+class Marker(_NoForward, torch.nn.Module):
+    """Parameter-free layer; keeps the reference's module indices in state_dict keys."""
+
+    def __init__(self, kind, arg=None):
+        super().__init__()
+        self.kind, self.arg = kind, arg
+
+    def extra_repr(self):
+        return self.kind if self.arg is None else f"{self.kind}, {self.arg}"
+
+
+class ResidualHolder(_NoForward, torch.nn.Module):
+    def __init__(self, architecture):
+        super().__init__()
+        self.res_block = build_holders(architecture[0])
+        name = architecture[1][0]
+        if name is None:
+            self.tail = (None, None)
+        elif name.lower() == "relu":
+            self.tail = ("relu", None)
+        elif name.lower() == "leaky relu":
+            self.tail = ("leaky relu", architecture[1][1])
+        else:
+            raise NotImplementedError("Layer {} not supported yet!".format(name))
+
+
+_PLAIN = ("leaky relu", "relu", "tanh", "sigmoid", "softplus", "flatten", "unflatten")
+
+
+def build_holders(architecture):
+    """Same vocabulary and error behaviour as the reference's ``build_sequential``
+    (utils.py:114-157); returns None for ``architecture is None`` (identity)."""
+    if architecture is None:
+        return None
+    mods = []
+    for layer in architecture:
+        if len(layer) == 2:
+            name, config = layer
+        elif len(layer) == 1:
+            name, config = layer[0], None
+        else:
+            raise RuntimeError("Layer definition ill-formed: {}.".format(layer))
+        name = name.lower()
+        if name == "conv":
+            mods.append(ParamConv2d(**config))
+        elif name == "transp conv":
+            mods.append(ParamConvTranspose2d(**config))
+        elif name == "linear":
+            mods.append(ParamLinear(**config))
+        elif name == "prelu":
+            mods.append(ParamPReLU())
+        elif name == "batchnorm":
+            mods.append(ParamBatchNorm2d(**config))
+        elif name == "residual block":
+            mods.append(ResidualHolder(config))
+        elif name in _PLAIN:
+            mods.append(Marker(name, config))
+        else:
+            raise NotImplementedError("Layer {} not supported yet!".format(name))
+    return torch.nn.Sequential(*mods)
+
+
+# ------------------------------------------------------------------ plan data structures
+class PW:
+    """Per-channel (scale, shift, slope) arrays of a pending activation; may be slices of a
+    wider array when the slot is part of a channel concatenation."""
+
+    def __init__(self, scale, shift, slope):
+        self.scale, self.shift, self.slope = scale, shift, slope
+        self.struct = L.Pointwise(scale.data_ptr(), shift.data_ptr(), slope.data_ptr())
+
+    @staticmethod
+    def identity(c, device):
+        return PW(torch.ones(c, device=device), torch.zeros(c, device=device), torch.ones(c, device=device))
+
+    def slice(self, c0, c1):
+        return PW(self.scale[c0:c1], self.shift[c0:c1], self.slope[c0:c1])
+
+
+class Slot:
+    def __init__(self, buf, n, h, w, c, coff=0, pw=None, parent=None):
+        self.buf = buf                       # torch tensor (n,h,w,cstride)
+        self.n, self.h, self.w, self.c = n, h, w, c
+        self.cstride = buf.shape[-1]
+        self.coff = coff
+        self.pw = pw                          # None = identity
+        self.parent = parent
+        self.view = L.View(buf.data_ptr(), n, h, w, c, self.cstride, coff)
+        self.grad_buf = None
+        self.grad = None                      # L.View
+        self.grad2 = None                     # L.View (second contribution) or None
+        self.n_consumers = 0
+
+    @staticmethod
+    def new(n, h, w, c, device, cstride=None, pw=None):
+        cs = c if cstride is None else cstride
+        return Slot(torch.zeros((n, h, w, cs), device=device, dtype=torch.float32), n, h, w, c, 0, pw)
+
+    def sub(self, c0, c1, pw=None):
+        """Channel slice sharing storage (and gradient storage)."""
+        return Slot(self.buf, self.n, self.h, self.w, c1 - c0, self.coff + c0, pw, parent=self)
+
+    def pw_struct(self):
+        return None if self.pw is None else C.byref(self.pw.struct)
+
+    def shape(self):
+        return (self.n, self.h, self.w, self.c)
+
+    # ---- gradients
+    def ensure_grad(self):
+        if self.grad is None:
+            if self.parent is not None:
+                self.parent.ensure_grad()
+                self.grad_buf = self.parent.grad_buf
+            else:
+                self.grad_buf = torch.zeros_like(self.buf)
+            self.grad = L.View(self.grad_buf.data_ptr(), self.n, self.h, self.w, self.c, self.cstride, self.coff)
+        return self.grad
+
+    def claim_grad(self):
+        """A consumer asks where to write d(loss)/d(activated slot)."""
+        self.n_consumers += 1
+        if self.n_consumers == 1:
+            return self.ensure_grad()
+        if self.n_consumers == 2 and self.grad2 is None:
+            self._grad2_buf = torch.zeros((self.n, self.h, self.w, self.c), device=self.buf.device)
+            self.grad2 = L.View(self._grad2_buf.data_ptr(), self.n, self.h, self.w, self.c, self.c, 0)
+            return self.grad2
+        raise NotImplementedError("more than two consumers of one activation")
+
+    def set_grad2_alias(self, view):
+        self.n_consumers += 1
+        if self.grad2 is not None or self.n_consumers > 2:
+            raise NotImplementedError("more than two consumers of one activation")
+        self.grad2 = view
+
+
+class ConvUnit:
+    """conv / transp conv [+ batchnorm] [+ relu | leaky relu | prelu]  (utils.py:128-147)."""
+
+    def __init__(self, plan, name, holder, bn, act, act_arg, act_holder, inp, out_slot=None, out_pw=None,
+                 need_dgrad=True):
+        self.plan, self.name = plan, name
+        dev = plan.device
+        transposed = isinstance(holder, torch.nn.ConvTranspose2d)
+        k, s, p = holder.kernel_size, holder.stride, holder.padding
+        op = holder.output_padding if transposed else (0, 0)
+        if k[0] != k[1] or s[0] != s[1] or p[0] != p[1] or op[0] != op[1] or holder.groups != 1 \
+                or tuple(holder.dilation) != (1, 1):
+            raise NotImplementedError(f"{name}: only square, undilated, ungrouped convolutions")
+        self.cv = cv = L.Conv(1 if transposed else 0, holder.in_channels, holder.out_channels, k[0], s[0], p[0],
+                              op[0])
+        if inp.c != cv.cin:
+            raise ValueError(f"{name}: input has {inp.c} channels, layer expects {cv.cin}")
+        self.holder, self.bn, self.act_holder = holder, bn, act_holder
+        self.act, self.act_arg = act, act_arg
+        self.inp, self.need_dgrad = inp, need_dgrad
+        if transposed:
+            ho = (inp.h - 1) * cv.stride - 2 * cv.pad + cv.k + cv.out_pad
+            wo = (inp.w - 1) * cv.stride - 2 * cv.pad + cv.k + cv.out_pad
+        else:
+            ho = (inp.h + 2 * cv.pad - cv.k) // cv.stride + 1
+            wo = (inp.w + 2 * cv.pad - cv.k) // cv.stride + 1
+        if ho <= 0 or wo <= 0:
+            raise ValueError(f"{name}: empty output {ho}x{wo}")
+        c = cv.cout
+        self.has_pw = bn is not None or act is not None
+        if out_pw is None and self.has_pw:
+            out_pw = PW.identity(c, dev)
+        if out_pw is not None:
+            out_pw.scale.fill_(1.0)
+            out_pw.shift.fill_(0.0)
+            if act == "relu":
+                out_pw.slope.fill_(0.0)
+            elif act == "leaky relu":
+                out_pw.slope.fill_(float(act_arg))
+            else:
+                out_pw.slope.fill_(1.0)      # none; prelu is refreshed every forward
+        self.out_pw = out_pw
+        if out_slot is None:
+            self.out = Slot.new(inp.n, ho, wo, c, dev, pw=out_pw)
+        else:
+            if out_slot.shape() != (inp.n, ho, wo, c):
+                raise ValueError(f"{name}: concat slot shape {out_slot.shape()} != {(inp.n, ho, wo, c)}")
+            self.out = out_slot
+            self.out.pw = out_pw
+        self.sums = torch.zeros(3 * c, device=dev, dtype=torch.float64)
+        if bn is not None:
+            self.save_mean = torch.zeros(c, device=dev)
+            self.save_invstd = torch.zeros(c, device=dev)
+            self.abc = torch.zeros(3 * c, device=dev)
+            self.count = 1.0
+        lib = plan.lib
+        n_fwd = lib.bp_conv_packed_floats(C.byref(cv), L.PACK_FWD)
+        n_bwd = lib.bp_conv_packed_floats(C.byref(cv), L.PACK_BWD)
+        if n_fwd <= 0 or n_bwd <= 0:
+            raise NotImplementedError(f"{name}: shape not supported by the gfx950 kernels")
+        self.packed_fwd = torch.zeros(n_fwd, device=dev)
+        self.packed_bwd = torch.zeros(n_bwd, device=dev) if need_dgrad else None
+        self._packed_version = None
+        self.dx = None
+        plan.need_ws(lib.bp_channel_sums_workspace(C.byref(self.out.view)))
+
+    # ---- weights
+    def maybe_pack(self):
+        w = self.holder.weight
+        ver = (w._version, w.data_ptr())
+        if ver == self._packed_version:
+            return
+        lib, st = self.plan.lib, _stream()
+        L.check(lib.bp_conv_pack(C.byref(self.cv), L.PACK_FWD, L.ptr(w), L.ptr(self.packed_fwd), st), "pack")
+        if self.packed_bwd is not None:
+            L.check(lib.bp_conv_pack(C.byref(self.cv), L.PACK_BWD, L.ptr(w), L.ptr(self.packed_bwd), st), "pack")
+        self._packed_version = ver
+
+    # ---- forward
+    def forward(self, training):
+        plan, lib, st = self.plan, self.plan.lib, _stream()
+        self.maybe_pack()
+        hold = self.holder
+        L.check(lib.bp_conv_forward(C.byref(self.cv), C.byref(self.inp.view), self.inp.pw_struct(),
+                                    L.ptr(self.packed_fwd), L.ptr(hold.weight), L.ptr(hold.bias),
+                                    C.byref(self.out.view), plan.impl, st), f"{self.name} forward")
+        c = self.cv.cout
+        if self.act == "prelu":
+            self.out_pw.slope.copy_(self.act_holder.weight.detach().expand(c))
+        bn = self.bn
+        if bn is None:
+            return
+        if training:
+            L.check(lib.bp_channel_sums(C.byref(self.out.view), L.ptr(self.sums), L.ptr(plan.ws), plan.ws_bytes,
+                                        st), f"{self.name} bn stats")
+            count = float(self.out.n * self.out.h * self.out.w)
+            if plan.sync is not None:
+                plan.sync.all_reduce_sum(self.sums[:2 * c])
+                count *= plan.sync.world_size
+            self.count = count
+            L.check(lib.bp_bn_finalize(L.ptr(self.sums), count, c, L.ptr(bn.weight), L.ptr(bn.bias),
+                                       float(bn.eps), float(bn.momentum), L.ptr(bn.running_mean),
+                                       L.ptr(bn.running_var), L.ptr(bn.num_batches_tracked),
+                                       L.ptr(self.out_pw.scale), L.ptr(self.out_pw.shift),
+                                       L.ptr(self.save_mean), L.ptr(self.save_invstd), st), f"{self.name} bn")
+        else:
+            L.check(lib.bp_bn_eval_pointwise(c, L.ptr(bn.weight), L.ptr(bn.bias), L.ptr(bn.running_mean),
+                                             L.ptr(bn.running_var), float(bn.eps), L.ptr(self.out_pw.scale),
+                                             L.ptr(self.out_pw.shift), st), f"{self.name} bn eval")
+
+    # ---- backward
+    def prepare_backward(self):
+        lib = self.plan.lib
+        self.out.ensure_grad()
+        self.plan.need_ws(lib.bp_act_backward_workspace(C.byref(self.out.view)))
+        self.plan.need_ws(lib.bp_conv_backward_weight_workspace(C.byref(self.cv), C.byref(self.inp.view),
+                                                                C.byref(self.out.view)))
+        self.dx = self.inp.claim_grad() if self.need_dgrad else None
+
+    def backward(self, grads):
+        """``out.grad`` (+``out.grad2``) hold d/d(activated out).  Writes parameter gradients into
+        ``grads[id(param)]`` and d/d(activated in) into the view claimed from the input slot."""
+        out = self.out
+        if self.has_pw or out.grad2 is not None:
+            pw = None if self.out_pw is None else C.byref(self.out_pw.struct)
+            self.activation_backward(out.grad, out.grad2, pw, None, out.grad, out.grad, grads)
+        self.conv_backward(grads)
+
+    def activation_backward(self, dout, dout2, pw, act_out, g_out, d_raw_out, grads):
+        """g = (dout+dout2)*act'(t) -> g_out;  batch-norm backward of g -> d_raw_out."""
+        plan, lib, st = self.plan, self.plan.lib, _stream()
+        c = self.cv.cout
+        L.check(lib.bp_act_backward(C.byref(dout), None if dout2 is None else C.byref(dout2),
+                                    C.byref(self.out.view), pw, None if act_out is None else C.byref(act_out),
+                                    C.byref(g_out), L.ptr(self.sums), L.ptr(plan.ws), plan.ws_bytes, st),
+                f"{self.name} act backward")
+        if self.act == "prelu":
+            L.check(lib.bp_prelu_slope_grad(L.ptr(self.sums), c, L.ptr(grads[id(self.act_holder.weight)]), st),
+                    f"{self.name} prelu grad")
+        bn = self.bn
+        if bn is not None:
+            if plan.sync is not None:
+                plan.sync.all_reduce_sum(self.sums[:2 * c])
+            L.check(lib.bp_bn_backward_finalize(L.ptr(self.sums), self.count, c, L.ptr(bn.weight),
+                                                L.ptr(self.save_mean), L.ptr(self.save_invstd),
+                                                L.ptr(grads[id(bn.weight)]), L.ptr(grads[id(bn.bias)]),
+                                                L.ptr(self.abc), st), f"{self.name} bn backward")
+            L.check(lib.bp_bn_backward_apply(C.byref(g_out), C.byref(self.out.view), L.ptr(self.abc),
+                                             C.byref(d_raw_out), st), f"{self.name} bn backward apply")
+            return True
+        return False
+
+    def conv_backward(self, grads):
+        plan, lib, st = self.plan, self.plan.lib, _stream()
+        g, hold = self.out.grad, self.holder
+        dbias = None if hold.bias is None else grads[id(hold.bias)]
+        L.check(lib.bp_conv_backward_weight(C.byref(self.cv), C.byref(self.inp.view), self.inp.pw_struct(),
+                                            C.byref(g), L.ptr(grads[id(hold.weight)]), L.ptr(dbias),
+                                            L.ptr(plan.ws), plan.ws_bytes, plan.impl, st),
+                f"{self.name} backward_weight")
+        if self.dx is not None:
+            L.check(lib.bp_conv_backward_data(C.byref(self.cv), C.byref(g), L.ptr(self.packed_bwd),
+                                              L.ptr(hold.weight), C.byref(self.dx), plan.impl, st),
+                    f"{self.name} backward_data")
+
+
+class ResidualUnit:
+    """activation(res_block(x) + x)  (utils.py:22-38)."""
+
+    def __init__(self, plan, name, body_units, inp, tail):
+        self.plan, self.name = plan, name
+        self.body, self.inp = body_units, inp
+        kind, arg = tail
+        self.slope = {"relu": 0.0, None: 1.0}.get(kind, arg)
+        last = body_units[-1].out
+        if last.shape() != inp.shape():
+            raise ValueError(f"{name}: residual branch changes the shape")
+        self.out = Slot.new(inp.n, inp.h, inp.w, inp.c, plan.device, pw=None)
+        lp = last.pw if last.pw is not None else PW.identity(inp.c, plan.device)
+        # mask pointwise of the tail: the branch's affine, the tail's slope
+        self.tail_pw = PW(lp.scale, lp.shift, torch.full((inp.c,), float(self.slope), device=plan.device))
+
+    def forward(self, training):
+        for u in self.body:
+            u.forward(training)
+        last = self.body[-1].out
+        L.check(self.plan.lib.bp_residual_forward(C.byref(last.view), last.pw_struct(), C.byref(self.inp.view),
+                                                  self.inp.pw_struct(), float(self.slope),
+                                                  C.byref(self.out.view), _stream()), f"{self.name} tail")
+
+    def prepare_backward(self):
+        self.out.ensure_grad()
+        for u in reversed(self.body):
+            u.prepare_backward()
+        # skip path: d/d(act(inp)) also receives the tail's masked gradient, kept in out.grad
+        self.inp.set_grad2_alias(self.out.grad)
+
+    def backward(self, grads):
+        out, last = self.out, self.body[-1]
+        # g_t in place in out.grad (also the skip gradient); branch d_raw -> last.out.grad
+        had_bn = last.activation_backward(out.grad, out.grad2, C.byref(self.tail_pw.struct), out.view, out.grad,
+                                          last.out.grad, grads)
+        if not had_bn:
+            last.out.grad_buf.copy_(out.grad_buf)
+        last.conv_backward(grads)
+        for u in reversed(self.body[:-1]):
+            u.backward(grads)
+
+
+# ------------------------------------------------------------------ sequential compiler
+def compile_sequential(plan, prefix, architecture, holders, inp, out_slot=None, out_pw=None,
+                       need_input_grad=True):
+    """Group the layer list into units.  Returns (units, output slot, trailing) where
+    ``trailing`` lists parameter-free layers after the last convolution that are not
+    expressible as a pending pointwise (softplus / tanh / sigmoid / unflatten / flatten)."""
+    units, trailing = [], []
+    if architecture is None:
+        return units, inp, trailing
+    layers = []
+    for layer in architecture:
+        name = layer[0].lower()
+        layers.append((name, layer[1] if len(layer) == 2 else None))
+    # index of the last conv-like layer (its output may go to a concat slot)
+    conv_like = [i for i, (n, _) in enumerate(layers) if n in ("conv", "transp conv", "residual block")]
+    last_conv = conv_like[-1] if conv_like else -1
+    cur = inp
+    i = 0
+    first = True
+    while i < len(layers):
+        name, cfg = layers[i]
+        if name in ("conv", "transp conv"):
+            holder = holders[i]
+            j = i + 1
+            bn = act = act_arg = act_holder = None
+            if j < len(layers) and layers[j][0] == "batchnorm":
+                bn = holders[j]
+                j += 1
+            if j < len(layers) and layers[j][0] in ("relu", "leaky relu", "prelu"):
+                act, act_arg = layers[j][0], layers[j][1]
+                act_holder = holders[j] if act == "prelu" else None
+                j += 1
+            is_last = (i == last_conv)
+            u = ConvUnit(plan, f"{prefix}{i}", holder, bn, act, act_arg, act_holder, cur,
+                         out_slot=out_slot if is_last else None, out_pw=out_pw if is_last else None,
+                         need_dgrad=(need_input_grad or not first))
+            units.append(u)
+            cur = u.out
+            i = j
+        elif name == "residual block":
+            rh = holders[i]
+            body, body_out, tr = compile_sequential(plan, f"{prefix}{i}.res_block.", cfg[0], rh.res_block, cur)
+            if tr:
+                raise NotImplementedError("residual branch must end in a convolution/batch-norm")
+            if i == last_conv and out_slot is not None:
+                raise NotImplementedError("residual block as the last layer of a concatenated branch")
+            u = ResidualUnit(plan, f"{prefix}{i}", body, cur, rh.tail)
+            units.append(u)
+            cur = u.out
+            i += 1
+        elif name in ("softplus", "tanh", "sigmoid", "unflatten", "flatten"):
+            if i < last_conv:
+                raise NotImplementedError(f"{prefix}{i}: '{name}' between convolutions is not supported "
+                                          "by the HIP path")
+            trailing.append((name, cfg))
+            i += 1
+        else:
+            raise NotImplementedError(f"{prefix}{i}: layer '{name}' is not supported by the HIP path here")
+        first = False
+    return units, cur, trailing
+
+
+def probe_output(architecture, c, h, w):
+    """(c,h,w) produced by a layer list, without building anything."""
+    for layer in architecture or []:
+        name = layer[0].lower()
+        if name in ("conv", "transp conv"):
+            cfg = layer[1]
+            k, st, pd = cfg["kernel_size"], cfg.get("stride", 1), cfg.get("padding", 0)
+            if name == "conv":
+                h, w = (h + 2 * pd - k) // st + 1, (w + 2 * pd - k) // st + 1
+            else:
+                op = cfg.get("output_padding", 0)
+                h, w = (h - 1) * st - 2 * pd + k + op, (w - 1) * st - 2 * pd + k + op
+            c = cfg["out_channels"]
+    return c, h, w

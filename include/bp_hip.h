@@ -1,0 +1,212 @@
+/*
+ * bp_hip.h -- C ABI of the MI355X (gfx950) kernels behind the baryon_painter CVAE hot path.
+ *
+ * The reference has no FFI: its arithmetic boundary is the set of stock torch.nn modules that
+ * `build_sequential` instantiates (/root/reference/baryon_painter/models/utils.py:114-157) plus
+ * the tensor expressions in models/cvae.py:63-146.  Each entry point below replaces one of those
+ * call sites (cited per function).  Signatures use plain pointers and sizes only; all buffers are
+ * device memory owned by the caller, nothing is allocated or synchronised inside, every launch
+ * goes to `stream` (a hipStream_t passed as void*), so a call sequence can be captured in a
+ * hipGraph.  Return value: BP_OK or a negative error code; nothing is launched on error.
+ *
+ * Data layout: activations are NHWC fp32.  A `bp_view` addresses channels [coff, coff+c) of a
+ * buffer whose pixels are `cstride` floats apart, so channel concatenation (cvae.py:72,109) is
+ * "write into a slice".  Convolution outputs are stored RAW (pre batch-norm / pre activation);
+ * the per-channel affine + leaky-ReLU that follows them in the module list (BatchNorm2d + ReLU /
+ * PReLU / LeakyReLU) is described by a `bp_pointwise` and applied by the CONSUMER while it stages
+ * its input ("lazy activation"), which keeps every activation at one HBM write + one read.
+ */
+#ifndef BP_HIP_H
+#define BP_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BP_OK 0
+#define BP_EINVAL (-1)       /* inconsistent shapes / null pointers */
+#define BP_EUNSUPPORTED (-2) /* shape outside what the kernels are built for */
+#define BP_ELAUNCH (-3)      /* hipGetLastError() != hipSuccess after the launch */
+#define BP_EWORKSPACE (-4)   /* workspace too small */
+
+/* NHWC view: element (n,y,x,ch) lives at ptr[((n*h + y)*w + x)*cstride + coff + ch]. */
+typedef struct bp_view {
+  float* ptr;
+  int32_t n, h, w;
+  int32_t c;       /* channels in this view            */
+  int32_t cstride; /* channels of the underlying buffer */
+  int32_t coff;    /* first channel of the view         */
+} bp_view;
+
+/* Per-channel t = x*scale[ch] + shift[ch];  y = t > 0 ? t : t*slope[ch].
+ * scale == NULL means identity (no transform at all).  ReLU: slope 0; PReLU: slope a;
+ * identity-with-affine: slope 1.  Arrays have `c` entries of the view they accompany. */
+typedef struct bp_pointwise {
+  const float* scale;
+  const float* shift;
+  const float* slope;
+} bp_pointwise;
+
+/* torch.nn.Conv2d / ConvTranspose2d hyper-parameters (utils.py:128-131, square kernels). */
+typedef struct bp_conv {
+  int32_t transposed; /* 0: Conv2d, 1: ConvTranspose2d */
+  int32_t cin, cout;  /* module in_channels / out_channels */
+  int32_t k, stride, pad, out_pad;
+} bp_conv;
+
+enum { BP_IMPL_AUTO = 0, BP_IMPL_DIRECT = 1, BP_IMPL_MFMA = 2 };
+enum { BP_PACK_FWD = 0, BP_PACK_BWD = 1 };
+
+/* ---- library ------------------------------------------------------------------------------ */
+int bp_version(void);
+const char* bp_strerror(int code);
+
+/* ---- convolution (replaces nn.Conv2d / nn.ConvTranspose2d forward + their autograd backward,
+ *      utils.py:128-131, painter.py:227) ----------------------------------------------------- */
+
+/* Number of floats of the packed weight image for direction `dir` (BP_PACK_FWD feeds
+ * bp_conv_forward, BP_PACK_BWD feeds bp_conv_backward_data). */
+int64_t bp_conv_packed_floats(const bp_conv* cv, int dir);
+
+/* Re-layout torch-format weights (Conv2d: [cout][cin][k][k]; ConvTranspose2d: [cin][cout][k][k])
+ * into the MFMA image [phase][tap][cin_chunk][cout_pad][chunk] (zero padded).  Must be re-run
+ * whenever the weights change (once per optimiser step). */
+int bp_conv_pack(const bp_conv* cv, int dir, const float* w_torch, float* packed, void* stream);
+
+/* y_raw = conv(act(x)) [+ bias].  `x_pw` may be NULL (identity). */
+int bp_conv_forward(const bp_conv* cv, const bp_view* x, const bp_pointwise* x_pw,
+                    const float* packed_fwd, const float* w_torch, const float* bias,
+                    const bp_view* y, int impl, void* stream);
+
+/* dx = d(loss)/d(act(x)) given dy = d(loss)/d(y_raw).  (The activation's own derivative is
+ * applied afterwards by bp_act_backward.) */
+int bp_conv_backward_data(const bp_conv* cv, const bp_view* dy, const float* packed_bwd,
+                          const float* w_torch, const bp_view* dx, int impl, void* stream);
+
+/* dw (torch layout, overwritten) and optionally dbias (NULL to skip) from act(x) and dy. */
+size_t bp_conv_backward_weight_workspace(const bp_conv* cv, const bp_view* x, const bp_view* dy);
+int bp_conv_backward_weight(const bp_conv* cv, const bp_view* x, const bp_pointwise* x_pw,
+                            const bp_view* dy, float* dw_torch, float* dbias, void* workspace,
+                            size_t workspace_bytes, int impl, void* stream);
+
+/* ---- batch norm (replaces nn.BatchNorm2d, utils.py:146-147) -------------------------------- */
+
+/* Per-channel double sums[2*c] = {sum x, sum x^2} over all pixels of `x` (deterministic two-stage
+ * reduction).  workspace: bp_channel_sums_workspace(x) bytes.  Under data parallelism the caller
+ * all-reduces `sums` across ranks before bp_bn_finalize (global-batch statistics). */
+size_t bp_channel_sums_workspace(const bp_view* x);
+int bp_channel_sums(const bp_view* x, double* sums, void* workspace, size_t workspace_bytes,
+                    void* stream);
+
+/* Train mode: batch mean / biased variance from `sums` and `count` (= N*H*W over all ranks),
+ * writes the consumer's pointwise (scale = gamma*invstd, shift = beta - mean*scale), saves
+ * mean/invstd for backward and updates running stats (momentum, unbiased variance) and
+ * num_batches_tracked (int64, may be NULL). */
+int bp_bn_finalize(const double* sums, double count, int32_t c, const float* gamma,
+                   const float* beta, float eps, float momentum, float* running_mean,
+                   float* running_var, int64_t* num_batches_tracked, float* scale, float* shift,
+                   float* save_mean, float* save_invstd, void* stream);
+
+/* Eval mode: scale/shift from the running statistics. */
+int bp_bn_eval_pointwise(int32_t c, const float* gamma, const float* beta,
+                         const float* running_mean, const float* running_var, float eps,
+                         float* scale, float* shift, void* stream);
+
+/* ---- activation / batch-norm backward ------------------------------------------------------ */
+
+/* Backward through y = leaky(raw*scale+shift [+ skip], slope):
+ *   g = (dout [+ dout2]) * act'(t)           written to `g` (may alias dout)
+ *   sums[3*c] (double) = { sum g, sum g*raw, sum (dout[+dout2]) * t * [t<=0] }  (third: d slope)
+ * `act_out`, if given, is the saved activated output and supplies the sign of t (residual
+ * blocks, where t includes the skip); otherwise t is recomputed from raw and `pw`. */
+size_t bp_act_backward_workspace(const bp_view* raw);
+int bp_act_backward(const bp_view* dout, const bp_view* dout2, const bp_view* raw,
+                    const bp_pointwise* pw, const bp_view* act_out, const bp_view* g,
+                    double* sums, void* workspace, size_t workspace_bytes, void* stream);
+
+/* From the (all-reduced) sums: dgamma, dbeta and the coefficients of
+ *   d_raw = A*g + B*raw + C   (batch-norm backward as a per-channel affine map of (g, raw)). */
+int bp_bn_backward_finalize(const double* sums, double count, int32_t c, const float* gamma,
+                            const float* save_mean, const float* save_invstd, float* dgamma,
+                            float* dbeta, float* coef_abc /* [3*c] */, void* stream);
+
+/* out = A*g + B*raw + C  (out may alias g). */
+int bp_bn_backward_apply(const bp_view* g, const bp_view* raw, const float* coef_abc,
+                         const bp_view* out, void* stream);
+
+/* dst[ch] = (float) sums[ch]  (e.g. a bias gradient from bp_channel_sums of dy). */
+int bp_sums_to_float(const double* sums, int32_t c, float* dst, void* stream);
+
+/* PReLU slope gradient (one shared slope, utils.py:137): dslope = sum over channels of sums[2]. */
+int bp_prelu_slope_grad(const double* sums, int32_t c, float* dslope, void* stream);
+
+/* ---- residual block tail (utils.py:35-37): out = leaky(raw*scale+shift + act(skip), slope) -- */
+int bp_residual_forward(const bp_view* raw, const bp_pointwise* pw, const bp_view* skip,
+                        const bp_pointwise* skip_pw, float slope, const bp_view* out, void* stream);
+
+/* ---- layout glue ---------------------------------------------------------------------------- */
+
+/* NCHW (N,c,H,W) -> channels [coff, coff+c) of `out`, and the aux label(s) (N,caux) broadcast to
+ * constant planes in the next caux channels (merge_aux_label, utils.py:159-182). aux may be NULL. */
+int bp_nchw_to_view(const float* src_nchw, int32_t c, const float* aux, int32_t caux,
+                    const bp_view* out, void* stream);
+/* dst = [softplus](act(src)) as NCHW; `softplus` = 1 applies torch's Softplus(beta=1,threshold=20). */
+int bp_view_to_nchw(const bp_view* src, const bp_pointwise* pw, int32_t softplus, float* dst_nchw,
+                    void* stream);
+int bp_fill(float* dst, int64_t n, float value, void* stream);
+
+/* ---- latent heads: reparametrisation sampler + KL (cvae.py:63-66, 76-77, 126-130) ----------- */
+typedef struct bp_latent {
+  int32_t n;      /* batch M                         */
+  int32_t L;      /* samples per datum (cvae.py:21)  */
+  int32_t zc, zh, zw;
+  float min_z_var;
+} bp_latent;
+
+/* q_raw / p_raw: raw head outputs (N,zh,zw,2*zc) with their pointwise (BN+ReLU); p_raw may be
+ * NULL (no prior network: standard-normal prior).  eps: (L,N,zc,zh,zw) standard normal.
+ * Outputs: stats4 (4,N,zc,zh,zw) = {z_mu, z_log_var, prior_mu, prior_log_var} (NCHW planes),
+ * z (L*N, zh, zw, zc) view, kl_sum: one double = sum[...] of cvae.py:129-130 (un-normalised). */
+int bp_latent_forward(const bp_latent* lt, const bp_view* q_raw, const bp_pointwise* q_pw,
+                      const bp_view* p_raw, const bp_pointwise* p_pw, const float* eps,
+                      float* stats4, const bp_view* z, double* kl_sum, void* workspace,
+                      size_t workspace_bytes, void* stream);
+/* Gradients w.r.t. the ACTIVATED head outputs (N,zh,zw,2*zc): reparametrisation + KL terms. */
+int bp_latent_backward(const bp_latent* lt, const bp_view* dz, const float* stats4,
+                       const float* eps, const float* seed /* device scalar dL/dELBO */,
+                       float beta_kl, const bp_view* dq_act, const bp_view* dp_act, void* stream);
+
+/* ---- Gaussian log-likelihood head (cvae.py:132-146) ----------------------------------------- */
+typedef struct bp_loglik {
+  int32_t n;  /* M */
+  int32_t L;
+  int32_t c, h, w;
+  int32_t mu_softplus;  /* last activation of the mean head: 1 softplus, 0 none */
+  int32_t predict_var;
+  float alpha_var, beta_kl, likelihood_scaling;
+} bp_loglik;
+
+/* x: NCHW (M,c,H,W); mu_raw / var_raw: (L*M,H,W,c) raw head outputs with optional pointwise.
+ * Writes x_mu (NCHW, L*M) [and x_log_var], and stats (floats):
+ *   [0]=ELBO [1]=KL_term [2..2+c)=log_likelihood [..+c)=fixed_var [..+c)=free_var. */
+size_t bp_loglik_workspace(const bp_loglik* ll);
+int bp_loglik_forward(const bp_loglik* ll, const float* x_nchw, const bp_view* mu_raw,
+                      const bp_view* var_raw, const double* kl_sum, float* x_mu_nchw,
+                      float* x_log_var_nchw, float* stats, void* workspace,
+                      size_t workspace_bytes, void* stream);
+/* d(seed*ELBO)/d(mu_raw), d/d(var_raw). */
+int bp_loglik_backward(const bp_loglik* ll, const float* x_nchw, const bp_view* mu_raw,
+                       const bp_view* var_raw, const float* seed, const bp_view* d_mu_raw,
+                       const bp_view* d_var_raw, void* stream);
+
+/* ---- optimiser (replaces torch.optim.Adam.step, painter.py:93,228; same arithmetic) --------- */
+int bp_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                 float lr, float beta1, float beta2, float eps, int32_t step, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BP_HIP_H */

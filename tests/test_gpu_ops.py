@@ -1,0 +1,247 @@
+"""GPU parity of every operator entry point of the C ABI against the NumPy oracle and the
+golden fixtures generated from the reference (tests/golden/ops.npz).
+
+Tolerance: fp32 matrix-core FMA chains vs float64 oracle, relative to each tensor's scale:
+2e-5 for forward/data-gradient, 1e-4 for weight gradients (longer reductions)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from baryon_painter_amd import _lib as L
+from baryon_painter_amd.utils import synthetic as syn
+from golden.make_goldens_cases import OP_CASES
+from golden_util import check
+from oracle import ops
+
+import gpu_util as G
+
+pytestmark = pytest.mark.gpu
+
+
+def _case(idx):
+    name, kind, cfg, (n, h, w) = OP_CASES[idx]
+    cfg = dict(cfg)
+    cfg.setdefault("bias", False)
+    tr = kind == "transp conv"
+    wshape = ((cfg["in_channels"], cfg["out_channels"]) if tr else (cfg["out_channels"], cfg["in_channels"])) \
+        + (cfg["kernel_size"],) * 2
+    shapes = {"0.weight": wshape}
+    if cfg["bias"]:
+        shapes["0.bias"] = (cfg["out_channels"],)
+    P = syn.fill_params(shapes, 100 + idx)
+    x = syn.synthetic_eps((n, cfg["in_channels"], h, w), seed=200 + idx)
+    cv = L.Conv(1 if tr else 0, cfg["in_channels"], cfg["out_channels"], cfg["kernel_size"], cfg["stride"],
+                cfg["padding"], cfg.get("output_padding", 0))
+    return name, cfg, tr, P, x, cv
+
+
+@pytest.mark.parametrize("impl", [L.IMPL_DIRECT, L.IMPL_MFMA], ids=["direct", "mfma"])
+@pytest.mark.parametrize("idx", range(len(OP_CASES)))
+def test_conv_forward_backward(idx, impl, golden_ops):
+    lib = L.load()
+    name, cfg, tr, P, x, cv = _case(idx)
+    w = P["0.weight"]
+    bias = P.get("0.bias")
+    s, p, op = cfg["stride"], cfg["padding"], cfg.get("output_padding", 0)
+    x64, w64 = x.astype(np.float64), w.astype(np.float64)
+    y_ref = ops.convT2d_fwd(x64, w64, s, p, op) if tr else ops.conv2d_fwd(x64, w64, s, p)
+    if bias is not None:
+        y_ref = y_ref + bias[None, :, None, None]
+    n, co, ho, wo = y_ref.shape
+    dy = syn.synthetic_eps(y_ref.shape, seed=300 + idx)
+    st = G.stream()
+    # odd channel strides/offsets on purpose when the channel count is small
+    cs_in = x.shape[1] + (3 if x.shape[1] < 8 else 0)
+    xb, xv = G.to_nhwc(x, cstride=cs_in, coff=(1 if x.shape[1] < 8 else 0))
+    yb, yv = G.empty_nhwc(n, ho, wo, co)
+    wd = G.dev(w)
+    bd = None if bias is None else G.dev(bias)
+    nf = lib.bp_conv_packed_floats(C.byref(cv), L.PACK_FWD)
+    nb = lib.bp_conv_packed_floats(C.byref(cv), L.PACK_BWD)
+    assert nf > 0 and nb > 0
+    pf = torch.zeros(nf, device="cuda")
+    pb = torch.zeros(nb, device="cuda")
+    L.check(lib.bp_conv_pack(C.byref(cv), L.PACK_FWD, L.ptr(wd), L.ptr(pf), st))
+    L.check(lib.bp_conv_pack(C.byref(cv), L.PACK_BWD, L.ptr(wd), L.ptr(pb), st))
+    L.check(lib.bp_conv_forward(C.byref(cv), C.byref(xv), None, L.ptr(pf), L.ptr(wd), L.ptr(bd), C.byref(yv),
+                                impl, st), "forward")
+    y = G.from_nhwc(yb, co)
+    assert G.rel_err(y, y_ref) < 2e-5
+    check(f"{name}/y", y, golden_ops, 5e-5)
+
+    # data gradient
+    dyb, dyv = G.to_nhwc(dy)
+    dxb, dxv = G.empty_nhwc(*[x.shape[i] for i in (0, 2, 3, 1)])
+    L.check(lib.bp_conv_backward_data(C.byref(cv), C.byref(dyv), L.ptr(pb), L.ptr(wd), C.byref(dxv), impl, st),
+            "backward_data")
+    dx = G.from_nhwc(dxb, x.shape[1])
+    dy64 = dy.astype(np.float64)
+    dx_ref = ops.convT2d_bwd_data(dy64, w64, s, p) if tr else ops.conv2d_bwd_data(dy64, w64, s, p, *x.shape[2:])
+    assert G.rel_err(dx, dx_ref) < 2e-5
+    check(f"{name}/dx", dx, golden_ops, 5e-5)
+
+    # weight (+bias) gradient
+    ws_bytes = lib.bp_conv_backward_weight_workspace(C.byref(cv), C.byref(xv), C.byref(dyv))
+    ws = torch.zeros(ws_bytes // 8 + 8, dtype=torch.float64, device="cuda")
+    dw = torch.full(w.shape, float("nan"), device="cuda")
+    db = None if bias is None else torch.full(bias.shape, float("nan"), device="cuda")
+    L.check(lib.bp_conv_backward_weight(C.byref(cv), C.byref(xv), None, C.byref(dyv), L.ptr(dw), L.ptr(db),
+                                        L.ptr(ws), ws.numel() * 8, impl, st), "backward_weight")
+    k = cfg["kernel_size"]
+    dw_ref = ops.convT2d_bwd_weight(x64, dy64, s, p, k, k) if tr else ops.conv2d_bwd_weight(x64, dy64, s, p, k, k)
+    assert G.rel_err(dw.cpu().numpy(), dw_ref) < 1e-4
+    check(f"{name}/d_0.weight", dw.cpu().numpy(), golden_ops, 2e-4)
+    if bias is not None:
+        check(f"{name}/d_0.bias", db.cpu().numpy(), golden_ops, 2e-4)
+
+
+@pytest.mark.parametrize("impl", [L.IMPL_DIRECT, L.IMPL_MFMA], ids=["direct", "mfma"])
+def test_conv_lazy_activation_and_zero_padding(impl):
+    """The consumer applies the producer's affine+leaky-ReLU while loading; padding is zero in
+    the ACTIVATED domain (torch pads after the activation)."""
+    lib = L.load()
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((2, 16, 9, 11)).astype(np.float32)
+    w = (rng.standard_normal((32, 16, 3, 3)) * 0.2).astype(np.float32)
+    scale = rng.uniform(0.5, 1.5, 16).astype(np.float32)
+    shift = rng.uniform(0.2, 0.6, 16).astype(np.float32)      # act(0) != 0: padding must stay 0
+    slope = np.full(16, 0.1, np.float32)
+    t = x * scale[None, :, None, None] + shift[None, :, None, None]
+    xa = np.where(t > 0, t, t * slope[None, :, None, None]).astype(np.float64)
+    y_ref = ops.conv2d_fwd(xa, w.astype(np.float64), 1, 1)
+    cv = L.Conv(0, 16, 32, 3, 1, 1, 0)
+    st = G.stream()
+    xb, xv = G.to_nhwc(x)
+    yb, yv = G.empty_nhwc(2, 9, 11, 32)
+    keep, pw = G.pointwise(scale, shift, slope)
+    wd = G.dev(w)
+    pf = torch.zeros(lib.bp_conv_packed_floats(C.byref(cv), L.PACK_FWD), device="cuda")
+    L.check(lib.bp_conv_pack(C.byref(cv), L.PACK_FWD, L.ptr(wd), L.ptr(pf), st))
+    L.check(lib.bp_conv_forward(C.byref(cv), C.byref(xv), C.byref(pw), L.ptr(pf), L.ptr(wd), None, C.byref(yv),
+                                impl, st))
+    assert G.rel_err(G.from_nhwc(yb, 32), y_ref) < 2e-5
+    # weight gradient sees the activated input too
+    dy = rng.standard_normal(y_ref.shape).astype(np.float32)
+    dyb, dyv = G.to_nhwc(dy)
+    ws_bytes = lib.bp_conv_backward_weight_workspace(C.byref(cv), C.byref(xv), C.byref(dyv))
+    ws = torch.zeros(ws_bytes // 8 + 8, dtype=torch.float64, device="cuda")
+    dw = torch.zeros(w.shape, device="cuda")
+    L.check(lib.bp_conv_backward_weight(C.byref(cv), C.byref(xv), C.byref(pw), C.byref(dyv), L.ptr(dw), None,
+                                        L.ptr(ws), ws.numel() * 8, impl, st))
+    dw_ref = ops.conv2d_bwd_weight(xa, dy.astype(np.float64), 1, 1, 3, 3)
+    assert G.rel_err(dw.cpu().numpy(), dw_ref) < 1e-4
+
+
+def test_conv_rejects_bad_shapes():
+    lib = L.load()
+    cv = L.Conv(0, 16, 32, 3, 1, 1, 0)
+    xb, xv = G.empty_nhwc(2, 8, 8, 16)
+    yb, yv = G.empty_nhwc(2, 7, 8, 32)          # wrong height
+    assert lib.bp_conv_forward(C.byref(cv), C.byref(xv), None, None, L.ptr(xb), None, C.byref(yv), L.IMPL_DIRECT,
+                               G.stream()) == -1
+    bad = L.Conv(0, 0, 32, 3, 1, 1, 0)
+    assert lib.bp_conv_packed_floats(C.byref(bad), L.PACK_FWD) == -1
+
+
+def test_batchnorm_relu_chain(golden_ops):
+    """channel sums -> finalize -> (lazy apply) ; act backward -> bn backward."""
+    lib = L.load()
+    st = G.stream()
+    Pm = syn.fill_params({"0.weight": (5,), "0.bias": (5,)}, 400)
+    gamma, beta = Pm["0.weight"], Pm["0.bias"]
+    x = (syn.synthetic_eps((3, 5, 6, 7), seed=401) * 1.7 + 0.3).astype(np.float32)
+    dy = syn.synthetic_eps((3, 5, 6, 7), seed=402)
+    xb, xv = G.to_nhwc(x, cstride=8, coff=2)
+    sums = torch.zeros(15, dtype=torch.float64, device="cuda")
+    ws = torch.zeros(1 << 16, dtype=torch.float64, device="cuda")
+    L.check(lib.bp_channel_sums(C.byref(xv), L.ptr(sums), L.ptr(ws), ws.numel() * 8, st))
+    x64 = x.astype(np.float64)
+    assert G.rel_err(sums[:5].cpu().numpy(), x64.sum(axis=(0, 2, 3))) < 1e-12
+    assert G.rel_err(sums[5:10].cpu().numpy(), (x64 ** 2).sum(axis=(0, 2, 3))) < 1e-12
+    g, b = G.dev(gamma), G.dev(beta)
+    rm, rv = torch.zeros(5, device="cuda"), torch.ones(5, device="cuda")
+    nbt = torch.zeros((), dtype=torch.int64, device="cuda")
+    scale, shift = torch.zeros(5, device="cuda"), torch.zeros(5, device="cuda")
+    mean, inv = torch.zeros(5, device="cuda"), torch.zeros(5, device="cuda")
+    cnt = float(3 * 6 * 7)
+    L.check(lib.bp_bn_finalize(L.ptr(sums), cnt, 5, L.ptr(g), L.ptr(b), 1e-5, 0.1, L.ptr(rm), L.ptr(rv),
+                               L.ptr(nbt), L.ptr(scale), L.ptr(shift), L.ptr(mean), L.ptr(inv), st))
+    check("bn_relu/running_mean", rm.cpu().numpy(), golden_ops, 1e-6)
+    check("bn_relu/running_var", rv.cpu().numpy(), golden_ops, 1e-6)
+    assert int(nbt.item()) == 1
+    slope = torch.zeros(5, device="cuda")
+    pw = L.Pointwise(scale.data_ptr(), shift.data_ptr(), slope.data_ptr())
+    out = torch.empty((3, 5, 6, 7), device="cuda")
+    L.check(lib.bp_view_to_nchw(C.byref(xv), C.byref(pw), 0, L.ptr(out), st))
+    check("bn_relu/y", out.cpu().numpy(), golden_ops, 1e-5)
+    # backward
+    dyb, dyv = G.to_nhwc(dy)
+    gb, gv = G.empty_nhwc(3, 6, 7, 5)
+    L.check(lib.bp_act_backward(C.byref(dyv), None, C.byref(xv), C.byref(pw), None, C.byref(gv), L.ptr(sums),
+                                L.ptr(ws), ws.numel() * 8, st))
+    dgam, dbet, abc = torch.zeros(5, device="cuda"), torch.zeros(5, device="cuda"), torch.zeros(15, device="cuda")
+    L.check(lib.bp_bn_backward_finalize(L.ptr(sums), cnt, 5, L.ptr(g), L.ptr(mean), L.ptr(inv), L.ptr(dgam),
+                                        L.ptr(dbet), L.ptr(abc), st))
+    L.check(lib.bp_bn_backward_apply(C.byref(gv), C.byref(xv), L.ptr(abc), C.byref(gv), st))
+    check("bn_relu/dx", G.from_nhwc(gb, 5), golden_ops, 2e-5)
+    check("bn_relu/d_0.weight", dgam.cpu().numpy(), golden_ops, 2e-5)
+    check("bn_relu/d_0.bias", dbet.cpu().numpy(), golden_ops, 2e-5)
+    # eval-mode pointwise from running stats
+    L.check(lib.bp_bn_eval_pointwise(5, L.ptr(g), L.ptr(b), L.ptr(rm), L.ptr(rv), 1e-5, L.ptr(scale),
+                                     L.ptr(shift), st))
+    L.check(lib.bp_view_to_nchw(C.byref(xv), C.byref(pw), 0, L.ptr(out), st))
+    check("bn_relu/y_eval", out.cpu().numpy(), golden_ops, 1e-5)
+
+
+def test_prelu_and_softplus(golden_ops):
+    lib = L.load()
+    st = G.stream()
+    x = (syn.synthetic_eps((2, 3, 5, 5), seed=410) * 8.0)
+    x[0, 0, 0, 0] = 25.0
+    dy = syn.synthetic_eps((2, 3, 5, 5), seed=411)
+    xb, xv = G.to_nhwc(x)
+    keep, pw = G.pointwise(np.ones(3), np.zeros(3), np.full(3, 0.25))
+    out = torch.empty((2, 3, 5, 5), device="cuda")
+    L.check(lib.bp_view_to_nchw(C.byref(xv), C.byref(pw), 0, L.ptr(out), st))
+    check("act_prelu/y", out.cpu().numpy(), golden_ops, 1e-6)
+    L.check(lib.bp_view_to_nchw(C.byref(xv), None, 1, L.ptr(out), st))
+    check("act_softplus/y", out.cpu().numpy(), golden_ops, 1e-6)
+    dyb, dyv = G.to_nhwc(dy)
+    gb, gv = G.empty_nhwc(2, 5, 5, 3)
+    sums = torch.zeros(9, dtype=torch.float64, device="cuda")
+    ws = torch.zeros(1 << 14, dtype=torch.float64, device="cuda")
+    L.check(lib.bp_act_backward(C.byref(dyv), None, C.byref(xv), C.byref(pw), None, C.byref(gv), L.ptr(sums),
+                                L.ptr(ws), ws.numel() * 8, st))
+    check("act_prelu/dx", G.from_nhwc(gb, 3), golden_ops, 1e-6)
+    da = torch.zeros(1, device="cuda")
+    L.check(lib.bp_prelu_slope_grad(L.ptr(sums), 3, L.ptr(da), st))
+    check("act_prelu/d_0.weight", da.cpu().numpy(), golden_ops, 1e-5)
+
+
+def test_merge_aux_label_layout(golden_ops):
+    lib = L.load()
+    yv = syn.synthetic_eps((3, 1, 4, 5), seed=430)
+    aux = np.array([0.0, 0.5, 2.0], np.float32)
+    ob, ov = G.empty_nhwc(3, 4, 5, 2, cstride=4, coff=1)
+    L.check(lib.bp_nchw_to_view(L.ptr(G.dev(yv)), 1, L.ptr(G.dev(aux)), 1, C.byref(ov), G.stream()))
+    got = G.from_nhwc(ob, 2, coff=1)
+    assert np.array_equal(got, golden_ops["merge_aux/out/full"].reshape(got.shape))   # bit-exact copy
+
+
+def test_adam_matches_torch():
+    lib = L.load()
+    rng = np.random.default_rng(0)
+    p0 = rng.standard_normal(10007).astype(np.float32)
+    ref = torch.nn.Parameter(torch.from_numpy(p0.copy()))
+    opt = torch.optim.Adam([ref], lr=1e-3)
+    p = G.dev(p0)
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    for step in range(1, 4):
+        g = rng.standard_normal(10007).astype(np.float32)
+        ref.grad = torch.from_numpy(g.copy())
+        opt.step()
+        L.check(lib.bp_adam_step(L.ptr(p), L.ptr(G.dev(g)), L.ptr(m), L.ptr(v), p.numel(), 1e-3, 0.9, 0.999, 1e-8,
+                                 step, G.stream()))
+    assert G.rel_err(p.cpu().numpy(), ref.detach().numpy()) < 1e-6
