@@ -49,6 +49,7 @@ SIGNATURES = {
     "bp_version": (C.c_int, []),
     "bp_strerror": (C.c_char_p, [C.c_int]),
     "bp_conv_packed_floats": (C.c_int64, [_CP, C.c_int]),
+    "bp_conv_kernel_id": (C.c_int, [_CP, C.c_int]),
     "bp_conv_pack": (C.c_int, [_CP, C.c_int, _P, _P, _P]),
     "bp_conv_forward": (C.c_int, [_CP, _VP, _PWP, _P, _P, _P, _VP, C.c_int, _P]),
     "bp_conv_backward_data": (C.c_int, [_CP, _VP, _P, _P, _VP, C.c_int, _P]),

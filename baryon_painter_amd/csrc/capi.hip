@@ -3,6 +3,7 @@
 #include "common.hpp"
 
 int64_t bp_igemm_packed_floats(const ConvGeom& g);
+int bp_igemm_kernel_id(const ConvGeom& g);
 int bp_igemm_pack(const ConvGeom& g, const WeightMap& wm, const float* w_torch, float* packed, hipStream_t st);
 int bp_igemm_run(const ConvGeom& g, const bp_view* in, const PW& pw, const float* packed, const float* bias,
                  const bp_view* out, hipStream_t st);
@@ -53,6 +54,11 @@ int64_t bp_conv_packed_floats(const bp_conv* cv, int dir) {
   if (!conv_ok(cv) || (dir != BP_PACK_FWD && dir != BP_PACK_BWD)) return -1;
   const ConvGeom g = dir == BP_PACK_FWD ? bp_geom_forward(cv) : bp_geom_backward_data(cv);
   return bp_igemm_packed_floats(g);
+}
+
+int bp_conv_kernel_id(const bp_conv* cv, int dir) {
+  if (!conv_ok(cv) || (dir != BP_PACK_FWD && dir != BP_PACK_BWD)) return -1;
+  return bp_igemm_kernel_id(dir == BP_PACK_FWD ? bp_geom_forward(cv) : bp_geom_backward_data(cv));
 }
 
 int bp_conv_pack(const bp_conv* cv, int dir, const float* w_torch, float* packed, void* stream) {

@@ -290,6 +290,11 @@ int launch_mt(const IgemmConfig& c, const IgemmArgs& a, dim3 grid, hipStream_t s
 
 }  // namespace
 
+int bp_igemm_kernel_id(const ConvGeom& g) {
+  const IgemmConfig c = igemm_config(g);
+  return c.ok ? c.CC * 1000 + c.NT * 100 + c.WN * 10 + c.MT : -1;
+}
+
 int64_t bp_igemm_packed_floats(const ConvGeom& g) {
   const IgemmConfig c = igemm_config(g);
   if (!c.ok) return -1;

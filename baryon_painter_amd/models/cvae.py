@@ -152,6 +152,23 @@ class _Plan:
     def need_ws(self, nbytes):
         self.ws_bytes = max(self.ws_bytes, int(nbytes))
 
+    # per-launch HIP-event timing of the convolution kernels (bench.py roofline); off by default
+    prof = None
+
+    def prof_begin(self):
+        if self.prof is None:
+            return None
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        return e
+
+    def prof_end(self, e0, unit, kind):
+        if e0 is None:
+            return
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        self.prof.append((e0, e1, unit, kind))
+
     @staticmethod
     def _no_trailing(tr, where):
         if tr:

@@ -254,6 +254,12 @@ class ConvUnit:
         self.dx = None
         plan.need_ws(lib.bp_channel_sums_workspace(C.byref(self.out.view)))
 
+    def macs(self):
+        """Multiply-accumulates of one forward (= of each of the two gradients)."""
+        cv = self.cv
+        dense = self.inp if cv.transposed else self.out       # the grid every tap visits
+        return dense.n * dense.h * dense.w * cv.k * cv.k * cv.cin * cv.cout
+
     # ---- weights
     def maybe_pack(self):
         w = self.holder.weight
@@ -271,9 +277,11 @@ class ConvUnit:
         plan, lib, st = self.plan, self.plan.lib, _stream()
         self.maybe_pack()
         hold = self.holder
+        t0 = plan.prof_begin()
         L.check(lib.bp_conv_forward(C.byref(self.cv), C.byref(self.inp.view), self.inp.pw_struct(),
                                     L.ptr(self.packed_fwd), L.ptr(hold.weight), L.ptr(hold.bias),
                                     C.byref(self.out.view), plan.impl, st), f"{self.name} forward")
+        plan.prof_end(t0, self, "forward")
         c = self.cv.cout
         if self.act == "prelu":
             self.out_pw.slope.copy_(self.act_holder.weight.detach().expand(c))
@@ -284,7 +292,7 @@ class ConvUnit:
             L.check(lib.bp_channel_sums(C.byref(self.out.view), L.ptr(self.sums), L.ptr(plan.ws), plan.ws_bytes,
                                         st), f"{self.name} bn stats")
             count = float(self.out.n * self.out.h * self.out.w)
-            if plan.sync is not None:
+            if plan.sync is not None and plan.sync.sync_bn:
                 plan.sync.all_reduce_sum(self.sums[:2 * c])
                 count *= plan.sync.world_size
             self.count = count
@@ -329,7 +337,7 @@ class ConvUnit:
                     f"{self.name} prelu grad")
         bn = self.bn
         if bn is not None:
-            if plan.sync is not None:
+            if plan.sync is not None and plan.sync.sync_bn:
                 plan.sync.all_reduce_sum(self.sums[:2 * c])
             L.check(lib.bp_bn_backward_finalize(L.ptr(self.sums), self.count, c, L.ptr(bn.weight),
                                                 L.ptr(self.save_mean), L.ptr(self.save_invstd),
@@ -344,14 +352,18 @@ class ConvUnit:
         plan, lib, st = self.plan, self.plan.lib, _stream()
         g, hold = self.out.grad, self.holder
         dbias = None if hold.bias is None else grads[id(hold.bias)]
+        t0 = plan.prof_begin()
         L.check(lib.bp_conv_backward_weight(C.byref(self.cv), C.byref(self.inp.view), self.inp.pw_struct(),
                                             C.byref(g), L.ptr(grads[id(hold.weight)]), L.ptr(dbias),
                                             L.ptr(plan.ws), plan.ws_bytes, plan.impl, st),
                 f"{self.name} backward_weight")
+        plan.prof_end(t0, self, "backward_weight")
         if self.dx is not None:
+            t0 = plan.prof_begin()
             L.check(lib.bp_conv_backward_data(C.byref(self.cv), C.byref(g), L.ptr(self.packed_bwd),
                                               L.ptr(hold.weight), C.byref(self.dx), plan.impl, st),
                     f"{self.name} backward_data")
+            plan.prof_end(t0, self, "backward_data")
 
 
 class ResidualUnit:

@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""Headline benchmark: CVAE fiducial train step (forward + backward + Adam) on synthetic
+512x512 dark-matter -> pressure tiles, fp32, 64 tiles per GPU (BASELINE.json configs[1]).
+
+    python bench.py --gpus N --steps K --warmup W
+
+N>1 is launched by the driver with torch.distributed.run (one rank per GPU, RCCL); the batch is
+sharded data-parallel (weak scaling: 64 tiles per GPU), gradients are all-reduced as one flat
+buffer and batch-norm statistics are all-reduced per layer (global-batch arithmetic).
+Prints ONE JSON line on rank 0 (contract in the task description), including
+  roofline     -- the dominant kernel's achieved fp32 MFMA rate from HIP events recorded around
+                  every convolution launch inside the timed region,
+  cpu_baseline -- oracle/torch_ref.py (the reference's torch.nn.functional graph) timed on the
+                  host cores on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_* dense peak
+TILE = 512
+BATCH_PER_GPU = 64
+
+
+def kernel_name(kind, unit, lib):
+    import ctypes as C
+    from baryon_painter_amd import _lib as L
+    if kind == "backward_weight":
+        cy = unit.cv.cin if unit.cv.transposed else unit.cv.cout
+        return "wgrad_kernel<%d>" % (2 if cy > 16 else 1)
+    kid = lib.bp_conv_kernel_id(C.byref(unit.cv), L.PACK_FWD if kind == "forward" else L.PACK_BWD)
+    return "igemm_kernel<%d,%d,%d,%d>" % (kid // 1000, kid // 100 % 10, kid // 10 % 10, kid % 10)
+
+
+def cpu_baseline(arch, seconds_budget=20.0):
+    """Reference arithmetic on the host: torch.nn.functional graph + autograd + torch Adam."""
+    from baryon_painter_amd.utils import synthetic as syn
+    from oracle.cvae_oracle import CVAEOracle
+    from oracle.torch_ref import TorchRefCVAE
+    n = 4
+    shapes = CVAEOracle(arch).param_shapes()
+    m = TorchRefCVAE(arch, syn.fill_params(shapes, 7))
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+    x, y, aux = syn.synthetic_batch(n, TILE, TILE, seed=5)
+    eps = syn.synthetic_eps((1, n, *arch["dim_z"]), seed=6)
+    times = []
+    t_start = time.time()
+    for it in range(12):
+        t0 = time.time()
+        elbo = m.forward(x, y, aux, eps)
+        opt.zero_grad()
+        (-elbo).backward()
+        opt.step()
+        times.append(time.time() - t0)
+        if it >= 3 and time.time() - t_start > seconds_budget:
+            break
+    med = float(np.median(times[1:]))
+    return {"value": n / med, "unit": "tiles/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{len(times) - 1} timed train steps (fwd+bwd+Adam) of batch {n} x {TILE}x{TILE}, fp32, "
+                      f"oracle/torch_ref.py (torch.nn.functional on CPU), median {med:.3f} s/step"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="tiles per GPU")
+    ap.add_argument("--tile", type=int, default=TILE)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--local-bn", action="store_true", help="do not all-reduce batch-norm statistics")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    torch.cuda.set_device(local_rank)
+    dev = f"cuda:{local_rank}"
+    sync = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev))
+        from baryon_painter_amd.dist import Sync
+        sync = Sync(sync_bn=not args.local_bn)
+
+    from baryon_painter_amd.models import arch as A
+    from baryon_painter_amd.models.cvae import CVAE
+    from baryon_painter_amd.utils import synthetic as syn
+
+    arch = A.fiducial_architecture(args.tile)
+    torch.manual_seed(1234)                      # same initial weights on every rank
+    model = CVAE(arch, dev, sync=sync)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    n = args.batch
+    # synthetic tiles: a few distinct ones, tiled up to the batch (generation cost, not arithmetic)
+    nb = min(n, 8)
+    x, y, aux = syn.synthetic_batch(nb, args.tile, args.tile, seed=1234 + rank)
+    reps = (n + nb - 1) // nb
+    x = torch.from_numpy(np.tile(x, (reps, 1, 1, 1))[:n]).to(dev)
+    y = torch.from_numpy(np.tile(y, (reps, 1, 1, 1))[:n]).to(dev)
+    aux = torch.from_numpy(np.tile(aux, reps)[:n]).to(dev)
+
+    def step():
+        elbo = model(x, y, aux)
+        opt.zero_grad()
+        (-elbo).backward()
+        opt.step()
+        return elbo
+
+    for _ in range(args.warmup):
+        step()
+    plan = model._last
+    plan.prof = []                               # HIP events around every convolution launch
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        elbo = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    final_elbo = float(elbo)
+
+    if rank == 0:
+        # ---- roofline of the dominant kernel
+        per = {}
+        for e0, e1, unit, kind in plan.prof:
+            name = kernel_name(kind, unit, model._lib)
+            d = per.setdefault(name, {"ms": 0.0, "launches": 0, "flop": 0.0})
+            d["ms"] += e0.elapsed_time(e1)
+            d["launches"] += 1
+            d["flop"] += 2.0 * unit.macs()
+        dom = max(per, key=lambda k: per[k]["ms"])
+        d = per[dom]
+        achieved = d["flop"] / (d["ms"] * 1e-3) / 1e12
+        conv_ms = sum(v["ms"] for v in per.values()) / args.steps
+        roofline = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                    "avg_launch_ms": round(d["ms"] / d["launches"], 4),
+                    "flop_per_launch": d["flop"] / d["launches"], "launches_per_step": d["launches"] // args.steps,
+                    "share_of_step": round(d["ms"] / args.steps / (dt / args.steps * 1e3), 3),
+                    "all_conv_kernels_ms_per_step": round(conv_ms, 2),
+                    "per_kernel": {k: {"ms_per_step": round(v["ms"] / args.steps, 3),
+                                       "tflops": round(v["flop"] / (v["ms"] * 1e-3) / 1e12, 2)}
+                                   for k, v in sorted(per.items(), key=lambda kv: -kv[1]["ms"])}}
+        out = {
+            "metric": "cvae_train_tiles_per_sec", "value": round(world * n * args.steps / dt, 2), "unit": "tiles/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"CVAE fiducial train step (fwd+bwd+Adam), batch {n}/GPU of "
+                                   f"{args.tile}x{args.tile} tiles, fp32 (BASELINE.json configs[1])",
+                       "tile": args.tile, "batch_per_gpu": n, "global_batch": n * world,
+                       "parallelism": f"dp{world}", "batch_norm": "local" if args.local_bn or world == 1 and False
+                       else ("global (all-reduced statistics)" if world > 1 else "single device"),
+                       "optimizer": "torch.optim.Adam(lr=1e-3)", "final_elbo": final_elbo},
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(arch)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

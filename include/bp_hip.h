@@ -71,6 +71,10 @@ const char* bp_strerror(int code);
  * bp_conv_forward, BP_PACK_BWD feeds bp_conv_backward_data). */
 int64_t bp_conv_packed_floats(const bp_conv* cv, int dir);
 
+/* Which igemm_kernel<CC,NT,WN,MT> instantiation serves this layer/direction, encoded as
+ * CC*1000 + NT*100 + WN*10 + MT (so a profile's kernel names can be matched to layers). */
+int bp_conv_kernel_id(const bp_conv* cv, int dir);
+
 /* Re-layout torch-format weights (Conv2d: [cout][cin][k][k]; ConvTranspose2d: [cin][cout][k][k])
  * into the MFMA image [phase][tap][cin_chunk][cout_pad][chunk] (zero padded).  Must be re-run
  * whenever the weights change (once per optimiser step). */

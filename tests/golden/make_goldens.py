@@ -192,6 +192,22 @@ def model_golden(tag, arch, n, size, out, seed_w=7, seed_d=1234, seed_eps=99, ad
     print(tag, "ELBO", float(elbo), "stats", model.get_stats())
 
 
+def truth64(tag, arch, n, size, out, seed_w=7, seed_d=1234, seed_eps=99):
+    """Float64 "true value" of the same case from the NumPy oracle (itself pinned to the
+    reference by tests/test_oracle_golden.py).  Lets the GPU tests state their gradient
+    tolerance relative to the fp32 reference's OWN distance from the true value."""
+    from oracle.cvae_oracle import CVAEOracle
+    m = CVAEOracle(arch, dtype=np.float64)
+    m.load_params(syn.fill_params(m.param_shapes(), seed_w))
+    x, y, aux = syn.synthetic_batch(n, size, size, seed=seed_d)
+    eps = syn.synthetic_eps((arch.get("L", 1), n, *arch["dim_z"]), seed=seed_eps)
+    m.forward(x, y, aux, eps)
+    g = m.backward(seed=-1.0)
+    summarize(f"{tag}/stats64", np.array(m.get_stats(), np.float64), out)
+    for k, v in g.items():
+        summarize(f"{tag}/grad64/{k}", v, out)
+
+
 def main():
     fid_txt = open("/root/reference/trained_models/CVAE/fiducial/architecture.txt").read()
     fid = ast.literal_eval(fid_txt)
@@ -211,6 +227,8 @@ def main():
     # the checked-in script's two-head network (scripts/CVAE_single_scale.py:97-138)
     model_golden("twohead64_n2", two, 2, 64, out, alpha_var=0.3)
     model_golden("fid512_n2", fid, 2, 512, out)
+    truth64("fid512_n2", fid, 2, 512, out)
+    truth64("fid128_n2", a128, 2, 128, out)
     np.savez_compressed(os.path.join(HERE, "model.npz"), **out)
     for f in ("ops.npz", "model.npz"):
         print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, "KiB")

@@ -49,3 +49,32 @@ def check(prefix, arr, gold, rtol, atol_frac=1e-6, what=""):
     assert e1 <= rtol, f"{what}{prefix}: l2 rel err {e1:.3e} > {rtol:.1e}"
     assert e2 <= rtol * 4, f"{what}{prefix}: sample err/scale {e2:.3e} > {4*rtol:.1e}"
     return max(e1, e2)
+
+
+def summary_distance(prefix_a, prefix_b, gold):
+    """Distance between two stored summaries of the same tensor (same measure as check())."""
+    if prefix_a + "/full" in gold:
+        a = gold[prefix_a + "/full"].astype(np.float64)
+        b = gold[prefix_b + "/full"].astype(np.float64)
+        return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+    la, lb = float(gold[prefix_a + "/l2"]), float(gold[prefix_b + "/l2"])
+    sa = gold[prefix_a + "/samples"].astype(np.float64)
+    sb = gold[prefix_b + "/samples"].astype(np.float64)
+    n = int(np.prod(gold[prefix_b + "/shape"]))
+    rms = max(lb / np.sqrt(n), 1e-30)
+    return max(abs(la - lb) / max(lb, 1e-30), np.abs(sa - sb).max() / max(np.abs(sb).max(), rms))
+
+
+def distance(prefix, arr, gold):
+    """Distance of ``arr`` from a stored summary, without asserting."""
+    a = np.asarray(arr, dtype=np.float64)
+    if prefix + "/full" in gold:
+        g = gold[prefix + "/full"].astype(np.float64).reshape(a.shape)
+        return np.abs(a - g).max() / max(np.abs(g).max(), 1e-30)
+    flat = a.reshape(-1)
+    gl2 = float(gold[prefix + "/l2"])
+    rms = max(gl2 / np.sqrt(flat.size), 1e-30)
+    gs = gold[prefix + "/samples"].astype(np.float64)
+    e1 = abs(np.sqrt((flat ** 2).sum()) - gl2) / max(gl2, 1e-30)
+    e2 = np.abs(flat[sample_indices(flat.size)] - gs).max() / max(np.abs(gs).max(), rms)
+    return max(e1, e2)

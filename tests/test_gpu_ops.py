@@ -225,7 +225,8 @@ def test_merge_aux_label_layout(golden_ops):
     yv = syn.synthetic_eps((3, 1, 4, 5), seed=430)
     aux = np.array([0.0, 0.5, 2.0], np.float32)
     ob, ov = G.empty_nhwc(3, 4, 5, 2, cstride=4, coff=1)
-    L.check(lib.bp_nchw_to_view(L.ptr(G.dev(yv)), 1, L.ptr(G.dev(aux)), 1, C.byref(ov), G.stream()))
+    yd, ad = G.dev(yv), G.dev(aux)        # keep the device buffers alive across the call
+    L.check(lib.bp_nchw_to_view(L.ptr(yd), 1, L.ptr(ad), 1, C.byref(ov), G.stream()))
     got = G.from_nhwc(ob, 2, coff=1)
     assert np.array_equal(got, golden_ops["merge_aux/out/full"].reshape(got.shape))   # bit-exact copy
 
@@ -242,6 +243,8 @@ def test_adam_matches_torch():
         g = rng.standard_normal(10007).astype(np.float32)
         ref.grad = torch.from_numpy(g.copy())
         opt.step()
-        L.check(lib.bp_adam_step(L.ptr(p), L.ptr(G.dev(g)), L.ptr(m), L.ptr(v), p.numel(), 1e-3, 0.9, 0.999, 1e-8,
+        gd = G.dev(g)
+        L.check(lib.bp_adam_step(L.ptr(p), L.ptr(gd), L.ptr(m), L.ptr(v), p.numel(), 1e-3, 0.9, 0.999, 1e-8,
                                  step, G.stream()))
+        torch.cuda.synchronize()
     assert G.rel_err(p.cpu().numpy(), ref.detach().numpy()) < 1e-6

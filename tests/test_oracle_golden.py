@@ -146,3 +146,26 @@ def test_full_model_matches_reference(tag, size, n, two, alpha, golden_model):
     if two:
         _, var = m.sample_P(y, aux, z=zfix, return_var=True)
         check(f"{tag}/sample_P_eval_var", var, golden_model, 5e-5)
+
+
+@pytest.mark.parametrize("tag,size,n,two,alpha", CASES[:1] + CASES[2:])
+def test_torch_cpu_restatement_matches_reference(tag, size, n, two, alpha, golden_model):
+    """oracle/torch_ref.py (the timed CPU baseline of bench.py) against the same fixtures."""
+    import torch
+    from oracle.torch_ref import TorchRefCVAE
+    arch = A.fiducial_architecture(size, predict_var=two)
+    shapes = O.CVAEOracle(arch).param_shapes()
+    m = TorchRefCVAE(arch, syn.fill_params(shapes, 7))
+    if alpha is not None:
+        m.alpha_var = alpha
+    x, y, aux = syn.synthetic_batch(n, size, size, seed=1234)
+    eps = syn.synthetic_eps((1, n, *arch["dim_z"]), seed=99)
+    elbo = m.forward(x, y, aux, eps)
+    (-elbo).backward()
+    check(f"{tag}/stats", np.array(m.get_stats()), golden_model, 1e-6)
+    check(f"{tag}/x_mu", m.x_mu.detach().numpy(), golden_model, 1e-6)
+    for k in shapes:
+        check(f"{tag}/grad/{k}", m.P[k].grad.numpy(), golden_model, 1e-5, what="grad ")
+    m.training = False
+    zfix = syn.synthetic_eps((n, *arch["dim_z"]), seed=101)
+    check(f"{tag}/sample_P_eval_zfix", m.sample_P(y, aux, z=zfix).numpy(), golden_model, 1e-6)
