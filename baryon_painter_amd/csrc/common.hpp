@@ -39,6 +39,33 @@ __device__ __forceinline__ float pw_apply(const PW& pw, int ch, float x) {
   return t > 0.f ? t : t * pw.slope[ch];
 }
 
+// The pending activation of 4 consecutive channels held in registers (staging loops: a thread
+// always handles the same channel quad, so the parameters are loaded once, not per element).
+struct PW4 {
+  float sc[4], sf[4], sl[4];
+  bool on;
+};
+__device__ __forceinline__ PW4 pw4_load(const PW& pw, int ch, int cmax) {
+  PW4 r;
+  r.on = pw.scale != nullptr;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const bool ok = r.on && (ch + j) < cmax;
+    r.sc[j] = ok ? pw.scale[ch + j] : 1.f;
+    r.sf[j] = ok ? pw.shift[ch + j] : 0.f;
+    r.sl[j] = ok ? pw.slope[ch + j] : 1.f;
+  }
+  return r;
+}
+__device__ __forceinline__ float pw4_apply(const PW4& p, int j, float x) {
+  const float t = fmaf(x, p.sc[j], p.sf[j]);
+  return t > 0.f ? t : t * p.sl[j];
+}
+__device__ __forceinline__ float4 pw4_apply4(const PW4& p, float4 v) {
+  if (!p.on) return v;
+  return make_float4(pw4_apply(p, 0, v.x), pw4_apply(p, 1, v.y), pw4_apply(p, 2, v.z), pw4_apply(p, 3, v.w));
+}
+
 // Geometry of one (transposed) convolution expressed as a stride-IS correlation over an output
 // sub-grid ("phase").  Conv2d: one phase, IS = stride, taps = k.  ConvTranspose2d / data-gradient
 // of a strided Conv2d: stride^2 phases with ceil(k/stride) taps each and IS = 1.

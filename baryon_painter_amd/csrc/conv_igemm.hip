@@ -111,30 +111,34 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
   for (int chunk = 0; chunk < a.nchunk; ++chunk) {
     __syncthreads();  // previous chunk's readers are done with lds_in / lds_w
     // ---- stage the input halo tile for channels [chunk*CC, chunk*CC+CC)
-    for (int e = tid; e < in_elems4; e += 256) {
-      const int c4 = e % VW;
-      const int c = (e / VW) % a.IW;
-      const int r = e / (VW * a.IW);
-      const int iy = gy0 + r, ix = gx0 + c;
+    {
+      const int c4 = tid % VW;                   // 256 % VW == 0: fixed channel quad per thread
       const int ch = chunk * CC + c4 * 4;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (iy >= 0 && iy < a.in_h && ix >= 0 && ix < a.in_w) {
-        const float* p = in_n + ((int64_t)iy * a.in_w + ix) * a.in_cs + ch;
-        if (a.vec_ok) {
-          if (ch < a.cin) {
+      const PW4 p4 = pw4_load(a.pw, ch, a.cin);
+      for (int e = tid; e < in_elems4; e += 256) {
+        const int pix = e / VW;
+        const int c = pix % a.IW;
+        const int r = pix / a.IW;
+        const int iy = gy0 + r, ix = gx0 + c;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (iy >= 0 && iy < a.in_h && ix >= 0 && ix < a.in_w && ch < a.cin) {
+          const float* p = in_n + ((int64_t)iy * a.in_w + ix) * a.in_cs + ch;
+          if (a.vec_ok) {
             v = *reinterpret_cast<const float4*>(p);
-            v.x = pw_apply(a.pw, ch + 0, v.x); v.y = pw_apply(a.pw, ch + 1, v.y);
-            v.z = pw_apply(a.pw, ch + 2, v.z); v.w = pw_apply(a.pw, ch + 3, v.w);
+          } else {
+            v.x = p[0];
+            if (ch + 1 < a.cin) v.y = p[1];
+            if (ch + 2 < a.cin) v.z = p[2];
+            if (ch + 3 < a.cin) v.w = p[3];
           }
-        } else {
-          if (ch + 0 < a.cin) v.x = pw_apply(a.pw, ch + 0, p[0]);
-          if (ch + 1 < a.cin) v.y = pw_apply(a.pw, ch + 1, p[1]);
-          if (ch + 2 < a.cin) v.z = pw_apply(a.pw, ch + 2, p[2]);
-          if (ch + 3 < a.cin) v.w = pw_apply(a.pw, ch + 3, p[3]);
+          v = pw4_apply4(p4, v);
+          if (ch + 1 >= a.cin) v.y = 0.f;
+          if (ch + 2 >= a.cin) v.z = 0.f;
+          if (ch + 3 >= a.cin) v.w = 0.f;
         }
+        const int li = ((r * a.IS + c % a.IS) * a.IWq + c / a.IS) * CC + c4 * 4;
+        *reinterpret_cast<float4*>(lds_in + li) = v;
       }
-      const int li = ((r * a.IS + c % a.IS) * a.IWq + c / a.IS) * CC + c4 * 4;
-      *reinterpret_cast<float4*>(lds_in + li) = v;
     }
     for (int ty = 0; ty < a.taps; ++ty) {
       if (ty) __syncthreads();  // readers of the previous tap row's weights are done
@@ -328,7 +332,7 @@ int bp_igemm_run(const ConvGeom& g, const bp_view* in, const PW& pw, const float
   a.stride = g.stride; a.pad = g.pad;
   a.TPR = c.TPR; a.BH = c.BH; a.nchunk = c.nchunk; a.cout_padP = c.cout_padP;
   a.IH = c.IH; a.IW = c.IW; a.IWq = c.IWq;
-  a.vec_ok = (in->cstride % 4 == 0 && in->coff % 4 == 0 && g.cin_g % 4 == 0 &&
+  a.vec_ok = (in->cstride % 4 == 0 && in->coff % 4 == 0 &&
               (reinterpret_cast<uintptr_t>(in->ptr) % 16 == 0)) ? 1 : 0;
   const int qh = bp_ceil_div(out->h, g.OS), qw = bp_ceil_div(out->w, g.OS);
   a.tiles_x = bp_ceil_div(qw, 16 * c.TPR);

@@ -137,18 +137,18 @@ struct WreduceArgs {
 };
 
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(WreduceArgs a) {
+  // thread order = workspace order [ky][kx][cy][cx] (cx fastest): coalesced reads of every split
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  const int64_t total = (int64_t)a.cy * a.cx * a.k * a.k;
+  const int64_t total = (int64_t)a.k * a.k * a.cy * a.cx;
   if (i >= total) return;
-  const int kx = i % a.k;
-  const int ky = (i / a.k) % a.k;
-  const int cx = (i / (a.k * a.k)) % a.cx;
-  const int cy = i / ((int64_t)a.k * a.k * a.cx);
+  const int cx = i % a.cx;
+  const int cy = (i / a.cx) % a.cy;
+  const int t = i / ((int64_t)a.cx * a.cy);
   const int64_t stride = (int64_t)a.k * a.k * a.CYP * a.CXP;
-  const float* p = a.ws + (((int64_t)ky * a.k + kx) * a.CYP + cy) * a.CXP + cx;
+  const float* p = a.ws + ((int64_t)t * a.CYP + cy) * a.CXP + cx;
   double s = 0.0;
   for (int sp = 0; sp < a.nsplit; ++sp) s += (double)p[sp * stride];
-  a.dst[i] = (float)s;
+  a.dst[((int64_t)cy * a.cx + cx) * a.k * a.k + t] = (float)s;
 }
 
 struct WgradPlan {
@@ -187,13 +187,39 @@ WgradPlan wgrad_plan(const bp_conv* cv, const bp_view* X, const bp_view* Y) {
 
 }  // namespace
 
+int bp_wgrad_tiles(const bp_conv* cv, const bp_view* X, const PW& pwx, const bp_view* Y, const PW& pwy, float* ws,
+                   size_t ws_bytes, size_t* need, int* nsplit, int* cxp, int* cyp, hipStream_t st, bool dry);
+
+static int wgrad_reduce(const float* ws, float* dst, int k, int cx, int cy, int CXP, int CYP, int nsplit,
+                        hipStream_t st) {
+  WreduceArgs r{};
+  r.ws = ws; r.dst = dst; r.k = k; r.cx = cx; r.cy = cy; r.CXP = CXP; r.CYP = CYP; r.nsplit = nsplit;
+  const int64_t total = (int64_t)cy * cx * k * k;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, r);
+  BP_CHECK_LAUNCH();
+  return BP_OK;
+}
+
 size_t bp_wgrad_mfma_workspace(const bp_conv* cv, const bp_view* X, const bp_view* Y) {
+  size_t need = 0;
+  int ns, cxp, cyp;
+  const PW none{nullptr, nullptr, nullptr};
+  if (bp_wgrad_tiles(cv, X, none, Y, none, nullptr, 0, &need, &ns, &cxp, &cyp, nullptr, true) == BP_OK) return need;
   const WgradPlan p = wgrad_plan(cv, X, Y);
   return p.ok ? p.ws_bytes : 0;
 }
 
 int bp_wgrad_mfma(const bp_conv* cv, const bp_view* X, const PW& pwx, const bp_view* Y, const PW& pwy,
                   float* dst, void* workspace, size_t workspace_bytes, hipStream_t st) {
+  {
+    size_t need = 0;
+    int ns, cxp, cyp;
+    const int rc = bp_wgrad_tiles(cv, X, pwx, Y, pwy, reinterpret_cast<float*>(workspace), workspace_bytes, &need,
+                                  &ns, &cxp, &cyp, st, false);
+    if (rc == BP_OK)
+      return wgrad_reduce(reinterpret_cast<const float*>(workspace), dst, cv->k, X->c, Y->c, cxp, cyp, ns, st);
+    if (rc != BP_EUNSUPPORTED) return rc;
+  }
   const WgradPlan p = wgrad_plan(cv, X, Y);
   if (!p.ok) return BP_EUNSUPPORTED;
   if (!workspace || workspace_bytes < p.ws_bytes) return BP_EWORKSPACE;

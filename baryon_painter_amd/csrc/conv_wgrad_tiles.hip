@@ -1,0 +1,299 @@
+// Weight gradient, register-blocked over kernel taps (fp32 MFMA 16x16x4), NHWC.
+//
+//   dst[cy][cx][ky][kx] = sum_{n,q} act(X)[n, q*S + k - p, cx] * act(Y)[n, q, cy]
+//
+// Compared with the generic kernel in conv_wgrad.hip this one keeps the accumulators of ALL taps
+// of KHB kernel rows x NTX x NTY channel tiles in registers (up to 144 accumulator VGPRs per
+// lane), so one staged pixel tile feeds KHB*KW*NTX*NTY MFMAs per k-step per wave instead of KW*NTY:
+// the kernel is MFMA-bound, not LDS/L2-bound.  Everything that indexes LDS is a template constant
+// (taps, stride, tile rows), so all tap offsets fold into ds_read immediates.
+//
+// Workgroup = 4 waves arranged WX x WY x WK: WX*NTX X-channel tiles, WY*NTY Y-channel tiles, and
+// WK-way split of the k-steps (pixel groups) of a tile, summed through LDS at the end.
+// Per tile of BH x 16 coarse-grid pixels the block stages
+//   X rows  [CXC/16][(BH-1)*S + KHB][S][IWq][16]   (x de-interleaved by the stride -> the 4 pixels of
+//   Y       [CYC/16][BH][16][16]                     an MFMA k-step are contiguous: conflict-free)
+// through registers, applying the pending activation of whichever operand is a layer input.
+// Partials per pixel split go to a workspace; wgrad_reduce_kernel (conv_wgrad.hip) sums them in a
+// fixed order (bitwise reproducible).
+#include "common.hpp"
+
+namespace {
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+struct WtArgs {
+  const float* X; int xh, xw, xcs, xco, cx;
+  const float* Y; int yh, yw, ycs, yco, cy;
+  int n, k, pad;
+  PW pwx, pwy;
+  float* ws;
+  int ncxb, nsplit, tiles_x, tiles_y, CXP, CYP;
+  int xvec, yvec;
+};
+
+template <int KHB, int KW, int S, int NTX, int NTY, int WX, int WY, int WK, int BH>
+struct WtCfg {
+  static constexpr int CXC = 16 * NTX * WX;
+  static constexpr int CYC = 16 * NTY * WY;
+  static constexpr int XR = (BH - 1) * S + KHB;
+  static constexpr int IW = 15 * S + KW;
+  static constexpr int IWq = (IW + S - 1) / S;
+  static constexpr int XT = XR * S * IWq * 16;    // floats per X channel tile
+  static constexpr int YT = BH * 16 * 16;         // floats per Y channel tile
+  static constexpr int TAPS = KHB * KW;
+  static constexpr int STEPS = BH * 4 / WK;
+  static constexpr size_t LDS_MAIN = (size_t)(CXC / 16 * XT + CYC / 16 * YT) * 4;
+  static constexpr size_t LDS_RED = (WK > 1) ? (size_t)WK * NTX * NTY * 64 * 4 * 4 : 0;
+  static constexpr size_t LDS = LDS_MAIN > LDS_RED ? LDS_MAIN : LDS_RED;
+};
+
+template <int KHB, int KW, int S, int NTX, int NTY, int WX, int WY, int WK, int BH>
+__global__ __launch_bounds__(256) void wgrad_tiles_kernel(WtArgs a) {
+  using Cfg = WtCfg<KHB, KW, S, NTX, NTY, WX, WY, WK, BH>;
+  static_assert(WX * WY * WK == 4, "4 waves");
+  static_assert(BH * 4 % WK == 0, "k-steps must divide");
+  constexpr int CXC = Cfg::CXC, CYC = Cfg::CYC, XR = Cfg::XR, IW = Cfg::IW, IWq = Cfg::IWq;
+  constexpr int XT = Cfg::XT, YT = Cfg::YT, TAPS = Cfg::TAPS;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* xs = smem;
+  float* ys = smem + CXC / 16 * XT;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wx = wave / (WY * WK), wy = (wave / WK) % WY, wk = wave % WK;
+  const int li = lane & 15, kq = lane >> 4;
+
+  const int cxb = blockIdx.x % a.ncxb, cyb = blockIdx.x / a.ncxb;
+  const int ky0 = blockIdx.y * KHB;
+  const int split = blockIdx.z;
+  const int cx0 = cxb * CXC, cy0 = cyb * CYC;
+
+  v4f acc[TAPS][NTX][NTY];
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+    for (int i = 0; i < NTX; ++i)
+#pragma unroll
+      for (int j = 0; j < NTY; ++j) acc[t][i][j] = v4f{0.f, 0.f, 0.f, 0.f};
+
+  const int xbase = (wx * NTX) * XT + kq * 16 + li;
+  const int ybase = (wy * NTY) * YT + kq * 16 + li;
+
+  const PW4 px4 = pw4_load(a.pwx, cx0 + (tid % (CXC / 4)) * 4, a.cx);
+  const PW4 py4 = pw4_load(a.pwy, cy0 + (tid % (CYC / 4)) * 4, a.cy);
+  const int tiles_per_img = a.tiles_x * a.tiles_y;
+  const int ntiles = a.n * tiles_per_img;
+  for (int tile = split; tile < ntiles; tile += a.nsplit) {
+    const int n = tile / tiles_per_img;
+    const int trem = tile - n * tiles_per_img;
+    const int ty_ = trem / a.tiles_x, tx_ = trem - ty_ * a.tiles_x;
+    const int qy0 = ty_ * BH, qx0 = tx_ * 16;
+    const int gy0 = qy0 * S + ky0 - a.pad, gx0 = qx0 * S - a.pad;
+    __syncthreads();
+    // ---- stage X: a float4 of channels per thread-iteration (fixed channel quad per thread)
+    {
+      const float* Xn = a.X + (int64_t)n * a.xh * a.xw * a.xcs + a.xco;
+      constexpr int C4 = CXC / 4;
+      const int c4 = tid % C4;
+      const int chl = c4 * 4, ch = cx0 + chl;
+      for (int e = tid; e < XR * IW * C4; e += 256) {
+        const int pix = e / C4;
+        const int c = pix % IW, r = pix / IW;
+        const int iy = gy0 + r, ix = gx0 + c;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (iy >= 0 && iy < a.xh && ix >= 0 && ix < a.xw && ch < a.cx) {
+          const float* p = Xn + ((int64_t)iy * a.xw + ix) * a.xcs + ch;
+          if (a.xvec) {
+            v = *reinterpret_cast<const float4*>(p);
+          } else {
+            v.x = p[0];
+            if (ch + 1 < a.cx) v.y = p[1];
+            if (ch + 2 < a.cx) v.z = p[2];
+            if (ch + 3 < a.cx) v.w = p[3];
+          }
+          v = pw4_apply4(px4, v);
+          if (ch + 1 >= a.cx) v.y = 0.f;
+          if (ch + 2 >= a.cx) v.z = 0.f;
+          if (ch + 3 >= a.cx) v.w = 0.f;
+        }
+        const int li_ = (chl >> 4) * XT + ((r * S + c % S) * IWq + c / S) * 16 + (chl & 15);
+        *reinterpret_cast<float4*>(xs + li_) = v;
+      }
+    }
+    // ---- stage Y
+    {
+      const float* Yn = a.Y + (int64_t)n * a.yh * a.yw * a.ycs + a.yco;
+      constexpr int C4 = CYC / 4;
+      const int c4 = tid % C4;
+      const int chl = c4 * 4, ch = cy0 + chl;
+      for (int e = tid; e < BH * 16 * C4; e += 256) {
+        const int pix = e / C4;
+        const int c = pix & 15, r = pix >> 4;
+        const int qy = qy0 + r, qx = qx0 + c;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (qy < a.yh && qx < a.yw && ch < a.cy) {
+          const float* p = Yn + ((int64_t)qy * a.yw + qx) * a.ycs + ch;
+          if (a.yvec) {
+            v = *reinterpret_cast<const float4*>(p);
+          } else {
+            v.x = p[0];
+            if (ch + 1 < a.cy) v.y = p[1];
+            if (ch + 2 < a.cy) v.z = p[2];
+            if (ch + 3 < a.cy) v.w = p[3];
+          }
+          v = pw4_apply4(py4, v);
+          if (ch + 1 >= a.cy) v.y = 0.f;
+          if (ch + 2 >= a.cy) v.z = 0.f;
+          if (ch + 3 >= a.cy) v.w = 0.f;
+        }
+        *reinterpret_cast<float4*>(ys + (chl >> 4) * YT + (r * 16 + c) * 16 + (chl & 15)) = v;
+      }
+    }
+    __syncthreads();
+    // ---- MFMA: this wave's k-steps (row r, pixel group g of 4)
+#pragma unroll 2
+    for (int st = 0; st < Cfg::STEPS; ++st) {
+      const int step = st * WK + wk;
+      const int r = step >> 2, g = step & 3;
+      const float* xp = xs + xbase + (r * S * S * IWq + 4 * g) * 16;
+      const float* yp = ys + ybase + (r * 16 + 4 * g) * 16;
+      float bf[NTY];
+#pragma unroll
+      for (int j = 0; j < NTY; ++j) bf[j] = yp[j * YT];
+#pragma unroll
+      for (int kyl = 0; kyl < KHB; ++kyl)
+#pragma unroll
+        for (int kx = 0; kx < KW; ++kx) {
+          constexpr int dummy = 0;
+          (void)dummy;
+          const int toff = ((kyl * S + kx % S) * IWq + kx / S) * 16;
+#pragma unroll
+          for (int i = 0; i < NTX; ++i) {
+            const float af = xp[i * XT + toff];
+#pragma unroll
+            for (int j = 0; j < NTY; ++j)
+              acc[kyl * KW + kx][i][j] =
+                  __builtin_amdgcn_mfma_f32_16x16x4f32(af, bf[j], acc[kyl * KW + kx][i][j], 0, 0, 0);
+          }
+        }
+    }
+  }
+
+  // ---- write this split's partial tiles: D[row = 4*(lane>>4)+r : X channel][col = lane&15 : Y channel]
+  if constexpr (WK == 1) {
+#pragma unroll
+    for (int kyl = 0; kyl < KHB; ++kyl) {
+      const int ky = ky0 + kyl;
+      if (ky < a.k) {
+#pragma unroll
+        for (int kx = 0; kx < KW; ++kx)
+#pragma unroll
+          for (int i = 0; i < NTX; ++i)
+#pragma unroll
+            for (int j = 0; j < NTY; ++j) {
+              const int cx = cx0 + (wx * NTX + i) * 16 + 4 * kq;
+              const int cy = cy0 + (wy * NTY + j) * 16 + li;
+              const v4f v = acc[kyl * KW + kx][i][j];
+              *reinterpret_cast<float4*>(a.ws + ((((int64_t)split * a.k + ky) * a.k + kx) * a.CYP + cy) * a.CXP + cx) =
+                  make_float4(v[0], v[1], v[2], v[3]);
+            }
+      }
+    }
+  } else {
+    float* red = smem;  // [WK][NTX][NTY][64][4]
+#pragma unroll
+    for (int kyl = 0; kyl < KHB; ++kyl)
+#pragma unroll
+      for (int kx = 0; kx < KW; ++kx) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NTX; ++i)
+#pragma unroll
+          for (int j = 0; j < NTY; ++j) {
+            const v4f v = acc[kyl * KW + kx][i][j];
+            *reinterpret_cast<float4*>(red + (((wk * NTX + i) * NTY + j) * 64 + lane) * 4) =
+                make_float4(v[0], v[1], v[2], v[3]);
+          }
+        __syncthreads();
+        const int ky = ky0 + kyl;
+        if (ky < a.k) {
+          // WX*WY == 1 whenever WK == 4; for WK == 2 the (wx,wy) pair owns its own slice below
+          for (int e = tid; e < NTX * NTY * 64; e += 256 / 1) {
+            const int l = e & 63, ij = e >> 6;
+            const int i = ij / NTY, j = ij % NTY;
+            float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int w = 0; w < WK; ++w) {
+              const float4 t = *reinterpret_cast<const float4*>(red + (((w * NTX + i) * NTY + j) * 64 + l) * 4);
+              s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+            }
+            const int cx = cx0 + i * 16 + 4 * (l >> 4);
+            const int cy = cy0 + j * 16 + (l & 15);
+            *reinterpret_cast<float4*>(a.ws + ((((int64_t)split * a.k + ky) * a.k + kx) * a.CYP + cy) * a.CXP + cx) = s;
+          }
+        }
+      }
+  }
+}
+
+template <int KHB, int KW, int S, int NTX, int NTY, int WX, int WY, int WK, int BH>
+int launch(const bp_conv* cv, const bp_view* X, const PW& pwx, const bp_view* Y, const PW& pwy, float* ws,
+           size_t ws_bytes, size_t* need, int* nsplit_out, int* cxp, int* cyp, hipStream_t st, bool dry) {
+  using Cfg = WtCfg<KHB, KW, S, NTX, NTY, WX, WY, WK, BH>;
+  static_assert(WK == 1 || (WX == 1 && WY == 1), "k-split variants own the whole channel block");
+  static_assert(Cfg::LDS <= 64 * 1024, "LDS budget");
+  WtArgs a{};
+  a.X = X->ptr; a.xh = X->h; a.xw = X->w; a.xcs = X->cstride; a.xco = X->coff; a.cx = X->c;
+  a.Y = Y->ptr; a.yh = Y->h; a.yw = Y->w; a.ycs = Y->cstride; a.yco = Y->coff; a.cy = Y->c;
+  a.n = X->n; a.k = cv->k; a.pad = cv->pad; a.pwx = pwx; a.pwy = pwy; a.ws = ws;
+  a.ncxb = bp_ceil_div(X->c, Cfg::CXC);
+  const int ncyb = bp_ceil_div(Y->c, Cfg::CYC);
+  a.CXP = a.ncxb * Cfg::CXC;
+  a.CYP = ncyb * Cfg::CYC;
+  a.tiles_x = bp_ceil_div(Y->w, 16);
+  a.tiles_y = bp_ceil_div(Y->h, BH);
+  const int kyg = bp_ceil_div(cv->k, KHB);
+  const int64_t ntiles = (int64_t)Y->n * a.tiles_x * a.tiles_y;
+  const int64_t base = (int64_t)a.ncxb * ncyb * kyg;
+  int64_t ns = (768 + base - 1) / base;      // ~3 workgroups per CU
+  if (ns > ntiles) ns = ntiles;
+  if (ns < 1) ns = 1;
+  if (ns > 65535) ns = 65535;
+  a.nsplit = (int)ns;
+  *need = (size_t)a.nsplit * cv->k * cv->k * a.CYP * a.CXP * sizeof(float);
+  *nsplit_out = a.nsplit; *cxp = a.CXP; *cyp = a.CYP;
+  if (dry) return BP_OK;
+  if (!ws || ws_bytes < *need) return BP_EWORKSPACE;
+  a.xvec = (X->cstride % 4 == 0 && X->coff % 4 == 0 && reinterpret_cast<uintptr_t>(X->ptr) % 16 == 0) ? 1 : 0;
+  a.yvec = (Y->cstride % 4 == 0 && Y->coff % 4 == 0 && reinterpret_cast<uintptr_t>(Y->ptr) % 16 == 0) ? 1 : 0;
+  dim3 grid((unsigned)(a.ncxb * ncyb), (unsigned)kyg, (unsigned)a.nsplit);
+  hipLaunchKernelGGL((wgrad_tiles_kernel<KHB, KW, S, NTX, NTY, WX, WY, WK, BH>), grid, dim3(256), Cfg::LDS, st, a);
+  BP_CHECK_LAUNCH();
+  return BP_OK;
+}
+
+}  // namespace
+
+// Returns BP_EUNSUPPORTED when no tap-blocked variant fits (caller falls back to conv_wgrad.hip).
+int bp_wgrad_tiles(const bp_conv* cv, const bp_view* X, const PW& pwx, const bp_view* Y, const PW& pwy, float* ws,
+                   size_t ws_bytes, size_t* need, int* nsplit, int* cxp, int* cyp, hipStream_t st, bool dry) {
+  const int k = cv->k, s = cv->stride, cx = X->c, cy = Y->c;
+#define BP_WT(...) return launch<__VA_ARGS__>(cv, X, pwx, Y, pwy, ws, ws_bytes, need, nsplit, cxp, cyp, st, dry)
+  if (k == 3 && s == 1) {
+    if (cx > 16 && cy > 16) BP_WT(3, 3, 1, 2, 2, 2, 2, 1, 4);
+    if (cy > 16) BP_WT(3, 3, 1, 1, 2, 1, 1, 4, 8);
+    BP_WT(3, 3, 1, 1, 1, 1, 1, 4, 8);
+  }
+  if (k == 4 && s == 2) {
+    if (cx > 16 && cy > 32) BP_WT(4, 4, 2, 1, 2, 2, 2, 1, 4);
+    if (cy > 16) BP_WT(4, 4, 2, 1, 2, 1, 1, 4, 4);
+    BP_WT(4, 4, 2, 1, 1, 1, 1, 4, 4);
+  }
+  if (k == 5 && s == 1) BP_WT(5, 5, 1, 1, 1, 1, 1, 4, 8);
+  if (k == 7 && s == 1) BP_WT(4, 7, 1, 1, 1, 1, 1, 4, 8);
+  if (k == 8 && s == 4) BP_WT(4, 8, 4, 1, 1, 1, 1, 4, 2);
+#undef BP_WT
+  return BP_EUNSUPPORTED;
+}

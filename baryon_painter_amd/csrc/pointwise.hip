@@ -56,18 +56,182 @@ __global__ __launch_bounds__(RB) void channel_sums_kernel(ViewD x, int cbase, in
   }
 }
 
-__global__ __launch_bounds__(RB) void sum_partials_kernel(const double* partial, int nblk, int n, double* out) {
-  const int i = blockIdx.x * RB + threadIdx.x;
-  if (i >= n) return;
+// ================================================================= vectorised fast paths
+// Dense views (cstride == c, coff == 0) with a power-of-two channel count are streamed as flat
+// float4s: thread t of a block always sees the same 4 channels ((4*t + j) % c) because every block
+// starts at a multiple of 1024 elements, so the per-channel sums live in registers.  The block
+// tree-reduces over threads that share a channel group (stride = c/4 threads) in LDS.
+__host__ __device__ __forceinline__ bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+
+static inline bool dense_ok(const bp_view* v) {
+  return v && v->cstride == v->c && v->coff == 0 && is_pow2(v->c) && v->c <= 1024 &&
+         (reinterpret_cast<uintptr_t>(v->ptr) % 16 == 0) && ((bp_view_pixels(v) * v->c) % 4 == 0);
+}
+
+template <int NS>
+__device__ __forceinline__ void block_reduce_store(double (&acc)[NS][4], int c, double* out /* [NS][c] */, double* sh) {
+  const int tid = threadIdx.x;
+  const int G = c >= 4 ? c / 4 : 1;     // threads per distinct channel group
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) sh[tid * 4 + j] = acc[s][j];
+    __syncthreads();
+    for (int st = RB / 2; st >= G; st >>= 1) {
+      if (tid < st) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sh[tid * 4 + j] += sh[(tid + st) * 4 + j];
+      }
+      __syncthreads();
+    }
+    if (c >= 4) {
+      if (tid < G) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) out[s * c + tid * 4 + j] = sh[tid * 4 + j];
+      }
+    } else if (tid == 0) {
+      if (c == 1) out[s] = sh[0] + sh[1] + sh[2] + sh[3];
+      else { out[s * 2] = sh[0] + sh[2]; out[s * 2 + 1] = sh[1] + sh[3]; }
+    }
+  }
+}
+
+__global__ __launch_bounds__(RB) void channel_sums_fast_kernel(const float4* __restrict__ x, int c, int64_t total4,
+                                                               int64_t chunk4, double* partial) {
+  __shared__ double sh[RB * 4];
+  const int64_t b0 = (int64_t)blockIdx.x * chunk4;
+  int64_t b1 = b0 + chunk4;
+  if (b1 > total4) b1 = total4;
+  double acc[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+  for (int64_t i = b0 + threadIdx.x; i < b1; i += RB) {
+    const float4 v = x[i];
+    acc[0][0] += v.x; acc[0][1] += v.y; acc[0][2] += v.z; acc[0][3] += v.w;
+    acc[1][0] += (double)v.x * v.x; acc[1][1] += (double)v.y * v.y;
+    acc[1][2] += (double)v.z * v.z; acc[1][3] += (double)v.w * v.w;
+  }
+  block_reduce_store<2>(acc, c, partial + (int64_t)blockIdx.x * 2 * c, sh);
+}
+
+struct ActBwdFast {
+  const float4* dout; const float4* dout2; const float4* raw; const float4* aout; float4* g;
+  PW pw; int c; int64_t total4, chunk4; double* partial;
+};
+
+__global__ __launch_bounds__(RB) void act_backward_fast_kernel(ActBwdFast a) {
+  __shared__ double sh[RB * 4];
+  const int tid = threadIdx.x;
+  const int c = a.c;
+  float sc[4], sf[4], sl[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int ch = (4 * tid + j) % c;
+    sc[j] = a.pw.scale ? a.pw.scale[ch] : 1.f;
+    sf[j] = a.pw.scale ? a.pw.shift[ch] : 0.f;
+    sl[j] = a.pw.scale ? a.pw.slope[ch] : 1.f;
+  }
+  const int64_t b0 = (int64_t)blockIdx.x * a.chunk4;
+  int64_t b1 = b0 + a.chunk4;
+  if (b1 > a.total4) b1 = a.total4;
+  double acc[3][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+  for (int64_t i = b0 + tid; i < b1; i += RB) {
+    float4 d4 = a.dout[i];
+    if (a.dout2) { const float4 e = a.dout2[i]; d4.x += e.x; d4.y += e.y; d4.z += e.z; d4.w += e.w; }
+    const float4 r4 = a.raw[i];
+    float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a.aout) s4 = a.aout[i];
+    const float d[4] = {d4.x, d4.y, d4.z, d4.w};
+    const float r[4] = {r4.x, r4.y, r4.z, r4.w};
+    const float so[4] = {s4.x, s4.y, s4.z, s4.w};
+    float g[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float t = fmaf(r[j], sc[j], sf[j]);
+      const bool pos = (a.aout ? so[j] : t) > 0.f;
+      g[j] = pos ? d[j] : d[j] * sl[j];
+      acc[0][j] += g[j];
+      acc[1][j] += (double)g[j] * r[j];
+      if (!pos) acc[2][j] += (double)d[j] * t;
+    }
+    a.g[i] = make_float4(g[0], g[1], g[2], g[3]);
+  }
+  block_reduce_store<3>(acc, c, a.partial + (int64_t)blockIdx.x * 3 * c, sh);
+}
+
+__global__ __launch_bounds__(RB) void bn_backward_apply_fast_kernel(const float4* g, const float4* raw, const double* abc,
+                                                                    float4* out, int c, int64_t total4) {
+  const int tid = threadIdx.x;
+  double A[4], G[4], B[4], M[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int ch = (4 * tid + j) % c;
+    A[j] = abc[ch]; G[j] = abc[c + ch]; B[j] = abc[2 * c + ch]; M[j] = abc[3 * c + ch];
+  }
+  for (int64_t i = (int64_t)blockIdx.x * RB + tid; i < total4; i += (int64_t)gridDim.x * RB) {
+    const float4 gv = g[i], r = raw[i];
+    out[i] = make_float4((float)(A[0] * ((double)gv.x - G[0]) + B[0] * ((double)r.x - M[0])),
+                         (float)(A[1] * ((double)gv.y - G[1]) + B[1] * ((double)r.y - M[1])),
+                         (float)(A[2] * ((double)gv.z - G[2]) + B[2] * ((double)r.z - M[2])),
+                         (float)(A[3] * ((double)gv.w - G[3]) + B[3] * ((double)r.w - M[3])));
+  }
+}
+
+__global__ __launch_bounds__(RB) void residual_forward_fast_kernel(const float4* raw, PW pw, const float4* skip, PW spw,
+                                                                   float slope, float4* out, int c, int64_t total4) {
+  const int tid = threadIdx.x;
+  float sc[4], sf[4], ksc[4], ksf[4], ksl[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int ch = (4 * tid + j) % c;
+    sc[j] = pw.scale ? pw.scale[ch] : 1.f; sf[j] = pw.scale ? pw.shift[ch] : 0.f;
+    ksc[j] = spw.scale ? spw.scale[ch] : 1.f; ksf[j] = spw.scale ? spw.shift[ch] : 0.f;
+    ksl[j] = spw.scale ? spw.slope[ch] : 1.f;
+  }
+  for (int64_t i = (int64_t)blockIdx.x * RB + tid; i < total4; i += (int64_t)gridDim.x * RB) {
+    const float4 r4 = raw[i], k4 = skip[i];
+    const float r[4] = {r4.x, r4.y, r4.z, r4.w};
+    const float k[4] = {k4.x, k4.y, k4.z, k4.w};
+    float o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float t = fmaf(r[j], sc[j], sf[j]);
+      float u = fmaf(k[j], ksc[j], ksf[j]);
+      u = u > 0.f ? u : u * ksl[j];
+      t += u;
+      o[j] = t > 0.f ? t : t * slope;
+    }
+    out[i] = make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+
+// out[i] = sum_b partial[b][i]: one wave per output, lanes stride over the blocks (fixed order).
+__global__ __launch_bounds__(64) void sum_partials_wave_kernel(const double* partial, int nblk, int n, double* out) {
+  const int i = blockIdx.x;
   double t = 0.0;
-  for (int b = 0; b < nblk; ++b) t += partial[(int64_t)b * n + i];
-  out[i] = t;
+  for (int b = threadIdx.x; b < nblk; b += 64) t += partial[(int64_t)b * n + i];
+#pragma unroll
+  for (int s = 32; s > 0; s >>= 1) t += __shfl_down(t, s, 64);
+  if (threadIdx.x == 0) out[i] = t;
+}
+
+struct FastPlan { int nblk; int64_t total4, chunk4; };
+static inline FastPlan fast_plan(int64_t total_elems) {
+  FastPlan f{};
+  f.total4 = total_elems / 4;
+  int64_t nb = (f.total4 + 2047) / 2048;          // >= 8 float4 per thread
+  if (nb > 2048) nb = 2048;
+  if (nb < 1) nb = 1;
+  int64_t chunk = (f.total4 + nb - 1) / nb;
+  chunk = (chunk + RB - 1) / RB * RB;             // block starts stay multiples of 1024 elements
+  f.chunk4 = chunk;
+  f.nblk = (int)((f.total4 + chunk - 1) / chunk);
+  return f;
 }
 
 // ---------------------------------------------------------------- batch-norm finalize
 __global__ void bn_finalize_kernel(const double* sums, double count, int c, const float* gamma,
                                    const float* beta, float eps, float momentum, float* rm, float* rv,
-                                   int64_t* nbt, float* scale, float* shift, float* smean, float* sinv) {
+                                   int64_t* nbt, float* scale, float* shift, double* smean, double* sinv) {
   const int ch = blockIdx.x * blockDim.x + threadIdx.x;
   if (ch == 0 && nbt) *nbt += 1;
   if (ch >= c) return;
@@ -78,8 +242,8 @@ __global__ void bn_finalize_kernel(const double* sums, double count, int c, cons
   const double g = gamma ? (double)gamma[ch] : 1.0, b = beta ? (double)beta[ch] : 0.0;
   scale[ch] = (float)(g * invstd);
   shift[ch] = (float)(b - mean * g * invstd);
-  if (smean) smean[ch] = (float)mean;
-  if (sinv) sinv[ch] = (float)invstd;
+  if (smean) smean[ch] = mean;
+  if (sinv) sinv[ch] = invstd;
   if (rm) rm[ch] = (float)((1.0 - momentum) * rm[ch] + momentum * mean);
   if (rv) {
     const double unb = count > 1.0 ? var * (count / (count - 1.0)) : var;
@@ -146,8 +310,8 @@ __global__ __launch_bounds__(RB) void act_backward_kernel(ActBwdArgs a) {
 }
 
 __global__ void bn_backward_finalize_kernel(const double* sums, double count, int c, const float* gamma,
-                                            const float* smean, const float* sinv, float* dgamma,
-                                            float* dbeta, float* abc) {
+                                            const double* smean, const double* sinv, float* dgamma,
+                                            float* dbeta, double* coef) {
   const int ch = blockIdx.x * blockDim.x + threadIdx.x;
   if (ch >= c) return;
   const double S0 = sums[ch], S1 = sums[c + ch];
@@ -155,16 +319,16 @@ __global__ void bn_backward_finalize_kernel(const double* sums, double count, in
   const double dg = inv * (S1 - mean * S0);
   if (dgamma) dgamma[ch] = (float)dg;
   if (dbeta) dbeta[ch] = (float)S0;
-  // d_raw = g*inv*(gr - S0/n - xhat*dg/n),  xhat = (raw-mean)*inv
-  const double A = g * inv;
-  const double B = -g * inv * inv * dg / count;
-  const double C = -g * inv * S0 / count + g * inv * inv * mean * dg / count;
-  abc[ch] = (float)A;
-  abc[c + ch] = (float)B;
-  abc[2 * c + ch] = (float)C;
+  // d_raw = g*inv*((gr - S0/n) - xhat*dg/n),  xhat = (raw-mean)*inv
+  //       = A*(gr - mg) + B*(raw - mean)     evaluated in double by the apply kernel (the reference's
+  //         CPU batch_norm_backward also runs this elementwise step in its double accumulate type)
+  coef[ch] = g * inv;
+  coef[c + ch] = S0 / count;
+  coef[2 * c + ch] = -g * inv * inv * dg / count;
+  coef[3 * c + ch] = mean;
 }
 
-__global__ __launch_bounds__(RB) void bn_backward_apply_kernel(ViewD g, ViewD raw, const float* abc, ViewD out,
+__global__ __launch_bounds__(RB) void bn_backward_apply_kernel(ViewD g, ViewD raw, const double* abc, ViewD out,
                                                                int64_t total) {
   const int64_t i = (int64_t)blockIdx.x * RB + threadIdx.x;
   if (i >= total) return;
@@ -173,7 +337,8 @@ __global__ __launch_bounds__(RB) void bn_backward_apply_kernel(ViewD g, ViewD ra
   const int64_t p = i / c;
   const float gv = g.p[p * g.cs + g.co + ch];
   const float r = raw.p[p * raw.cs + raw.co + ch];
-  out.p[p * out.cs + out.co + ch] = fmaf(abc[ch], gv, fmaf(abc[c + ch], r, abc[2 * c + ch]));
+  out.p[p * out.cs + out.co + ch] =
+      (float)(abc[ch] * ((double)gv - abc[c + ch]) + abc[2 * c + ch] * ((double)r - abc[3 * c + ch]));
 }
 
 __global__ void prelu_slope_grad_kernel(const double* sums, int c, float* dslope) {
@@ -475,7 +640,9 @@ extern "C" {
 size_t bp_channel_sums_workspace(const bp_view* x) {
   if (!bp_view_ok(x)) return 0;
   const RedPlan r = red_plan(x->c, bp_view_pixels(x));
-  return (size_t)r.nblk * 2 * x->c * sizeof(double);
+  const FastPlan f = fast_plan(bp_view_pixels(x) * x->c);
+  const int nb = r.nblk > f.nblk ? r.nblk : f.nblk;
+  return (size_t)nb * 2 * x->c * sizeof(double);
 }
 
 int bp_channel_sums(const bp_view* x, double* sums, void* workspace, size_t workspace_bytes, void* stream) {
@@ -484,19 +651,27 @@ int bp_channel_sums(const bp_view* x, double* sums, void* workspace, size_t work
   const RedPlan r = red_plan(x->c, bp_view_pixels(x));
   hipStream_t st = bp_stream(stream);
   double* partial = reinterpret_cast<double*>(workspace);
+  if (dense_ok(x)) {
+    const FastPlan f = fast_plan(bp_view_pixels(x) * x->c);
+    hipLaunchKernelGGL(channel_sums_fast_kernel, dim3(f.nblk), dim3(RB), 0, st,
+                       reinterpret_cast<const float4*>(x->ptr), x->c, f.total4, f.chunk4, partial);
+    BP_CHECK_LAUNCH();
+    hipLaunchKernelGGL(sum_partials_wave_kernel, dim3(2 * x->c), dim3(64), 0, st, partial, f.nblk, 2 * x->c, sums);
+    BP_CHECK_LAUNCH();
+    return BP_OK;
+  }
   for (int pass = 0; pass < r.npass; ++pass) {
     hipLaunchKernelGGL(channel_sums_kernel, dim3(r.nblk), dim3(RB), 0, st, vd(x), pass * r.CP, r.CP, r.ppb, partial);
     BP_CHECK_LAUNCH();
   }
-  hipLaunchKernelGGL(sum_partials_kernel, dim3(bp_ceil_div(2 * x->c, RB)), dim3(RB), 0, st, partial, r.nblk,
-                     2 * x->c, sums);
+  hipLaunchKernelGGL(sum_partials_wave_kernel, dim3(2 * x->c), dim3(64), 0, st, partial, r.nblk, 2 * x->c, sums);
   BP_CHECK_LAUNCH();
   return BP_OK;
 }
 
 int bp_bn_finalize(const double* sums, double count, int32_t c, const float* gamma, const float* beta, float eps,
                    float momentum, float* running_mean, float* running_var, int64_t* num_batches_tracked,
-                   float* scale, float* shift, float* save_mean, float* save_invstd, void* stream) {
+                   float* scale, float* shift, double* save_mean, double* save_invstd, void* stream) {
   if (!sums || c <= 0 || count <= 0 || !scale || !shift) return BP_EINVAL;
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(bp_ceil_div(c, 64)), dim3(64), 0, bp_stream(stream), sums, count, c,
                      gamma, beta, eps, momentum, running_mean, running_var, num_batches_tracked, scale, shift,
@@ -517,7 +692,9 @@ int bp_bn_eval_pointwise(int32_t c, const float* gamma, const float* beta, const
 size_t bp_act_backward_workspace(const bp_view* raw) {
   if (!bp_view_ok(raw)) return 0;
   const RedPlan r = red_plan(raw->c, bp_view_pixels(raw));
-  return (size_t)r.nblk * 3 * raw->c * sizeof(double);
+  const FastPlan f = fast_plan(bp_view_pixels(raw) * raw->c);
+  const int nb = r.nblk > f.nblk ? r.nblk : f.nblk;
+  return (size_t)nb * 3 * raw->c * sizeof(double);
 }
 
 static bool same_grid(const bp_view* a, const bp_view* b) {
@@ -534,6 +711,22 @@ int bp_act_backward(const bp_view* dout, const bp_view* dout2, const bp_view* ra
   if (!workspace || workspace_bytes < bp_act_backward_workspace(raw)) return BP_EWORKSPACE;
   const RedPlan r = red_plan(raw->c, bp_view_pixels(raw));
   hipStream_t st = bp_stream(stream);
+  if (dense_ok(raw) && dense_ok(dout) && dense_ok(g) && (!dout2 || dense_ok(dout2)) && (!act_out || dense_ok(act_out))) {
+    const FastPlan f = fast_plan(bp_view_pixels(raw) * raw->c);
+    ActBwdFast fa{};
+    fa.dout = reinterpret_cast<const float4*>(dout->ptr);
+    fa.dout2 = dout2 ? reinterpret_cast<const float4*>(dout2->ptr) : nullptr;
+    fa.raw = reinterpret_cast<const float4*>(raw->ptr);
+    fa.aout = act_out ? reinterpret_cast<const float4*>(act_out->ptr) : nullptr;
+    fa.g = reinterpret_cast<float4*>(g->ptr);
+    fa.pw = bp_pw(pw); fa.c = raw->c; fa.total4 = f.total4; fa.chunk4 = f.chunk4;
+    fa.partial = reinterpret_cast<double*>(workspace);
+    hipLaunchKernelGGL(act_backward_fast_kernel, dim3(f.nblk), dim3(RB), 0, st, fa);
+    BP_CHECK_LAUNCH();
+    hipLaunchKernelGGL(sum_partials_wave_kernel, dim3(3 * raw->c), dim3(64), 0, st, fa.partial, f.nblk, 3 * raw->c, sums);
+    BP_CHECK_LAUNCH();
+    return BP_OK;
+  }
   ActBwdArgs a{};
   a.dout = vd(dout); a.dout2 = vd(dout2); a.raw = vd(raw); a.aout = vd(act_out); a.g = vd(g);
   a.pw = bp_pw(pw); a.CP = r.CP; a.pix_per_block = r.ppb; a.partial = reinterpret_cast<double*>(workspace);
@@ -542,15 +735,14 @@ int bp_act_backward(const bp_view* dout, const bp_view* dout2, const bp_view* ra
     hipLaunchKernelGGL(act_backward_kernel, dim3(r.nblk), dim3(RB), 0, st, a);
     BP_CHECK_LAUNCH();
   }
-  hipLaunchKernelGGL(sum_partials_kernel, dim3(bp_ceil_div(3 * raw->c, RB)), dim3(RB), 0, st, a.partial, r.nblk,
-                     3 * raw->c, sums);
+  hipLaunchKernelGGL(sum_partials_wave_kernel, dim3(3 * raw->c), dim3(64), 0, st, a.partial, r.nblk, 3 * raw->c, sums);
   BP_CHECK_LAUNCH();
   return BP_OK;
 }
 
 int bp_bn_backward_finalize(const double* sums, double count, int32_t c, const float* gamma,
-                            const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta,
-                            float* coef_abc, void* stream) {
+                            const double* save_mean, const double* save_invstd, float* dgamma, float* dbeta,
+                            double* coef_abc, void* stream) {
   if (!sums || c <= 0 || count <= 0 || !save_mean || !save_invstd || !coef_abc) return BP_EINVAL;
   hipLaunchKernelGGL(bn_backward_finalize_kernel, dim3(bp_ceil_div(c, 64)), dim3(64), 0, bp_stream(stream), sums,
                      count, c, gamma, save_mean, save_invstd, dgamma, dbeta, coef_abc);
@@ -558,12 +750,22 @@ int bp_bn_backward_finalize(const double* sums, double count, int32_t c, const f
   return BP_OK;
 }
 
-int bp_bn_backward_apply(const bp_view* g, const bp_view* raw, const float* coef_abc, const bp_view* out,
+int bp_bn_backward_apply(const bp_view* g, const bp_view* raw, const double* coef_abc, const bp_view* out,
                          void* stream) {
   if (!bp_view_ok(g) || !bp_view_ok(raw) || !bp_view_ok(out) || !same_grid(g, raw) || !same_grid(g, out) ||
       !coef_abc)
     return BP_EINVAL;
   const int64_t total = bp_view_pixels(g) * g->c;
+  if (dense_ok(g) && dense_ok(raw) && dense_ok(out)) {
+    const int64_t total4 = total / 4;
+    int64_t nb = (total4 + RB * 4 - 1) / (RB * 4);
+    if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(bn_backward_apply_fast_kernel, dim3((unsigned)nb), dim3(RB), 0, bp_stream(stream),
+                       reinterpret_cast<const float4*>(g->ptr), reinterpret_cast<const float4*>(raw->ptr), coef_abc,
+                       reinterpret_cast<float4*>(out->ptr), g->c, total4);
+    BP_CHECK_LAUNCH();
+    return BP_OK;
+  }
   hipLaunchKernelGGL(bn_backward_apply_kernel, dim3(nblocks(total)), dim3(RB), 0, bp_stream(stream), vd(g), vd(raw),
                      coef_abc, vd(out), total);
   BP_CHECK_LAUNCH();
@@ -589,6 +791,16 @@ int bp_residual_forward(const bp_view* raw, const bp_pointwise* pw, const bp_vie
   if (!bp_view_ok(raw) || !bp_view_ok(skip) || !bp_view_ok(out)) return BP_EINVAL;
   if (!same_grid(raw, skip) || !same_grid(raw, out)) return BP_EINVAL;
   const int64_t total = bp_view_pixels(raw) * raw->c;
+  if (dense_ok(raw) && dense_ok(skip) && dense_ok(out)) {
+    const int64_t total4 = total / 4;
+    int64_t nb = (total4 + RB * 4 - 1) / (RB * 4);
+    if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(residual_forward_fast_kernel, dim3((unsigned)nb), dim3(RB), 0, bp_stream(stream),
+                       reinterpret_cast<const float4*>(raw->ptr), bp_pw(pw), reinterpret_cast<const float4*>(skip->ptr),
+                       bp_pw(skip_pw), slope, reinterpret_cast<float4*>(out->ptr), raw->c, total4);
+    BP_CHECK_LAUNCH();
+    return BP_OK;
+  }
   hipLaunchKernelGGL(residual_forward_kernel, dim3(nblocks(total)), dim3(RB), 0, bp_stream(stream), vd(raw),
                      bp_pw(pw), vd(skip), bp_pw(skip_pw), slope, vd(out), total);
   BP_CHECK_LAUNCH();
@@ -644,7 +856,7 @@ int bp_latent_forward(const bp_latent* lt, const bp_view* q_raw, const bp_pointw
   hipStream_t st = bp_stream(stream);
   hipLaunchKernelGGL(latent_forward_kernel, dim3(nblk), dim3(RB), 0, st, a);
   BP_CHECK_LAUNCH();
-  hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(RB), 0, st, a.partial, nblk, 1, kl_sum);
+  hipLaunchKernelGGL(sum_partials_wave_kernel, dim3(1), dim3(64), 0, st, a.partial, nblk, 1, kl_sum);
   BP_CHECK_LAUNCH();
   return BP_OK;
 }

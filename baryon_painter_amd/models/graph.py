@@ -239,9 +239,9 @@ class ConvUnit:
             self.out.pw = out_pw
         self.sums = torch.zeros(3 * c, device=dev, dtype=torch.float64)
         if bn is not None:
-            self.save_mean = torch.zeros(c, device=dev)
-            self.save_invstd = torch.zeros(c, device=dev)
-            self.abc = torch.zeros(3 * c, device=dev)
+            self.save_mean = torch.zeros(c, device=dev, dtype=torch.float64)
+            self.save_invstd = torch.zeros(c, device=dev, dtype=torch.float64)
+            self.abc = torch.zeros(4 * c, device=dev, dtype=torch.float64)
             self.count = 1.0
         lib = plan.lib
         n_fwd = lib.bp_conv_packed_floats(C.byref(cv), L.PACK_FWD)

@@ -34,10 +34,23 @@ def kernel_name(kind, unit, lib):
     import ctypes as C
     from baryon_painter_amd import _lib as L
     if kind == "backward_weight":
-        cy = unit.cv.cin if unit.cv.transposed else unit.cv.cout
-        return "wgrad_kernel<%d>" % (2 if cy > 16 else 1)
+        cv = unit.cv
+        cx, cy = (cv.cout, cv.cin) if cv.transposed else (cv.cin, cv.cout)
+        return "wgrad_tiles_kernel[k%ds%d %s]" % (cv.k, cv.stride, "wide" if (cx > 16 and cy > 16) else "thin")
     kid = lib.bp_conv_kernel_id(C.byref(unit.cv), L.PACK_FWD if kind == "forward" else L.PACK_BWD)
     return "igemm_kernel<%d,%d,%d,%d>" % (kid // 1000, kid // 100 % 10, kid // 10 % 10, kid % 10)
+
+
+def host_cores():
+    """CPU share of this process: cgroup quota if set, else the affinity mask."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(p))))
+    except Exception:
+        pass
+    return n
 
 
 def cpu_baseline(arch, seconds_budget=20.0):
@@ -46,6 +59,7 @@ def cpu_baseline(arch, seconds_budget=20.0):
     from oracle.cvae_oracle import CVAEOracle
     from oracle.torch_ref import TorchRefCVAE
     n = 4
+    torch.set_num_threads(host_cores())
     shapes = CVAEOracle(arch).param_shapes()
     m = TorchRefCVAE(arch, syn.fill_params(shapes, 7))
     opt = torch.optim.Adam(m.parameters(), lr=1e-3)
@@ -77,6 +91,7 @@ def main():
     ap.add_argument("--tile", type=int, default=TILE)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--local-bn", action="store_true", help="do not all-reduce batch-norm statistics")
+    ap.add_argument("--layers", action="store_true", help="also print a per-layer table to stderr")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -102,7 +117,9 @@ def main():
 
     arch = A.fiducial_architecture(args.tile)
     torch.manual_seed(1234)                      # same initial weights on every rank
-    model = CVAE(arch, dev, sync=sync)
+    import contextlib
+    with contextlib.redirect_stdout(sys.stderr):     # the model announces itself like the reference does
+        model = CVAE(arch, dev, sync=sync)
     opt = torch.optim.Adam(model.parameters(), lr=1e-3)
     n = args.batch
     # synthetic tiles: a few distinct ones, tiled up to the batch (generation cost, not arithmetic)
@@ -138,7 +155,7 @@ def main():
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
-    final_elbo = float(elbo)
+    final_elbo = float(elbo.detach())
 
     if rank == 0:
         # ---- roofline of the dominant kernel
@@ -149,6 +166,13 @@ def main():
             d["ms"] += e0.elapsed_time(e1)
             d["launches"] += 1
             d["flop"] += 2.0 * unit.macs()
+        if args.layers:
+            lay = {}
+            for e0, e1, unit, kind in plan.prof:
+                d = lay.setdefault((unit.name, kind), [0.0, 2.0 * unit.macs(), kernel_name(kind, unit, model._lib)])
+                d[0] += e0.elapsed_time(e1) / args.steps
+            for (name, kind), (ms, fl, kn) in sorted(lay.items(), key=lambda kv: -kv[1][0]):
+                print(f"{name:28s} {kind:16s} {ms:8.3f} ms  {fl / ms / 1e9:7.2f} TF/s  {kn}", file=sys.stderr)
         dom = max(per, key=lambda k: per[k]["ms"])
         d = per[dom]
         achieved = d["flop"] / (d["ms"] * 1e-3) / 1e12

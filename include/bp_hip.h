@@ -107,12 +107,12 @@ int bp_channel_sums(const bp_view* x, double* sums, void* workspace, size_t work
 
 /* Train mode: batch mean / biased variance from `sums` and `count` (= N*H*W over all ranks),
  * writes the consumer's pointwise (scale = gamma*invstd, shift = beta - mean*scale), saves
- * mean/invstd for backward and updates running stats (momentum, unbiased variance) and
+ * mean/invstd (in double: the backward's cancellation needs them exact) for backward and updates running stats (momentum, unbiased variance) and
  * num_batches_tracked (int64, may be NULL). */
 int bp_bn_finalize(const double* sums, double count, int32_t c, const float* gamma,
                    const float* beta, float eps, float momentum, float* running_mean,
                    float* running_var, int64_t* num_batches_tracked, float* scale, float* shift,
-                   float* save_mean, float* save_invstd, void* stream);
+                   double* save_mean, double* save_invstd, void* stream);
 
 /* Eval mode: scale/shift from the running statistics. */
 int bp_bn_eval_pointwise(int32_t c, const float* gamma, const float* beta,
@@ -131,14 +131,15 @@ int bp_act_backward(const bp_view* dout, const bp_view* dout2, const bp_view* ra
                     const bp_pointwise* pw, const bp_view* act_out, const bp_view* g,
                     double* sums, void* workspace, size_t workspace_bytes, void* stream);
 
-/* From the (all-reduced) sums: dgamma, dbeta and the coefficients of
- *   d_raw = A*g + B*raw + C   (batch-norm backward as a per-channel affine map of (g, raw)). */
+/* From the (all-reduced) sums: dgamma, dbeta and the per-channel coefficients {A, mg, B, mean} of
+ *   d_raw = A*(g - mg) + B*(raw - mean)   (batch-norm backward as an affine map of (g, raw)),
+ * kept and evaluated in double like the reference's CPU batch_norm_backward (its accumulate type). */
 int bp_bn_backward_finalize(const double* sums, double count, int32_t c, const float* gamma,
-                            const float* save_mean, const float* save_invstd, float* dgamma,
-                            float* dbeta, float* coef_abc /* [3*c] */, void* stream);
+                            const double* save_mean, const double* save_invstd, float* dgamma,
+                            float* dbeta, double* coef_abc /* [4*c] */, void* stream);
 
-/* out = A*g + B*raw + C  (out may alias g). */
-int bp_bn_backward_apply(const bp_view* g, const bp_view* raw, const float* coef_abc,
+/* out = A*(g - mg) + B*(raw - mean)  (out may alias g). */
+int bp_bn_backward_apply(const bp_view* g, const bp_view* raw, const double* coef_abc,
                          const bp_view* out, void* stream);
 
 /* dst[ch] = (float) sums[ch]  (e.g. a bias gradient from bp_channel_sums of dy). */

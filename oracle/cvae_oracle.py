@@ -438,6 +438,7 @@ class CVAEOracle:
         else:
             dh = self.nets["p_mu_out"].backward(s * diff, g, "p_mu_out.")
         dcat = self.nets["p_y_z_in"].backward(dh, g, "p_y_z_in.")
+        self._dcat = dcat          # kept for debugging tools
         dz = self.nets["p_z_in"].backward(dcat[:, :self._cz], g, "p_z_in.")
         if self.nets["p_y_in"].layers:
             d_hy = dcat[:, self._cz:]

@@ -164,7 +164,8 @@ def test_batchnorm_relu_chain(golden_ops):
     rm, rv = torch.zeros(5, device="cuda"), torch.ones(5, device="cuda")
     nbt = torch.zeros((), dtype=torch.int64, device="cuda")
     scale, shift = torch.zeros(5, device="cuda"), torch.zeros(5, device="cuda")
-    mean, inv = torch.zeros(5, device="cuda"), torch.zeros(5, device="cuda")
+    mean = torch.zeros(5, device="cuda", dtype=torch.float64)
+    inv = torch.zeros(5, device="cuda", dtype=torch.float64)
     cnt = float(3 * 6 * 7)
     L.check(lib.bp_bn_finalize(L.ptr(sums), cnt, 5, L.ptr(g), L.ptr(b), 1e-5, 0.1, L.ptr(rm), L.ptr(rv),
                                L.ptr(nbt), L.ptr(scale), L.ptr(shift), L.ptr(mean), L.ptr(inv), st))
@@ -181,7 +182,8 @@ def test_batchnorm_relu_chain(golden_ops):
     gb, gv = G.empty_nhwc(3, 6, 7, 5)
     L.check(lib.bp_act_backward(C.byref(dyv), None, C.byref(xv), C.byref(pw), None, C.byref(gv), L.ptr(sums),
                                 L.ptr(ws), ws.numel() * 8, st))
-    dgam, dbet, abc = torch.zeros(5, device="cuda"), torch.zeros(5, device="cuda"), torch.zeros(15, device="cuda")
+    dgam, dbet = torch.zeros(5, device="cuda"), torch.zeros(5, device="cuda")
+    abc = torch.zeros(20, device="cuda", dtype=torch.float64)
     L.check(lib.bp_bn_backward_finalize(L.ptr(sums), cnt, 5, L.ptr(g), L.ptr(mean), L.ptr(inv), L.ptr(dgam),
                                         L.ptr(dbet), L.ptr(abc), st))
     L.check(lib.bp_bn_backward_apply(C.byref(gv), C.byref(xv), L.ptr(abc), C.byref(gv), st))
