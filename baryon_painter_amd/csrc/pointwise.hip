@@ -310,15 +310,15 @@ __global__ __launch_bounds__(RB) void act_backward_kernel(ActBwdArgs a) {
 }
 
 __global__ void bn_backward_finalize_kernel(const double* sums, double count, int c, const float* gamma,
-                                            const double* smean, const double* sinv, float* dgamma,
-                                            float* dbeta, double* coef) {
+                                            const double* smean, const double* sinv, float pscale,
+                                            float* dgamma, float* dbeta, double* coef) {
   const int ch = blockIdx.x * blockDim.x + threadIdx.x;
   if (ch >= c) return;
   const double S0 = sums[ch], S1 = sums[c + ch];
   const double mean = smean[ch], inv = sinv[ch], g = gamma ? (double)gamma[ch] : 1.0;
   const double dg = inv * (S1 - mean * S0);
-  if (dgamma) dgamma[ch] = (float)dg;
-  if (dbeta) dbeta[ch] = (float)S0;
+  if (dgamma) dgamma[ch] = (float)(dg * pscale);
+  if (dbeta) dbeta[ch] = (float)(S0 * pscale);
   // d_raw = g*inv*((gr - S0/n) - xhat*dg/n),  xhat = (raw-mean)*inv
   //       = A*(gr - mg) + B*(raw - mean)     evaluated in double by the apply kernel (the reference's
   //         CPU batch_norm_backward also runs this elementwise step in its double accumulate type)
@@ -741,11 +741,11 @@ int bp_act_backward(const bp_view* dout, const bp_view* dout2, const bp_view* ra
 }
 
 int bp_bn_backward_finalize(const double* sums, double count, int32_t c, const float* gamma,
-                            const double* save_mean, const double* save_invstd, float* dgamma, float* dbeta,
-                            double* coef_abc, void* stream) {
+                            const double* save_mean, const double* save_invstd, float param_grad_scale,
+                            float* dgamma, float* dbeta, double* coef_abc, void* stream) {
   if (!sums || c <= 0 || count <= 0 || !save_mean || !save_invstd || !coef_abc) return BP_EINVAL;
   hipLaunchKernelGGL(bn_backward_finalize_kernel, dim3(bp_ceil_div(c, 64)), dim3(64), 0, bp_stream(stream), sums,
-                     count, c, gamma, save_mean, save_invstd, dgamma, dbeta, coef_abc);
+                     count, c, gamma, save_mean, save_invstd, param_grad_scale, dgamma, dbeta, coef_abc);
   BP_CHECK_LAUNCH();
   return BP_OK;
 }

@@ -12,6 +12,7 @@ built library raises.
 """
 import ctypes as C
 import math
+import os
 
 import torch
 
@@ -151,6 +152,15 @@ class _Plan:
     # ---- helpers
     def need_ws(self, nbytes):
         self.ws_bytes = max(self.ws_bytes, int(nbytes))
+
+    def impl_of(self, kind, unit=None):
+        """Kernel family per operation; BP_IMPL_FWD / BP_IMPL_DGRAD / BP_IMPL_WGRAD (auto|direct|mfma)
+        override the model's choice for debugging (BP_IMPL_UNITS=a,b restricts the override to units)."""
+        v = os.environ.get("BP_IMPL_" + kind.upper())
+        only = os.environ.get("BP_IMPL_UNITS")
+        if only and unit is not None and unit not in only.split(","):
+            v = None
+        return self.impl if v is None else {"auto": L.IMPL_AUTO, "direct": L.IMPL_DIRECT, "mfma": L.IMPL_MFMA}[v]
 
     # per-launch HIP-event timing of the convolution kernels (bench.py roofline); off by default
     prof = None

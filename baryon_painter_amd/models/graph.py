@@ -280,7 +280,8 @@ class ConvUnit:
         t0 = plan.prof_begin()
         L.check(lib.bp_conv_forward(C.byref(self.cv), C.byref(self.inp.view), self.inp.pw_struct(),
                                     L.ptr(self.packed_fwd), L.ptr(hold.weight), L.ptr(hold.bias),
-                                    C.byref(self.out.view), plan.impl, st), f"{self.name} forward")
+                                    C.byref(self.out.view), plan.impl_of("fwd", self.name), st),
+                f"{self.name} forward")
         plan.prof_end(t0, self, "forward")
         c = self.cv.cout
         if self.act == "prelu":
@@ -337,10 +338,12 @@ class ConvUnit:
                     f"{self.name} prelu grad")
         bn = self.bn
         if bn is not None:
+            pscale = 1.0
             if plan.sync is not None and plan.sync.sync_bn:
                 plan.sync.all_reduce_sum(self.sums[:2 * c])
+                pscale = 1.0 / plan.sync.world_size       # sums are global, losses are per-rank means
             L.check(lib.bp_bn_backward_finalize(L.ptr(self.sums), self.count, c, L.ptr(bn.weight),
-                                                L.ptr(self.save_mean), L.ptr(self.save_invstd),
+                                                L.ptr(self.save_mean), L.ptr(self.save_invstd), pscale,
                                                 L.ptr(grads[id(bn.weight)]), L.ptr(grads[id(bn.bias)]),
                                                 L.ptr(self.abc), st), f"{self.name} bn backward")
             L.check(lib.bp_bn_backward_apply(C.byref(g_out), C.byref(self.out.view), L.ptr(self.abc),
@@ -355,13 +358,13 @@ class ConvUnit:
         t0 = plan.prof_begin()
         L.check(lib.bp_conv_backward_weight(C.byref(self.cv), C.byref(self.inp.view), self.inp.pw_struct(),
                                             C.byref(g), L.ptr(grads[id(hold.weight)]), L.ptr(dbias),
-                                            L.ptr(plan.ws), plan.ws_bytes, plan.impl, st),
+                                            L.ptr(plan.ws), plan.ws_bytes, plan.impl_of("wgrad"), st),
                 f"{self.name} backward_weight")
         plan.prof_end(t0, self, "backward_weight")
         if self.dx is not None:
             t0 = plan.prof_begin()
             L.check(lib.bp_conv_backward_data(C.byref(self.cv), C.byref(g), L.ptr(self.packed_bwd),
-                                              L.ptr(hold.weight), C.byref(self.dx), plan.impl, st),
+                                              L.ptr(hold.weight), C.byref(self.dx), plan.impl_of("dgrad"), st),
                     f"{self.name} backward_data")
             plan.prof_end(t0, self, "backward_data")
 

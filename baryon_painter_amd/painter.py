@@ -1,0 +1,395 @@
+"""Painter API: train / validate / paint / checkpoint, with the reference's signatures.
+
+Mirrors ``baryon_painter.painter`` (/root/reference/baryon_painter/painter.py:16-545).  The loop
+semantics that affect results are kept: pseudo-epoch bookkeeping (one ``scheduler.step()`` per
+pseudo epoch, painter.py:179-190), adaptive batch size by rebuilding the DataLoader
+(:210-215), validation losses computed under ``no_grad`` but in TRAIN mode (:85,306-314 -- they
+update batch-norm running statistics, as in the reference), ``paint`` switching to eval mode
+for good (:372), file names and the text format of the statistics logs (:127-131,476-484).
+Out of scope and therefore absent: the matplotlib / cosmotools diagnostics
+(``validation_plotting``); ``show_plots`` / ``save_plots`` / ``plot_*`` arguments are accepted
+and ignored, and the two reference crashes they trigger do not occur.
+"""
+import collections
+import os
+import pickle
+
+import numpy as np
+import torch
+import torch.utils.data
+
+from .models import cvae as _cvae
+from .utils import datasets
+
+try:                                    # the reference pickles its metadata with dill
+    import dill as _pickler
+except ImportError:                     # pragma: no cover
+    _pickler = pickle
+
+
+class Painter:
+    """Abstract base class for a baryon painter (painter.py:16-31)."""
+
+    def __init__(self):
+        raise NotImplementedError("This is an abstract base class.")
+
+    def load_state_from_file(self, filename):
+        raise NotImplementedError("This is an abstract base class.")
+
+    def paint(self, input, **kwargs):
+        raise NotImplementedError("This is an abstract base class.")
+
+
+class CVAEPainter(Painter):
+    def __init__(self, filename=None, training_data_set=None, test_data_set=None, architecture="test",
+                 compute_device="cuda:0", sync=None):
+        self.sync = sync
+        if filename is not None:
+            self.load_state_from_file(filename, compute_device)
+        else:
+            self.architecture = architecture
+            self.compute_device = compute_device
+            self.model = _cvae.CVAE(architecture, torch.device(compute_device), sync=sync)
+        self.training_data = training_data_set
+        self.test_data = test_data_set
+
+    def load_training_data(self, filename):
+        self.data_path = os.path.dirname(filename)
+        with open(filename, "rb") as f:
+            self.training_data_file_info = pickle.load(f)
+
+    def load_test_data(self, filename):
+        self.test_data_path = os.path.dirname(filename)
+        with open(filename, "rb") as f:
+            self.test_data_file_info = pickle.load(f)
+
+    # ------------------------------------------------------------------------------ training
+    def _loader(self, batch_size):
+        if self.sync is not None and self.sync.world_size > 1:
+            return _ShardedLoader(self.training_data, batch_size, self.sync)
+        return torch.utils.data.DataLoader(self.training_data, batch_size=batch_size, shuffle=True)
+
+    def train(self, n_epoch=5, n_pepoch=None, learning_rate=1e-4, batch_size=1,
+              adaptive_learning_rate=None, adaptive_batch_size=None,
+              validation_pepochs=[0, 1], validation_batch_size=4,
+              validation_loss_frequency=100, validation_loss_batch_size=16,
+              checkpoint_frequency=1000, statistics_report_frequency=50,
+              loss_plot_frequency=1000, mavg_window_size=20,
+              plot_sample_var=False, plot_power_spectra=["auto"], plot_histogram=["log"],
+              show_plots=True, save_plots=False, output_path=None, verbose=True,
+              pepoch_size=3136, var_anneal_fn=None, KL_anneal_fn=None):
+        """Train.  1 pseudo epoch = ``pepoch_size`` samples (3136 by default; the checked-in
+        script uses 1568).  Returns ``(training_stats, validation_stats)``."""
+        if self.training_data is None:
+            raise RuntimeError("Trying to train but no training data specified.")
+        if len(validation_pepochs) > 0 and self.test_data is None:
+            raise RuntimeError("Trying to validate but no test data specified.")
+        model = self.model
+        model.train(True)
+        if adaptive_batch_size is not None or batch_size <= 0:
+            batch_size = adaptive_batch_size(0)
+        dataloader = self._loader(batch_size)
+
+        optimizer = torch.optim.Adam(model.parameters(), lr=learning_rate)
+        scheduler = None
+        if adaptive_learning_rate is not None:
+            if callable(adaptive_learning_rate):
+                scheduler = torch.optim.lr_scheduler.LambdaLR(optimizer, adaptive_learning_rate)
+            elif isinstance(adaptive_learning_rate, dict):
+                scheduler = torch.optim.lr_scheduler.StepLR(optimizer, step_size=adaptive_learning_rate["step_size"],
+                                                            gamma=adaptive_learning_rate["gamma"])
+            elif adaptive_learning_rate == "avoid_plateau":
+                scheduler = torch.optim.lr_scheduler.ReduceLROnPlateau(optimizer, mode="max", factor=0.1,
+                                                                       patience=10, threshold=0.0001,
+                                                                       threshold_mode="rel", cooldown=0, min_lr=0,
+                                                                       eps=1e-08)
+
+        # statistics labels: "log_likelihood_0" -> "log_likelihood_pressure_0" (painter.py:114-121)
+        nf = self.training_data.n_feature_per_field
+        stats_labels = model.get_stats_labels()
+        for j, f in enumerate(self.training_data.label_fields):
+            for k in range(nf):
+                stats_labels = [l.replace(f"{j * nf + k}", f"{f}_{k}") for l in stats_labels]
+        stats_labels += ["lr", "batch_size"]
+
+        ckpt_template = train_file = val_file = idx_file = None
+        if output_path is not None:
+            os.makedirs(output_path, exist_ok=True)
+            ckpt_template = os.path.join(output_path, "checkpoint_sample{sample:0>10}_batch{batch}_epoch{epoch}{suffix}")
+            train_file = os.path.join(output_path, "training_stats.txt")
+            val_file = os.path.join(output_path, "validation_stats.txt")
+            idx_file = os.path.join(output_path, "training_sample_indicies.txt")
+        elif save_plots:
+            raise ValueError("save_plots=True requires output_path to be set.")
+        rank0 = self.sync is None or self.sync.rank == 0
+        if not rank0:
+            ckpt_template = train_file = val_file = idx_file = None
+
+        training_stats = TrainingStats(stats_labels, mavg_window_size, stats_filename=train_file)
+        validation_stats = TrainingStats(stats_labels, mavg_window_size, stats_filename=val_file,
+                                         dump_to_file_frequency=1)
+        if n_pepoch is None:
+            n_pepoch = n_epoch * len(self.training_data) // pepoch_size
+
+        sample_indices = []
+        n_samples = n_batches = 0
+        last_pepoch_at = last_val = last_report = last_ckpt = 0
+        i_epoch = i_pepoch = i_batch = 0
+        world = 1 if self.sync is None else self.sync.world_size
+        ELBO = None
+
+        while i_epoch < n_epoch:
+            i_epoch = n_samples // len(self.training_data)
+            if verbose:
+                model.check_gpu()
+            if i_pepoch >= n_pepoch:
+                break
+            for i_batch, batch_data in enumerate(dataloader):
+                if n_samples - pepoch_size >= last_pepoch_at or n_samples == 0:
+                    if n_samples != 0:
+                        i_pepoch += 1
+                        last_pepoch_at = n_samples
+                        if i_pepoch >= n_pepoch:
+                            break
+                        if scheduler is not None:
+                            if adaptive_learning_rate == "avoid_plateau":
+                                scheduler.step(float(ELBO.item()))
+                            else:
+                                scheduler.step()
+                    if callable(var_anneal_fn):
+                        model.alpha_var = var_anneal_fn(i_pepoch)
+                    if callable(KL_anneal_fn):
+                        model.beta_KL = KL_anneal_fn(i_pepoch)
+                    if i_pepoch in validation_pepochs:
+                        self.validate(validation_batch_size=validation_batch_size, plot_sample_var=plot_sample_var)
+                    if adaptive_batch_size is not None:
+                        new_bs = adaptive_batch_size(i_pepoch)
+                        if new_bs != batch_size:
+                            batch_size = new_bs
+                            dataloader = self._loader(batch_size)
+                            break
+
+                x = torch.cat(batch_data[0][1:], dim=1).to(model.device)
+                y = batch_data[0][0].to(model.device)
+                aux = batch_data[2].to(device=model.device, dtype=y.dtype) if len(batch_data) > 2 else None
+
+                ELBO = model(x, y, aux)
+                optimizer.zero_grad()
+                (-ELBO).backward()
+                optimizer.step()
+
+                n_samples += x.size(0) * world
+                n_batches += 1
+                with torch.no_grad():
+                    sample_indices += list(np.asarray(batch_data[1]))
+                    lr = [g["lr"] for g in optimizer.param_groups]
+                    training_stats.push_loss(n_samples, *model.get_stats(), lr[0], batch_size)
+                    if n_samples - validation_loss_frequency >= last_val:
+                        last_val = n_samples
+                        stats = self.validate(validation_batch_size=validation_loss_batch_size, compute_loss=True)
+                        validation_stats.push_loss(n_samples, *stats, lr[0], batch_size)
+                    if n_samples - checkpoint_frequency >= last_ckpt and ckpt_template is not None:
+                        last_ckpt = n_samples
+                        base = ckpt_template.format(epoch=i_epoch, batch=i_batch, sample=n_samples, suffix="")
+                        self.save_state_to_file((base + "_state", base + "_meta"))
+                    if n_samples - statistics_report_frequency >= last_report and statistics_report_frequency > 0:
+                        last_report = n_samples
+                        if rank0:
+                            print("Epoch: [{}/{}], P-Epoch: [{}/{}], Batch: [{}/{}], Loss: {:.3e}".format(
+                                i_epoch, n_epoch, i_pepoch, n_pepoch, i_batch,
+                                len(self.training_data) // (batch_size * world),
+                                training_stats.loss_terms["ELBO"]["mavg"][-1]))
+                            print("Processed batches: {}, processed samples: {}, batch size: {}, learning rate: {}"
+                                  .format(n_batches, n_samples, batch_size, " ".join("{:.1e}".format(v) for v in lr)))
+                            print(training_stats.get_pretty_str(n_col=1))
+                        if idx_file is not None:
+                            with open(idx_file, "wb") as f:
+                                pickle.dump(sample_indices, f)
+
+        self.validate(validation_batch_size=validation_batch_size, plot_sample_var=plot_sample_var)
+        if ckpt_template is not None:
+            base = ckpt_template.format(epoch=i_epoch, batch=i_batch, sample=n_samples, suffix="_final")
+            self.save_state_to_file((base + "_state", base + "_meta"))
+            self.save_state_to_file((os.path.join(output_path, "model_state"), os.path.join(output_path, "model_meta")))
+        training_stats.flush_to_file()
+        validation_stats.flush_to_file()
+        return training_stats, validation_stats
+
+    def validate(self, validation_batch_size=8, compute_loss=False, validation_redshift=None,
+                 plot_samples=1, plot_sample_var=False, plot_power_spectra=["auto"], plot_histogram=["log"],
+                 histogram_n_sample=1, show_plots=True, save_plots=False, filename_template="{plot_type}.png"):
+        """A random test batch through the model (painter.py:295-367).  With ``compute_loss`` the
+        loss terms (``model.get_stats()``) are returned; otherwise the reference draws diagnostic
+        plots from a prior sample -- here the sample is drawn (same device work, same random
+        stream) and returned as ``(x, y, x_pred[, x_pred_var])`` NumPy arrays instead."""
+        model = self.model
+        with torch.no_grad():
+            fields, indicies, z = self.test_data.get_batch(size=validation_batch_size, z=validation_redshift)
+            x = torch.tensor(np.concatenate(fields[1:], axis=1), device=model.device)
+            y = torch.tensor(fields[0], device=model.device)
+            aux = torch.tensor(z, device=model.device, dtype=y.dtype)
+            if compute_loss:
+                model(x, y, aux)
+                return model.get_stats()
+            if plot_sample_var and model.predict_var:
+                x_pred, x_var = model.sample_P(y, return_var=True, aux_label=aux)
+                return x.cpu().numpy(), y.cpu().numpy(), x_pred.cpu().numpy(), x_var.cpu().numpy()
+            x_pred = model.sample_P(y, aux_label=aux)
+            return x.cpu().numpy(), y.cpu().numpy(), x_pred.cpu().numpy()
+
+    # ------------------------------------------------------------------------------ inference
+    def paint(self, input, z=0.0, transform=True, inverse_transform=True):
+        """Paint one tile (painter.py:371-392): dark-matter tile (H,W) at redshift z -> pressure."""
+        self.model.train(False)
+        with torch.no_grad():
+            y = self.transform(input, field=self.input_field, z=z) if transform and self.transform is not None \
+                else input
+            y = np.asarray(y)
+            y = y.reshape(1, *y.shape)
+            if y.shape != (1, *self.model.dim_y):
+                raise ValueError(f"Shape mismatch between input and model: {input.shape} vs {self.model.dim_y}")
+            yt = torch.tensor(y, device=self.compute_device, dtype=torch.float32)
+            aux = torch.tensor(z, device=self.compute_device, dtype=yt.dtype)
+            prediction = self.model.sample_P(yt, aux_label=aux).cpu().numpy()
+        if inverse_transform and self.inverse_transform is not None:
+            if len(self.label_fields) > 1:
+                raise NotImplementedError("Painting with more than one output field is not supported yet.")
+            return self.inverse_transform(prediction, field=self.label_fields[0], z=z)
+        return prediction
+
+    def paint_batch(self, inputs, z, transform=True, inverse_transform=True, batch_size=64):
+        """Throughput form of ``paint``: many tiles (N,H,W) with redshifts (N,) in batches through the
+        same eval-mode forward (BASELINE.json configs[4]); per-tile results equal ``paint``'s up to
+        the prior noise draw."""
+        self.model.train(False)
+        inputs = np.asarray(inputs)
+        zs = np.broadcast_to(np.asarray(z, dtype=np.float64), (inputs.shape[0],))
+        out = []
+        with torch.no_grad():
+            for s in range(0, inputs.shape[0], batch_size):
+                chunk = inputs[s:s + batch_size]
+                zc = zs[s:s + batch_size]
+                if transform and self.transform is not None:
+                    y = np.stack([np.asarray(self.transform(t, field=self.input_field, z=float(zz)))
+                                  for t, zz in zip(chunk, zc)])
+                else:
+                    y = chunk.reshape(chunk.shape[0], 1, *chunk.shape[-2:])
+                y = y.reshape(y.shape[0], *self.model.dim_y)
+                yt = torch.tensor(y, device=self.compute_device, dtype=torch.float32)
+                aux = torch.tensor(zc, device=self.compute_device, dtype=torch.float32)
+                pred = self.model.sample_P(yt, aux_label=aux).cpu().numpy()
+                if inverse_transform and self.inverse_transform is not None:
+                    pred = np.stack([self.inverse_transform(p[None], field=self.label_fields[0], z=float(zz))
+                                     for p, zz in zip(pred, zc)])
+                out.append(pred)
+        return np.concatenate(out, axis=0)
+
+    # ------------------------------------------------------------------------------ checkpoints
+    def save_state_to_file(self, filename, mode="model_state_dict+metadata"):
+        """(state_path, meta_path): ``torch.save(state_dict)`` + pickled metadata with the
+        compiled transforms (painter.py:395-418).  The state dict has the reference's keys."""
+        if not isinstance(filename, (tuple, list)):
+            raise ValueError("filename needs to be a tuple of (state_filename, meta_filename).")
+        td = self.training_data
+        d = {"L": td.L, "n_grid": td.n_grid, "tile_L": td.tile_L, "n_tile": td.n_tile, "tile_size": td.tile_size,
+             "input_field": td.input_field, "label_fields": td.label_fields, "scale_to_SLICS": td.scale_to_SLICS,
+             "transform": datasets.compile_transform(transform=td.transform_func, stats=td.stats),
+             "inverse_transform": datasets.compile_transform(transform=td.inverse_transform_func, stats=td.stats),
+             "model_architecture": self.architecture}
+        with open(filename[1], "wb") as f:
+            _pickler.dump(d, f)
+        torch.save({k: v.detach().cpu().clone() for k, v in self.model.state_dict().items()}, filename[0])
+
+    def load_state_from_file(self, filename, compute_device="cuda:0"):
+        if not isinstance(filename, (tuple, list)):
+            raise ValueError("filename needs to be a tuple of (state_filename, meta_filename).")
+        self.compute_device = compute_device
+        state_dict = torch.load(filename[0], map_location=torch.device(self.compute_device))
+        with open(filename[1], "rb") as f:
+            d = _pickler.load(f)
+        self.model = _cvae.CVAE(d["model_architecture"], torch.device(self.compute_device),
+                                sync=getattr(self, "sync", None))
+        self.model.load_state_dict(state_dict)
+        self.architecture = d["model_architecture"]
+        for k in ("L", "n_grid", "tile_L", "n_tile", "tile_size", "input_field", "label_fields", "scale_to_SLICS"):
+            setattr(self, k, d[k])
+        self.transform = d.get("transform")
+        self.inverse_transform = d.get("inverse_transform")
+
+
+class _ShardedLoader:
+    """Data-parallel replacement for ``DataLoader(shuffle=True)``: every rank draws the SAME
+    global permutation (seeded, advanced per pass) and takes its slice of each global batch
+    (baryon_painter_amd.dist.shard_indices), so the union over ranks is what one device would
+    have processed."""
+
+    def __init__(self, dataset, batch_size, sync, seed=20190101):
+        self.dataset, self.batch_size, self.sync = dataset, batch_size, sync
+        self.seed, self.epoch = seed, 0
+
+    def __iter__(self):
+        from .dist import shard_indices
+        rng = np.random.Generator(np.random.PCG64([self.seed, self.epoch]))
+        self.epoch += 1
+        perm = rng.permutation(len(self.dataset))
+        collate = torch.utils.data.default_collate
+        for idx in shard_indices(perm, self.sync.rank, self.sync.world_size, self.batch_size):
+            yield collate([self.dataset[int(i)] for i in idx])
+
+    def __len__(self):
+        return len(self.dataset) // (self.batch_size * self.sync.world_size)
+
+
+class TrainingStats:
+    """Loss log with moving average and the reference's text format (painter.py:447-545):
+    header ``# Batch nr, sample nr, <labels>``, one line ``batch sample v0 v1 ...`` per push."""
+
+    def __init__(self, loss_terms=[], moving_average_window=100, dump_to_file_frequency=10, stats_filename=None):
+        self.mavg_window = moving_average_window
+        self.n_batches = 0
+        self.n_processed_samples = []
+        self.last_dump_to_file = 0
+        self.dump_to_file_frequency = dump_to_file_frequency
+        self.loss_terms = collections.OrderedDict((t, {"all": [], "mavg": []}) for t in loss_terms)
+        self.stats_filename = stats_filename
+        if stats_filename is not None:
+            with open(stats_filename, "w") as f:
+                f.write("# Batch nr, sample nr, {}\n".format(", ".join(loss_terms)))
+
+    def __del__(self):
+        try:
+            self.flush_to_file()
+        except Exception:
+            pass
+
+    def push_loss(self, n_sample, *args):
+        self.n_batches += 1
+        self.n_processed_samples.append(n_sample)
+        for value, term in zip(args, self.loss_terms.values()):
+            term["all"].append(value)
+            term["mavg"].append(np.mean(term["all"][-min(self.n_batches, self.mavg_window):]))
+        if self.stats_filename is not None and self.n_batches - self.dump_to_file_frequency >= self.last_dump_to_file:
+            self.flush_to_file()
+
+    def flush_to_file(self):
+        if self.stats_filename is None:
+            return
+        with open(self.stats_filename, "a") as f:
+            for s in range(self.last_dump_to_file, self.n_batches):
+                f.write(self.get_str(s) + "\n")
+        self.last_dump_to_file = self.n_batches
+
+    def get_str(self, idx=-1):
+        batch = idx if idx >= 0 else self.n_batches + idx + 1
+        return f"{batch} {self.n_processed_samples[idx]} " + "".join(f"{t['all'][idx]} " for t in self.loss_terms.values())
+
+    def get_pretty_str(self, n_col=1):
+        width = max(len(k) for k in self.loss_terms)
+        out, in_row = "", 0
+        for key, term in self.loss_terms.items():
+            out += "{key:<{width}s}: {value:8.3e}     ".format(key=key, width=width, value=term["mavg"][-1])
+            in_row += 1
+            if in_row >= n_col:
+                out += "\n"
+                in_row = 0
+        return out

@@ -133,10 +133,13 @@ int bp_act_backward(const bp_view* dout, const bp_view* dout2, const bp_view* ra
 
 /* From the (all-reduced) sums: dgamma, dbeta and the per-channel coefficients {A, mg, B, mean} of
  *   d_raw = A*(g - mg) + B*(raw - mean)   (batch-norm backward as an affine map of (g, raw)),
- * kept and evaluated in double like the reference's CPU batch_norm_backward (its accumulate type). */
+ * kept and evaluated in double like the reference's CPU batch_norm_backward (its accumulate type).
+ * dgamma/dbeta are multiplied by `param_grad_scale` (1/world_size under data parallelism, where
+ * the sums are global but every rank's loss is normalised by its local batch; 1 otherwise). */
 int bp_bn_backward_finalize(const double* sums, double count, int32_t c, const float* gamma,
-                            const double* save_mean, const double* save_invstd, float* dgamma,
-                            float* dbeta, double* coef_abc /* [4*c] */, void* stream);
+                            const double* save_mean, const double* save_invstd,
+                            float param_grad_scale, float* dgamma, float* dbeta,
+                            double* coef_abc /* [4*c] */, void* stream);
 
 /* out = A*(g - mg) + B*(raw - mean)  (out may alias g). */
 int bp_bn_backward_apply(const bp_view* g, const bp_view* raw, const double* coef_abc,

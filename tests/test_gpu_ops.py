@@ -184,7 +184,7 @@ def test_batchnorm_relu_chain(golden_ops):
                                 L.ptr(ws), ws.numel() * 8, st))
     dgam, dbet = torch.zeros(5, device="cuda"), torch.zeros(5, device="cuda")
     abc = torch.zeros(20, device="cuda", dtype=torch.float64)
-    L.check(lib.bp_bn_backward_finalize(L.ptr(sums), cnt, 5, L.ptr(g), L.ptr(mean), L.ptr(inv), L.ptr(dgam),
+    L.check(lib.bp_bn_backward_finalize(L.ptr(sums), cnt, 5, L.ptr(g), L.ptr(mean), L.ptr(inv), 1.0, L.ptr(dgam),
                                         L.ptr(dbet), L.ptr(abc), st))
     L.check(lib.bp_bn_backward_apply(C.byref(gv), C.byref(xv), L.ptr(abc), C.byref(gv), st))
     check("bn_relu/dx", G.from_nhwc(gb, 5), golden_ops, 2e-5)

@@ -1,0 +1,132 @@
+"""GPU: the drop-in boundary (CVAEPainter train / validate / paint / checkpoint files) and the
+data-parallel arithmetic (2 ranks, global-batch batch-norm) on the HIP path."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from baryon_painter_amd.models import arch as A
+from baryon_painter_amd.utils import datasets as D
+from baryon_painter_amd.utils import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_train_checkpoint_reload_paint(tmp_path):
+    from baryon_painter_amd.painter import CVAEPainter
+    tile = 64
+    train = D.SyntheticTileDataset(n_sample=64, tile_size=tile, seed=1)
+    test = D.SyntheticTileDataset(n_sample=16, tile_size=tile, seed=2)
+    arch = A.fiducial_architecture(tile, predict_var=True)
+    torch.manual_seed(0)
+    p = CVAEPainter(training_data_set=train, test_data_set=test, architecture=arch, compute_device="cuda:0")
+    out = tmp_path / "run"
+    ts, vs = p.train(n_epoch=1, n_pepoch=3, learning_rate=1e-3, batch_size=4,
+                     adaptive_batch_size=lambda pe: 4 if pe < 2 else 8,
+                     adaptive_learning_rate=lambda pe: 1.0 if pe < 1 else 0.5,
+                     pepoch_size=16, validation_pepochs=[0, 1], validation_batch_size=2,
+                     validation_loss_frequency=8, validation_loss_batch_size=4, checkpoint_frequency=24,
+                     statistics_report_frequency=16, output_path=str(out), verbose=False, show_plots=False)
+    assert ts.n_batches >= 8 and vs.n_batches >= 2
+    assert all(np.isfinite(v) for v in ts.loss_terms["ELBO"]["all"])
+    assert ts.loss_terms["batch_size"]["all"][0] == 4 and ts.loss_terms["batch_size"]["all"][-1] == 8
+    assert ts.loss_terms["lr"]["all"][-1] == pytest.approx(5e-4)
+    header = (out / "training_stats.txt").read_text().splitlines()[0]
+    assert header == ("# Batch nr, sample nr, ELBO, KL_term, log_likelihood_pressure_0, "
+                      "log_likelihood_fixed_var_pressure_0, log_likelihood_free_var_pressure_0, lr, batch_size")
+    files = sorted(os.listdir(out))
+    assert "model_state" in files and "model_meta" in files and "validation_stats.txt" in files
+    assert any(f.startswith("checkpoint_sample") and f.endswith("_final_state") for f in files)
+    # the loss goes down on the training distribution
+    first, last = np.mean(ts.loss_terms["ELBO"]["all"][:3]), np.mean(ts.loss_terms["ELBO"]["all"][-3:])
+    assert last > first
+
+    q = CVAEPainter(filename=(str(out / "model_state"), str(out / "model_meta")), compute_device="cuda:0")
+    for (k, a), (k2, b) in zip(p.model.state_dict().items(), q.model.state_dict().items()):
+        assert k == k2 and torch.equal(a, b), k
+    dm, pr, z = test.raw_fields(5)
+    eps = syn.synthetic_eps((1, 1, *arch["dim_z"]), seed=8)
+    p.input_field, p.label_fields = q.input_field, q.label_fields
+    p.transform, p.inverse_transform = q.transform, q.inverse_transform
+    p.model._eps_override = q.model._eps_override = eps
+    a = p.paint(dm, z=z)
+    b = q.paint(dm, z=z)
+    assert a.shape == (tile, tile) and np.array_equal(a, b) and np.isfinite(a).all() and (a >= -1e-6).all()
+    raw = q.paint(dm, z=z, inverse_transform=False)
+    assert raw.shape == (1, 1, tile, tile)
+    # batched paint == per-tile paint (same eps, eval-mode batch-norm is per sample)
+    q.model._eps_override = np.repeat(eps, 3, axis=1)
+    many = q.paint_batch(np.stack([dm, dm, dm]), z=z)
+    assert many.shape == (3, tile, tile) and np.allclose(many[1], a, rtol=1e-5, atol=1e-7)
+    with pytest.raises(ValueError):
+        q.paint(dm[:32], z=z)
+    with pytest.raises(ValueError):
+        CVAEPainter(filename=str(out / "model_state"))
+    with pytest.raises(RuntimeError):
+        CVAEPainter(architecture=arch, compute_device="cuda:0").train()
+
+
+_DP_WORKER = r"""
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np, torch, torch.distributed as dist
+from baryon_painter_amd.dist import Sync
+from baryon_painter_amd.models import arch as A
+from baryon_painter_amd.models.cvae import CVAE
+from baryon_painter_amd.utils import synthetic as syn
+dist.init_process_group("gloo")            # 2 ranks share the one GPU of the box; RCCL needs distinct devices
+r, w = dist.get_rank(), dist.get_world_size()
+size, n = 64, 4
+arch = A.fiducial_architecture(size)
+x, y, aux = syn.synthetic_batch(n, size, size, seed=21)
+eps = syn.synthetic_eps((1, n, *arch["dim_z"]), seed=22)
+def run(sync, sl):
+    m = CVAE(arch, "cuda:0", sync=sync)
+    P = syn.fill_params({k: tuple(p.shape) for k, p in m.named_parameters()}, 7)
+    with torch.no_grad():
+        for k, p in m.named_parameters(): p.copy_(torch.from_numpy(P[k]))
+    m._eps_override = eps[:, sl]
+    e = m(torch.from_numpy(x[sl]), torch.from_numpy(y[sl]), torch.from_numpy(aux[sl]))
+    (-e).backward()
+    return m, float(e.detach())
+h = n // w
+dp, e_dp = run(Sync(), slice(r * h, (r + 1) * h))
+t = torch.tensor([e_dp], dtype=torch.float64); dist.all_reduce(t); e_mean = t.item() / w
+if r == 0:
+    ref, e_ref = run(None, slice(0, n))
+    assert abs(e_mean - e_ref) <= 2e-6 * abs(e_ref), (e_mean, e_ref)
+    errs = []
+    for (k, a), (_, b) in zip(dp.named_parameters(), ref.named_parameters()):
+        ga, gb = a.grad.double(), b.grad.double()
+        errs.append((float((ga - gb).abs().max() / gb.abs().max().clamp_min(1e-30)), k))
+    errs.sort(reverse=True)
+    print("worst:", errs[:6])
+    worst = errs[0][0]
+    for (k, a), (_, b) in zip(dp.named_buffers(), ref.named_buffers()):
+        assert torch.allclose(a.double(), b.double(), rtol=1e-5, atol=1e-7), k
+    assert worst < 2e-4, worst
+    print("dp parity ok", worst)
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+def test_two_rank_data_parallel_equals_single_device(tmp_path):
+    """Sharded batch + all-reduced batch-norm statistics + averaged gradients == the single-device
+    global batch (the reference's arithmetic)."""
+    import socket
+    script = tmp_path / "dp_worker.py"
+    script.write_text(_DP_WORKER)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), str(script), ROOT],
+                         capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    assert "dp parity ok" in out.stdout

@@ -1,0 +1,194 @@
+"""CPU tests of the host side: C ABI symbols, architecture language, datasets / transforms /
+checkpoint-format helpers, data-parallel plumbing over gloo (world_size 2)."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    """Every function declared in include/bp_hip.h resolves in the built .so (no compute calls)."""
+    from baryon_painter_amd import _lib as L
+    lib = L.load()
+    header = open(os.path.join(ROOT, "include", "bp_hip.h")).read()
+    names = set(re.findall(r"\b(bp_[a-z0-9_]+)\s*\(", header))
+    assert len(names) >= 25
+    for n in sorted(names):
+        assert hasattr(lib, n), f"{n} declared in bp_hip.h but not exported"
+        assert n in L.SIGNATURES, f"{n} has no ctypes signature"
+    assert lib.bp_version() >= 100
+    assert b"invalid" in lib.bp_strerror(-1)
+    cv = L.Conv(0, 128, 128, 3, 1, 1, 0)
+    assert lib.bp_conv_packed_floats(ctypes.byref(cv), L.PACK_FWD) == 9 * 128 * 128
+    assert lib.bp_conv_kernel_id(ctypes.byref(cv), L.PACK_FWD) == 16424
+
+
+def test_model_refuses_cpu_and_missing_library(monkeypatch, tmp_path):
+    from baryon_painter_amd.models import arch as A
+    from baryon_painter_amd.models.cvae import CVAE
+    with pytest.raises(RuntimeError, match="GPU only"):
+        CVAE(A.fiducial_architecture(64), "cpu")
+    from baryon_painter_amd import _lib as L
+    monkeypatch.setattr(L, "_lib", None)
+    monkeypatch.setattr(L, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        L.load()
+
+
+def test_architecture_helpers_error_behaviour():
+    from baryon_painter_amd.models import arch as A
+    from baryon_painter_amd.models.graph import build_holders
+    with pytest.raises(ValueError):
+        A.conv_block(1, 1, kernel=4)                       # utils.py:42-43
+    with pytest.raises(NotImplementedError):
+        A.conv_block(1, 1, scale=3)
+    with pytest.raises(NotImplementedError):
+        A.conv_block(1, 1, activation="swish")
+    with pytest.raises(NotImplementedError):
+        build_holders([("maxpool", {})])
+    with pytest.raises(RuntimeError):
+        build_holders([("conv", {}, 1)])
+    seq = build_holders(A.fiducial_architecture(64)["p_y_z_in"])
+    keys = list(seq.state_dict().keys())
+    assert "12.res_block.0.weight" in keys and "1.num_batches_tracked" in keys
+    assert build_holders(None) is None
+
+
+def test_transform_roundtrip_within_reference_tolerance():
+    """transform o inverse == id within 2e-5*sigma (the reference's tests/test_dataset.py:80-83)."""
+    from baryon_painter_amd.utils import data_transforms as T
+    stats = {"dm": {0.0: {"mean": 1.0, "var": 1.47}, 1.0: {"mean": 1.0, "var": 0.4}, 2.0: {"mean": 1.0, "var": 0.11}}}
+    rng = np.random.default_rng(0)
+    x = rng.lognormal(0, 1, (64, 64)).astype(np.float32)
+    for mode, k in (("shift-log", 4.0), ("log", 2.0), ("shift-log-2p", (0.01, 4.0)), ("x/(1+x)", (2, 1))):
+        fwd, inv = T.create_range_compress_transforms({"dm": k}, {"dm": mode}, eps=1e-4)
+        for z in (0.0, 0.3, 1.0, 2.5):
+            back = inv(fwd(x, "dm", z, stats), "dm", z, stats)
+            sigma = np.sqrt(T.interpolate_z(stats["dm"], z)["var"])
+            assert np.abs(back - x).max() <= 2e-5 * sigma * max(1.0, x.max())
+    assert T.interpolate_z(stats["dm"], 0.5)["var"] == pytest.approx(0.5 * 1.47 + 0.5 * 0.4)
+    assert T.interpolate_z(stats["dm"], 9.0)["var"] == 0.11 and T.interpolate_z(stats["dm"], -1.0)["var"] == 1.47
+    with pytest.raises(ValueError):
+        T.create_range_compress_transforms({"dm": 1}, {"dm": "nope"})[0](x, "dm", 0.0, stats)
+
+
+def _fake_stacks(n_stack=5, n_grid=32):
+    rng = np.random.default_rng(1)
+    data = {}
+    for field in ("dm", "pressure"):
+        data[field] = {}
+        for z in (0.0, 1.0):
+            data[field][z] = {"100": rng.random((n_stack, n_grid, n_grid), dtype=np.float32),
+                              "150": rng.random((n_stack, n_grid, n_grid), dtype=np.float32),
+                              "mean_100": 0.5, "mean_150": 0.5, "var_100": 0.08, "var_150": 0.08}
+    return data
+
+
+def test_bahamas_index_mapping_quirks():
+    from baryon_painter_amd.utils.datasets import BAHAMASDataset
+    data = _fake_stacks()
+    ds = BAHAMASDataset(data=data, redshifts=[0.0, 1.0], label_fields=["pressure"], n_stack=4, stack_offset=1,
+                        n_tile=4, tile_permutations=True, scale_to_SLICS=True)
+    assert ds.n_tile_permutation == 8 and ds.tile_size == 8
+    assert ds.n_sample == 4 ** 2 * 4 ** 4 * 64 and len(ds) == 2 * ds.n_sample
+    # only idx % 64 selects the (stack, tile) combination (datasets.py:327)
+    assert ds.sample_idx_to_tile(5) == ds.sample_idx_to_tile(5 + 64) == (1, 0, 0, 1, 1, 1)
+    assert ds.sample_idx_to_tile(63) == (1, 0, 0, 4, 3, 3)
+    assert ds.sample_idx_to_tile_permutation(0) == (0, 0)
+    assert ds.sample_idx_to_tile_permutation(ds.n_sample - 1) == (7, 7)
+    assert ds.sample_idx_to_redshift(ds.n_sample) == 1.0
+    t = np.arange(16.0).reshape(4, 4)
+    assert np.array_equal(ds.apply_tile_permutation(t, 3), t)              # flip code 3: no-op
+    assert np.array_equal(ds.apply_tile_permutation(t, 1), t[:, ::-1])
+    assert np.array_equal(ds.apply_tile_permutation(t, 6), np.rot90(t, 1)[::-1])
+    sample, idx, z = ds[70]
+    assert idx == 70 and z == 0.0 and sample[0].shape == (8, 8) and len(sample) == 2
+    expected = (data["dm"][0.0]["100"][1][0:8, 0:8] + data["dm"][0.0]["150"][1][8:16, 16:24]) * (1 / (32 / 8 * 5) * 0.2793 / (0.2793 - 0.0463))
+    assert np.allclose(sample[0], expected)
+    fixed = BAHAMASDataset(data=data, redshifts=[0.0, 1.0], label_fields=["pressure"], n_stack=4, stack_offset=1,
+                           tile_permutations=True, fixed_indexing=True)
+    assert fixed.sample_idx_to_tile(5 + 64) != fixed.sample_idx_to_tile(5)
+    with pytest.raises(ValueError):
+        BAHAMASDataset(data=data, n_stack=6)
+    with pytest.raises(ValueError):
+        BAHAMASDataset()
+
+
+def test_training_stats_text_format(tmp_path):
+    from baryon_painter_amd.painter import TrainingStats
+    f = tmp_path / "training_stats.txt"
+    st = TrainingStats(["ELBO", "KL_term", "log_likelihood_pressure_0", "lr", "batch_size"], 2,
+                       dump_to_file_frequency=2, stats_filename=str(f))
+    st.push_loss(4, -10.0, -1.0, -9.0, 1e-3, 4)
+    st.push_loss(8, -8.0, -0.5, -7.5, 1e-3, 4)
+    st.push_loss(12, -6.0, -0.5, -5.5, 1e-3, 4)
+    st.flush_to_file()
+    lines = f.read_text().splitlines()
+    assert lines[0] == "# Batch nr, sample nr, ELBO, KL_term, log_likelihood_pressure_0, lr, batch_size"
+    assert lines[1] == "0 4 -10.0 -1.0 -9.0 0.001 4 "
+    assert len(lines) == 4 and st.loss_terms["ELBO"]["mavg"][-1] == -7.0
+    assert "ELBO" in st.get_pretty_str()
+
+
+def test_shard_indices_reproduce_global_batches():
+    from baryon_painter_amd.dist import shard_indices
+    perm = np.random.default_rng(0).permutation(103)
+    shards = [shard_indices(perm, r, 4, 6) for r in range(4)]
+    assert all(len(s) == 103 // 24 for s in shards)
+    for b in range(len(shards[0])):
+        merged = sum((shards[r][b] for r in range(4)), [])
+        assert merged == list(perm[b * 24:(b + 1) * 24])
+
+
+_GLOO_WORKER = r"""
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import torch, torch.distributed as dist
+from baryon_painter_amd.dist import Sync
+dist.init_process_group("gloo")
+s = Sync()
+r = s.rank
+sums = torch.tensor([1.0 + r, 10.0 * (r + 1)], dtype=torch.float64)
+s.all_reduce_sum(sums)
+assert sums.tolist() == [3.0, 30.0], sums
+flat = torch.full((1000,), float(r + 1))
+s.all_reduce_mean(flat)
+assert torch.allclose(flat, torch.full((1000,), 1.5))
+local = Sync(sync_bn=False)
+t = torch.tensor([float(r)], dtype=torch.float64)
+local.all_reduce_sum(t)
+assert t.item() == float(r)                      # batch-norm statistics stay local
+# two-rank batch-norm statistics == single-device statistics of the concatenated batch
+g = torch.Generator().manual_seed(0)
+full = torch.randn(8, 5, 4, 4, generator=g, dtype=torch.float64)
+mine = full[r * 4:(r + 1) * 4]
+st = torch.cat([mine.sum(dim=(0, 2, 3)), (mine ** 2).sum(dim=(0, 2, 3))])
+s.all_reduce_sum(st)
+n = full.numel() / 5
+mean = st[:5] / n
+var = st[5:] / n - mean ** 2
+assert torch.allclose(mean, full.mean(dim=(0, 2, 3))) and torch.allclose(var, full.var(dim=(0, 2, 3), unbiased=False))
+dist.destroy_process_group()
+print("rank", r, "ok")
+"""
+
+
+def test_sync_collectives_over_gloo(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(_GLOO_WORKER)
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), str(script), ROOT],
+                         capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "rank 0 ok" in out.stdout and "rank 1 ok" in out.stdout
