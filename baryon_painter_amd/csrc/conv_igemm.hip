@@ -24,7 +24,8 @@ struct IgemmArgs {
   float* out; int out_h, out_w, out_cs, out_co, cout;
   const float* wp; const float* bias;
   PW pw;
-  int taps, IS, OS, nphase, transposed, stride, pad;
+  int tapsy, tapsx, ISy, ISx, OS, nphase, transposed, stride, pad;
+  int PP, COP;   // pixel packing: N column j = (pp = j / COP, co = j % COP), pixel x = PP*group + pp
   int tiles_x, tiles_y, TPR, BH;
   int nchunk, cout_padP;
   int IH, IW, IWq;
@@ -56,7 +57,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
   constexpr int COB = 16 * NT * WN;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* lds_in = smem;
-  float* lds_w = smem + (size_t)a.IH * a.IS * a.IWq * CC;
+  float* lds_w = smem + (size_t)a.IH * a.ISx * a.IWq * CC;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -75,17 +76,17 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
   const int qy0 = tile_y * a.BH, qx0 = tile_x * BW;
   // phase grid extents
   const int qh = (a.out_h - py + a.OS - 1) / a.OS;
-  const int qw = (a.out_w - px + a.OS - 1) / a.OS;
+  const int qw = a.PP > 1 ? (a.out_w + a.PP - 1) / a.PP : (a.out_w - px + a.OS - 1) / a.OS;   // groups
   if (qy0 >= qh || qx0 >= qw) return;  // uniform per block
 
   int iy0, ix0;
   if (a.transposed) {
-    iy0 = bp_t_i0(py, a.pad, a.stride, a.taps);
-    ix0 = bp_t_i0(px, a.pad, a.stride, a.taps);
+    iy0 = bp_t_i0(py, a.pad, a.stride, a.tapsy);
+    ix0 = bp_t_i0(px, a.pad, a.stride, a.tapsy);
   } else {
     iy0 = -a.pad; ix0 = -a.pad;
   }
-  const int gy0 = a.IS * qy0 + iy0, gx0 = a.IS * qx0 + ix0;
+  const int gy0 = a.ISy * qy0 + iy0, gx0 = a.ISx * qx0 + ix0;
 
   // per-lane LDS bases of this wave's M tiles
   int abase[MT];
@@ -93,7 +94,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
   for (int mt = 0; mt < MT; ++mt) {
     const int t = wm * MT + mt;
     const int tr = t / a.TPR, tc = t % a.TPR;
-    abase[mt] = (tr * a.IS * a.IS * a.IWq + tc * 16 + lm) * CC + kq * VW;
+    abase[mt] = (tr * a.ISy * a.ISx * a.IWq + tc * 16 + lm) * CC + kq * VW;
   }
   int bbase[NT];
 #pragma unroll
@@ -136,26 +137,26 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
           if (ch + 2 >= a.cin) v.z = 0.f;
           if (ch + 3 >= a.cin) v.w = 0.f;
         }
-        const int li = ((r * a.IS + c % a.IS) * a.IWq + c / a.IS) * CC + c4 * 4;
+        const int li = ((r * a.ISx + c % a.ISx) * a.IWq + c / a.ISx) * CC + c4 * 4;
         *reinterpret_cast<float4*>(lds_in + li) = v;
       }
     }
-    for (int ty = 0; ty < a.taps; ++ty) {
+    for (int ty = 0; ty < a.tapsy; ++ty) {
       if (ty) __syncthreads();  // readers of the previous tap row's weights are done
       // ---- stage weights for (phase, ty, all tx, chunk): taps slabs of COB*CC floats
       {
         const int slab4 = COB * CC / 4;
-        for (int e = tid; e < a.taps * slab4; e += 256) {
+        for (int e = tid; e < a.tapsx * slab4; e += 256) {
           const int tx = e / slab4, o = e % slab4;
-          const float* src = a.wp + ((((int64_t)(ph * a.taps + ty) * a.taps + tx) * a.nchunk + chunk) *
+          const float* src = a.wp + ((((int64_t)(ph * a.tapsy + ty) * a.tapsx + tx) * a.nchunk + chunk) *
                                          a.cout_padP + co0) * CC;
           *reinterpret_cast<float4*>(lds_w + (size_t)tx * COB * CC + o * 4) =
               *reinterpret_cast<const float4*>(src + o * 4);
         }
       }
       __syncthreads();
-      for (int tx = 0; tx < a.taps; ++tx) {
-        const int tapoff = ((ty * a.IS + tx % a.IS) * a.IWq + tx / a.IS) * CC;
+      for (int tx = 0; tx < a.tapsx; ++tx) {
+        const int tapoff = ((ty * a.ISx + tx % a.ISx) * a.IWq + tx / a.ISx) * CC;
         float af[MT][VW], bf[NT][VW];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) lds_read<VW>(lds_in + abase[mt] + tapoff, af[mt]);
@@ -172,7 +173,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
     }
   }
 
-  // ---- epilogue: D[row = 4*(lane>>4)+r (pixel)][col = lane&15 (channel)]
+  // ---- epilogue: D[row = 4*(lane>>4)+r (pixel or pixel group)][col = lane&15 (channel, or (pp,channel))]
   float* out_n = a.out + (int64_t)n * a.out_h * a.out_w * a.out_cs + a.out_co;
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
@@ -182,13 +183,15 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
     const int Y = py + a.OS * qy;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-      const int co = co0 + (wn * NT + nt) * 16 + lm;
+      const int j = co0 + (wn * NT + nt) * 16 + lm;
+      const int co = a.PP > 1 ? j % a.COP : j;
+      const int pp = a.PP > 1 ? j / a.COP : 0;
       const float b = (a.bias && co < a.cout) ? a.bias[co] : 0.f;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int qx = qx0 + tc * 16 + kq * 4 + r;
-        const int X = px + a.OS * qx;
-        if (qy < qh && qx < qw && co < a.cout)
+        const int X = a.PP > 1 ? a.PP * qx + pp : px + a.OS * qx;
+        if (qy < qh && qx < qw && X < a.out_w && co < a.cout)
           out_n[((int64_t)Y * a.out_w + X) * a.out_cs + co] = acc[mt][nt][r] + b;
       }
     }
@@ -199,8 +202,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
 struct PackArgs {
   const float* w; float* dst;
   int64_t sa, sb;
-  int k, stride, pad, taps, nphase, transposed;
-  int cin_g, cout_g, CC, nchunk, cout_padP;
+  int k, stride, pad, tapsy, tapsx, nphase, transposed;
+  int cin_g, cout_g, CC, nchunk, cout_padP, PP, COP;
   int64_t total;
 };
 
@@ -211,26 +214,33 @@ __global__ __launch_bounds__(256) void pack_kernel(PackArgs a) {
   const int cl = r % a.CC; r /= a.CC;
   const int co = r % a.cout_padP; r /= a.cout_padP;
   const int chunk = r % a.nchunk; r /= a.nchunk;
-  const int tx = r % a.taps; r /= a.taps;
-  const int ty = r % a.taps; r /= a.taps;
+  const int tx = r % a.tapsx; r /= a.tapsx;
+  const int ty = r % a.tapsy; r /= a.tapsy;
   const int ph = (int)r;
   const int py = ph / a.nphase, px = ph % a.nphase;
-  int ky, kx;
+  int ky, kx, cch = co;
   if (a.transposed) {
-    ky = bp_t_ky(py, a.pad, a.stride, a.taps, ty);
-    kx = bp_t_ky(px, a.pad, a.stride, a.taps, tx);
+    ky = bp_t_ky(py, a.pad, a.stride, a.tapsy, ty);
+    kx = bp_t_ky(px, a.pad, a.stride, a.tapsy, tx);
   } else {
     ky = ty; kx = tx;
   }
+  if (a.PP > 1) {            // column = (pp, channel): pixel pp of the group sees tap tx - pp
+    const int pp = co / a.COP;
+    cch = co % a.COP;
+    kx = (a.transposed ? bp_t_ky(px, a.pad, a.stride, a.tapsy, tx - pp) : tx - pp);
+    if (tx - pp < 0 || tx - pp >= a.tapsy) kx = -1;
+  }
   const int ci = chunk * a.CC + cl;
   float v = 0.f;
-  if (ci < a.cin_g && co < a.cout_g && ky < a.k && kx < a.k)
-    v = a.w[ci * a.sa + co * a.sb + ky * a.k + kx];
+  if (ci < a.cin_g && cch < a.cout_g && ky < a.k && kx >= 0 && kx < a.k)
+    v = a.w[ci * a.sa + cch * a.sb + ky * a.k + kx];
   a.dst[i] = v;
 }
 
 struct IgemmConfig {
   int CC, NT, WN, MT, TPR, BH, COB, nchunk, cout_padP, IH, IW, IWq;
+  int PP, COP, tapsx, ISx;
   size_t lds_bytes;
   bool ok;
 };
@@ -244,6 +254,15 @@ IgemmConfig igemm_config(const ConvGeom& g) {
   else { c.NT = 1; c.WN = 1; }
   c.COB = 16 * c.NT * c.WN;
   c.cout_padP = bp_round_up(g.cout_g, c.COB);
+  // Few produced channels on a unit-stride grid: pack PP neighbouring pixels into the 16 MFMA columns
+  // (column = (pixel-in-group, channel)); costs PP-1 extra taps along x, saves a factor PP of M tiles.
+  c.PP = 1; c.COP = 16; c.tapsx = g.taps; c.ISx = g.IS;
+  if (g.cout_g <= 8 && g.IS == 1 && g.OS == 1 && g.nphase == 1) {
+    c.COP = g.cout_g <= 1 ? 1 : (g.cout_g <= 2 ? 2 : (g.cout_g <= 4 ? 4 : 8));
+    c.PP = 16 / c.COP;
+    c.tapsx = g.taps + c.PP - 1;
+    c.ISx = c.PP;
+  }
   const int cin4 = bp_round_up(g.cin_g, 4);
   const int cc_first = cin4 >= 16 ? 16 : (cin4 >= 8 ? 8 : 4);
   const int mts[2] = {4, 1};
@@ -253,9 +272,9 @@ IgemmConfig igemm_config(const ConvGeom& g) {
       const int TM = (4 / c.WN) * MT;
       const int TPR = (TM >= 16) ? 2 : 1;
       const int BH = TM / TPR, BW = 16 * TPR;
-      const int IH = (BH - 1) * g.IS + g.taps, IW = (BW - 1) * g.IS + g.taps;
-      const int IWq = bp_ceil_div(IW, g.IS);
-      const size_t lds = ((size_t)IH * g.IS * IWq * CC + (size_t)g.taps * c.COB * CC) * sizeof(float);
+      const int IH = (BH - 1) * g.IS + g.taps, IW = (BW - 1) * c.ISx + c.tapsx;
+      const int IWq = bp_ceil_div(IW, c.ISx);
+      const size_t lds = ((size_t)IH * c.ISx * IWq * CC + (size_t)c.tapsx * c.COB * CC) * sizeof(float);
       if (lds <= 64 * 1024) {
         c.CC = CC; c.MT = MT; c.TPR = TPR; c.BH = BH; c.IH = IH; c.IW = IW; c.IWq = IWq;
         c.nchunk = bp_ceil_div(g.cin_g, CC);
@@ -302,7 +321,7 @@ int bp_igemm_kernel_id(const ConvGeom& g) {
 int64_t bp_igemm_packed_floats(const ConvGeom& g) {
   const IgemmConfig c = igemm_config(g);
   if (!c.ok) return -1;
-  return (int64_t)g.nphase * g.nphase * g.taps * g.taps * c.nchunk * c.cout_padP * c.CC;
+  return (int64_t)g.nphase * g.nphase * g.taps * c.tapsx * c.nchunk * c.cout_padP * c.CC;
 }
 
 int bp_igemm_pack(const ConvGeom& g, const WeightMap& wm, const float* w_torch, float* packed,
@@ -311,9 +330,9 @@ int bp_igemm_pack(const ConvGeom& g, const WeightMap& wm, const float* w_torch, 
   if (!c.ok) return BP_EUNSUPPORTED;
   PackArgs a{};
   a.w = w_torch; a.dst = packed; a.sa = wm.sa; a.sb = wm.sb;
-  a.k = g.k; a.stride = g.stride; a.pad = g.pad; a.taps = g.taps; a.nphase = g.nphase;
+  a.k = g.k; a.stride = g.stride; a.pad = g.pad; a.tapsy = g.taps; a.tapsx = c.tapsx; a.nphase = g.nphase;
   a.transposed = g.gather_transposed; a.cin_g = g.cin_g; a.cout_g = g.cout_g;
-  a.CC = c.CC; a.nchunk = c.nchunk; a.cout_padP = c.cout_padP;
+  a.CC = c.CC; a.nchunk = c.nchunk; a.cout_padP = c.cout_padP; a.PP = c.PP; a.COP = c.COP;
   a.total = bp_igemm_packed_floats(g);
   hipLaunchKernelGGL(pack_kernel, dim3((unsigned)((a.total + 255) / 256)), dim3(256), 0, st, a);
   BP_CHECK_LAUNCH();
@@ -328,13 +347,14 @@ int bp_igemm_run(const ConvGeom& g, const bp_view* in, const PW& pw, const float
   a.in = in->ptr; a.in_h = in->h; a.in_w = in->w; a.in_cs = in->cstride; a.in_co = in->coff; a.cin = g.cin_g;
   a.out = out->ptr; a.out_h = out->h; a.out_w = out->w; a.out_cs = out->cstride; a.out_co = out->coff;
   a.cout = g.cout_g; a.wp = packed; a.bias = bias; a.pw = pw;
-  a.taps = g.taps; a.IS = g.IS; a.OS = g.OS; a.nphase = g.nphase; a.transposed = g.gather_transposed;
+  a.tapsy = g.taps; a.tapsx = c.tapsx; a.ISy = g.IS; a.ISx = c.ISx; a.OS = g.OS; a.nphase = g.nphase;
+  a.transposed = g.gather_transposed; a.PP = c.PP; a.COP = c.COP;
   a.stride = g.stride; a.pad = g.pad;
   a.TPR = c.TPR; a.BH = c.BH; a.nchunk = c.nchunk; a.cout_padP = c.cout_padP;
   a.IH = c.IH; a.IW = c.IW; a.IWq = c.IWq;
   a.vec_ok = (in->cstride % 4 == 0 && in->coff % 4 == 0 &&
               (reinterpret_cast<uintptr_t>(in->ptr) % 16 == 0)) ? 1 : 0;
-  const int qh = bp_ceil_div(out->h, g.OS), qw = bp_ceil_div(out->w, g.OS);
+  const int qh = bp_ceil_div(out->h, g.OS), qw = c.PP > 1 ? bp_ceil_div(out->w, c.PP) : bp_ceil_div(out->w, g.OS);
   a.tiles_x = bp_ceil_div(qw, 16 * c.TPR);
   a.tiles_y = bp_ceil_div(qh, c.BH);
   const int64_t gz = (int64_t)in->n * g.nphase * g.nphase;

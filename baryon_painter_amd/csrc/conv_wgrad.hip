@@ -137,18 +137,33 @@ struct WreduceArgs {
 };
 
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(WreduceArgs a) {
-  // thread order = workspace order [ky][kx][cy][cx] (cx fastest): coalesced reads of every split
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  // 64 consecutive outputs (workspace order [ky][kx][cy][cx], cx fastest: coalesced) x 4 groups of
+  // splits per block; the 4 partial sums are added in a fixed order -> bitwise reproducible.
+  __shared__ double sh[4][64];
+  const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int64_t i = (int64_t)blockIdx.x * 64 + lane;
   const int64_t total = (int64_t)a.k * a.k * a.cy * a.cx;
-  if (i >= total) return;
-  const int cx = i % a.cx;
-  const int cy = (i / a.cx) % a.cy;
-  const int t = i / ((int64_t)a.cx * a.cy);
-  const int64_t stride = (int64_t)a.k * a.k * a.CYP * a.CXP;
-  const float* p = a.ws + ((int64_t)t * a.CYP + cy) * a.CXP + cx;
   double s = 0.0;
-  for (int sp = 0; sp < a.nsplit; ++sp) s += (double)p[sp * stride];
-  a.dst[((int64_t)cy * a.cx + cx) * a.k * a.k + t] = (float)s;
+  int cx = 0, cy = 0, t = 0;
+  if (i < total) {
+    cx = i % a.cx;
+    cy = (i / a.cx) % a.cy;
+    t = i / ((int64_t)a.cx * a.cy);
+    const int64_t stride = (int64_t)a.k * a.k * a.CYP * a.CXP;
+    const float* p = a.ws + ((int64_t)t * a.CYP + cy) * a.CXP + cx;
+    double s0 = 0.0, s1 = 0.0;
+    int sp = grp;
+    for (; sp + 4 < a.nsplit; sp += 8) {
+      s0 += (double)p[sp * stride];
+      s1 += (double)p[(sp + 4) * stride];
+    }
+    if (sp < a.nsplit) s0 += (double)p[sp * stride];
+    s = s0 + s1;
+  }
+  sh[grp][lane] = s;
+  __syncthreads();
+  if (grp == 0 && i < total)
+    a.dst[((int64_t)cy * a.cx + cx) * a.k * a.k + t] = (float)(((sh[0][lane] + sh[1][lane]) + sh[2][lane]) + sh[3][lane]);
 }
 
 struct WgradPlan {
@@ -195,7 +210,7 @@ static int wgrad_reduce(const float* ws, float* dst, int k, int cx, int cy, int 
   WreduceArgs r{};
   r.ws = ws; r.dst = dst; r.k = k; r.cx = cx; r.cy = cy; r.CXP = CXP; r.CYP = CYP; r.nsplit = nsplit;
   const int64_t total = (int64_t)cy * cx * k * k;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, r);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, st, r);
   BP_CHECK_LAUNCH();
   return BP_OK;
 }
@@ -240,7 +255,7 @@ int bp_wgrad_mfma(const bp_conv* cv, const bp_view* X, const PW& pwx, const bp_v
   r.ws = a.ws; r.dst = dst; r.k = cv->k; r.cx = X->c; r.cy = Y->c; r.CXP = p.CXP; r.CYP = p.CYP;
   r.nsplit = p.nsplit;
   const int64_t total = (int64_t)Y->c * X->c * cv->k * cv->k;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, r);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, st, r);
   BP_CHECK_LAUNCH();
   return BP_OK;
 }

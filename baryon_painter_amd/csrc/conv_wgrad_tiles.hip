@@ -257,7 +257,7 @@ int launch(const bp_conv* cv, const bp_view* X, const PW& pwx, const bp_view* Y,
   const int kyg = bp_ceil_div(cv->k, KHB);
   const int64_t ntiles = (int64_t)Y->n * a.tiles_x * a.tiles_y;
   const int64_t base = (int64_t)a.ncxb * ncyb * kyg;
-  int64_t ns = (768 + base - 1) / base;      // ~3 workgroups per CU
+  int64_t ns = (512 + base - 1) / base;      // ~2 workgroups per CU
   if (ns > ntiles) ns = ntiles;
   if (ns < 1) ns = 1;
   if (ns > 65535) ns = 65535;

@@ -331,7 +331,18 @@ class _ELBOFunction(torch.autograd.Function):
         plan.backward(grad_out.detach().to(torch.float32), model._grad_views_by_id)
         if model.sync is not None:
             model.sync.all_reduce_mean(flat)
-        return (None, None, None, None, None, None) + tuple(model._grad_views)
+        # Parameter gradients live in ONE flat buffer; after optimizer.zero_grad() (grad = None) the
+        # views are attached directly instead of letting autograd clone 92 tensors per step.
+        out = []
+        for p, gv in zip(model._params, model._grad_views):
+            if p.grad is None:
+                p.grad = gv
+                out.append(None)
+            elif p.grad.data_ptr() == gv.data_ptr():
+                out.append(None)          # already attached: the plan overwrote it in place
+            else:
+                out.append(gv)            # a foreign .grad tensor: let autograd accumulate
+        return (None, None, None, None, None, None) + tuple(out)
 
 
 class CVAE(torch.nn.Module):
