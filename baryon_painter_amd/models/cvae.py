@@ -401,6 +401,7 @@ class CVAE(torch.nn.Module):
         self.beta_KL = 1.0
         self.n_aux = 1
         self._plans = {}
+        self._graphs = {}
         self._eps_override = None
         self.to(self.device)
         self._flatten_parameters()
@@ -428,6 +429,7 @@ class CVAE(torch.nn.Module):
         if hasattr(self, "_flat_params"):
             self._flatten_parameters()
             self._plans = {}
+            self._graphs = {}
         return out
 
     def load_state_dict(self, *a, **k):
@@ -534,6 +536,62 @@ class CVAE(torch.nn.Module):
                 self._head_to_nchw(plan.var_head, False, lv)
                 return mu, torch.exp(lv)
             return mu
+
+    # ---- hipGraph-captured eval forward (BASELINE.json configs[4]: stream tiles through P)
+    def sample_P_graphed(self, y, aux_label=None):
+        """``sample_P`` (prior-sampled z, mean head) replayed from a captured hipGraph: one graph
+        launch instead of ~110 kernel launches per batch.  Eval mode only; the graph is captured per
+        batch size on first use and re-used while the parameters' storage is unchanged."""
+        if self.training:
+            raise RuntimeError("sample_P_graphed is an eval-mode (paint) path: call model.train(False) first")
+        y = torch.as_tensor(y, device=self.device, dtype=torch.float32)
+        self._check_inputs(None, y)
+        n = y.shape[0]
+        aux = self._aux(aux_label, n)
+        g = self._graphs.get(n)
+        if g is None:
+            g = self._capture_paint_graph(n)
+            self._graphs[n] = g
+        for u in g["units"]:
+            u.maybe_pack()                       # eager, a no-op unless the weights changed
+        g["y"].copy_(y)
+        if aux is not None:
+            g["aux"].copy_(aux)
+        if self._eps_override is not None:
+            raise RuntimeError("eps override is not supported on the graphed path (noise is drawn in-graph)")
+        g["graph"].replay()
+        return g["out"].clone()
+
+    def _capture_paint_graph(self, n):
+        plan = self._plan(n, False, False)
+        cy, H, W = self.dim_y
+        cx = self.dim_x[0]
+        st = {"y": torch.zeros((n, cy, H, W), device=self.device),
+              "aux": torch.zeros((n, self.n_aux), device=self.device) if self.use_aux_label else None,
+              "out": torch.zeros((n, cx, H, W), device=self.device)}
+        units = []
+        for us in [plan.p_units] + plan.g_units + [plan.mu_units]:
+            for u in us:
+                units += u.body if hasattr(u, "body") else [u]
+        st["units"] = units
+
+        def run():
+            plan.load_inputs(st["y"], st["aux"])
+            plan.run_prior(False)
+            plan.run_latent(torch.randn(size=(self.L, n, *self.dim_z), device=self.device), use_q=False)
+            plan.run_generator(False)
+            self._head_to_nchw(plan.mu_head, plan.mu_softplus, st["out"])
+
+        side = torch.cuda.Stream(device=self.device)
+        side.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(side), torch.no_grad():
+            run()                                 # warm-up outside capture (packs weights, sizes workspaces)
+        torch.cuda.current_stream(self.device).wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.no_grad(), torch.cuda.graph(graph, stream=side):
+            run()
+        st["graph"] = graph
+        return st
 
     def _head_to_nchw(self, slot, softplus, dst):
         L.check(self._lib.bp_view_to_nchw(C.byref(slot.view), None, 1 if softplus else 0, L.ptr(dst), _stream()),

@@ -257,7 +257,7 @@ class CVAEPainter(Painter):
             return self.inverse_transform(prediction, field=self.label_fields[0], z=z)
         return prediction
 
-    def paint_batch(self, inputs, z, transform=True, inverse_transform=True, batch_size=64):
+    def paint_batch(self, inputs, z, transform=True, inverse_transform=True, batch_size=64, use_graph=True):
         """Throughput form of ``paint``: many tiles (N,H,W) with redshifts (N,) in batches through the
         same eval-mode forward (BASELINE.json configs[4]); per-tile results equal ``paint``'s up to
         the prior noise draw."""
@@ -277,7 +277,9 @@ class CVAEPainter(Painter):
                 y = y.reshape(y.shape[0], *self.model.dim_y)
                 yt = torch.tensor(y, device=self.compute_device, dtype=torch.float32)
                 aux = torch.tensor(zc, device=self.compute_device, dtype=torch.float32)
-                pred = self.model.sample_P(yt, aux_label=aux).cpu().numpy()
+                graphed = use_graph and self.model._eps_override is None and yt.shape[0] == batch_size
+                sample = self.model.sample_P_graphed if graphed else self.model.sample_P
+                pred = sample(yt, aux_label=aux).cpu().numpy()
                 if inverse_transform and self.inverse_transform is not None:
                     pred = np.stack([self.inverse_transform(p[None], field=self.label_fields[0], z=float(zz))
                                      for p, zz in zip(pred, zc)])

@@ -92,6 +92,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--local-bn", action="store_true", help="do not all-reduce batch-norm statistics")
     ap.add_argument("--layers", action="store_true", help="also print a per-layer table to stderr")
+    ap.add_argument("--no-paint", action="store_true", help="skip the paint() throughput leg")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -156,11 +157,37 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
     final_elbo = float(elbo.detach())
+    prof_events, plan.prof = plan.prof, None       # stop recording before the paint leg
+
+    # ---- paint(): eval-mode prior -> sampler -> generator, hipGraph-captured, tiles resident in HBM
+    paint_leg = None
+    if not args.no_paint:
+        model.train(False)
+        pb = min(n, 64)
+        with torch.no_grad():
+            model.sample_P_graphed(y[:pb], aux_label=aux[:pb])          # capture
+            torch.cuda.synchronize()
+            reps = 10
+            t0p = time.perf_counter()
+            for _ in range(reps):
+                model.sample_P_graphed(y[:pb], aux_label=aux[:pb])
+            torch.cuda.synchronize()
+            tg = (time.perf_counter() - t0p) / reps
+            t0p = time.perf_counter()
+            for _ in range(3):
+                model.sample_P(y[:pb], aux_label=aux[:pb])
+            torch.cuda.synchronize()
+            te = (time.perf_counter() - t0p) / 3
+        paint_leg = {"metric": "paint_tiles_per_sec", "value": round(world * pb / tg, 1), "unit": "tiles/s",
+                     "batch": pb, "ms_per_batch_graph": round(tg * 1e3, 3), "ms_per_batch_eager": round(te * 1e3, 3),
+                     "note": "sample_P (prior + sampler + generator, eval batch-norm) on resident tiles; "
+                             "per-rank, no collective"}
+        model.train(True)
 
     if rank == 0:
         # ---- roofline of the dominant kernel
         per = {}
-        for e0, e1, unit, kind in plan.prof:
+        for e0, e1, unit, kind in prof_events:
             name = kernel_name(kind, unit, model._lib)
             d = per.setdefault(name, {"ms": 0.0, "launches": 0, "flop": 0.0})
             d["ms"] += e0.elapsed_time(e1)
@@ -168,7 +195,7 @@ def main():
             d["flop"] += 2.0 * unit.macs()
         if args.layers:
             lay = {}
-            for e0, e1, unit, kind in plan.prof:
+            for e0, e1, unit, kind in prof_events:
                 d = lay.setdefault((unit.name, kind), [0.0, 2.0 * unit.macs(), kernel_name(kind, unit, model._lib)])
                 d[0] += e0.elapsed_time(e1) / args.steps
             for (name, kind), (ms, fl, kn) in sorted(lay.items(), key=lambda kv: -kv[1][0]):
@@ -199,6 +226,7 @@ def main():
                        "optimizer": "torch.optim.Adam(lr=1e-3)", "final_elbo": final_elbo},
             "roofline": roofline,
         }
+        out["paint"] = paint_leg
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(arch)
         print(json.dumps(out), flush=True)
