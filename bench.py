@@ -204,8 +204,13 @@ def main():
         d = per[dom]
         achieved = d["flop"] / (d["ms"] * 1e-3) / 1e12
         conv_ms = sum(v["ms"] for v in per.values()) / args.steps
+        traffic = None
+        try:       # HBM bytes per launch from the PMC passes (rocprofv3 cannot run inside bench.py)
+            traffic = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["hbm_bytes_per_launch"].get(dom)
+        except Exception:
+            pass
         roofline = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                    "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
                     "avg_launch_ms": round(d["ms"] / d["launches"], 4),
                     "flop_per_launch": d["flop"] / d["launches"], "launches_per_step": d["launches"] // args.steps,
                     "share_of_step": round(d["ms"] / args.steps / (dt / args.steps * 1e3), 3),
