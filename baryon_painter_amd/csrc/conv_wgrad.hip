@@ -204,6 +204,16 @@ WgradPlan wgrad_plan(const bp_conv* cv, const bp_view* X, const bp_view* Y) {
 
 int bp_wgrad_tiles(const bp_conv* cv, const bp_view* X, const PW& pwx, const bp_view* Y, const PW& pwy, float* ws,
                    size_t ws_bytes, size_t* need, int* nsplit, int* cxp, int* cyp, hipStream_t st, bool dry);
+int bp_wgrad_small(const bp_conv* cv, const bp_view* X, const PW& pwx, const bp_view* Y, const PW& pwy, float* ws,
+                   size_t ws_bytes, size_t* need, int* nsplit, int* cxp, int* cyp, hipStream_t st, bool dry);
+
+// tap-packed few-channel kernel first, then the tap-blocked one; BP_EUNSUPPORTED -> generic kernel
+static int wgrad_fast(const bp_conv* cv, const bp_view* X, const PW& pwx, const bp_view* Y, const PW& pwy, float* ws,
+                      size_t ws_bytes, size_t* need, int* nsplit, int* cxp, int* cyp, hipStream_t st, bool dry) {
+  int rc = bp_wgrad_small(cv, X, pwx, Y, pwy, ws, ws_bytes, need, nsplit, cxp, cyp, st, dry);
+  if (rc == BP_EUNSUPPORTED) rc = bp_wgrad_tiles(cv, X, pwx, Y, pwy, ws, ws_bytes, need, nsplit, cxp, cyp, st, dry);
+  return rc;
+}
 
 static int wgrad_reduce(const float* ws, float* dst, int k, int cx, int cy, int CXP, int CYP, int nsplit,
                         hipStream_t st) {
@@ -219,7 +229,7 @@ size_t bp_wgrad_mfma_workspace(const bp_conv* cv, const bp_view* X, const bp_vie
   size_t need = 0;
   int ns, cxp, cyp;
   const PW none{nullptr, nullptr, nullptr};
-  if (bp_wgrad_tiles(cv, X, none, Y, none, nullptr, 0, &need, &ns, &cxp, &cyp, nullptr, true) == BP_OK) return need;
+  if (wgrad_fast(cv, X, none, Y, none, nullptr, 0, &need, &ns, &cxp, &cyp, nullptr, true) == BP_OK) return need;
   const WgradPlan p = wgrad_plan(cv, X, Y);
   return p.ok ? p.ws_bytes : 0;
 }
@@ -229,8 +239,8 @@ int bp_wgrad_mfma(const bp_conv* cv, const bp_view* X, const PW& pwx, const bp_v
   {
     size_t need = 0;
     int ns, cxp, cyp;
-    const int rc = bp_wgrad_tiles(cv, X, pwx, Y, pwy, reinterpret_cast<float*>(workspace), workspace_bytes, &need,
-                                  &ns, &cxp, &cyp, st, false);
+    const int rc = wgrad_fast(cv, X, pwx, Y, pwy, reinterpret_cast<float*>(workspace), workspace_bytes, &need,
+                              &ns, &cxp, &cyp, st, false);
     if (rc == BP_OK)
       return wgrad_reduce(reinterpret_cast<const float*>(workspace), dst, cv->k, X->c, Y->c, cxp, cyp, ns, st);
     if (rc != BP_EUNSUPPORTED) return rc;

@@ -1,0 +1,251 @@
+// Weight gradient of unit-stride convolutions with FEW channels on one or both sides
+// (the full-resolution ends of the generator: 3->16 k5, 16->8 k7, 8->1 k5, 1->1 k3), fp32 MFMA 16x16x4.
+//
+//   dW[ky][kx][cx][cy] = sum_{n,r,x} act(X)[n, r+ky-p, x+kx-p, cx] * Y[n, r, x, cy]
+//
+// A 16x16 MFMA tile would be mostly padding if M = cx and N = cy.  Instead the tile's rows and
+// columns are filled with kernel taps:
+//   M row    i = (tpx, cx):  TPM = 16/CXS neighbouring x-taps  -> A[i][pixel] = X[r'+ky0-p][x+kx0+tpx-p][cx]
+//   N column j = (tpy, cy):  TPN = 16/CYS neighbouring y-taps  -> B[pixel][j] = Y[r'-tpy][x][cy]
+// (substituting r' = r + tpy moves the y-tap from X to Y, so one B fragment serves every tap group).
+// With the tiles stored compactly in LDS ([row][x][CXS] / [row][x][CYS]) both fragments are 16
+// CONSECUTIVE floats per pixel: conflict-free b32 reads, no per-lane gather tables.  Y gets TPN-1
+// zero rows above and TPNe-1 below so that shifted reads outside the tile's own rows contribute 0.
+// MFMAs per 4-pixel k-step: ceil(k/TPM)*ceil(k/TPN) instead of k*k (49 -> 28, 25 -> 10, 25 -> 3, 9 -> 1).
+//
+// Workgroup = 4 waves splitting the k-steps of a BH x 32 pixel tile; pixel tiles are split over
+// workgroups; partials go to the workspace layout of conv_wgrad.hip and are reduced there.
+#include "common.hpp"
+
+namespace {
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+struct WsArgs {
+  const float* X; int xh, xw, xcs, xco, cx;
+  const float* Y; int yh, yw, ycs, yco, cy;
+  int n, pad;
+  PW pwx, pwy;
+  float* ws;
+  int nsplit, tiles_x, tiles_y;
+  int xvec, yvec;
+};
+
+template <int K, int CXS, int CYS, int BH>
+struct WsCfg {
+  static constexpr int TPM = 16 / CXS, TPN = 16 / CYS;
+  static constexpr int GX = (K + TPM - 1) / TPM, GY = (K + TPN - 1) / TPN;
+  static constexpr int TPNe = TPN < K ? TPN : K;
+  static constexpr int RS = BH + TPNe - 1;                 // k-step rows per tile
+  static constexpr int XR = RS + (GY - 1) * TPN;           // X rows staged
+  static constexpr int XW = 32 + GX * TPM - 1;             // X columns staged
+  static constexpr int XWS = XW + 3;                       // (+3: the 4-pixel k-step of the last group)
+  static constexpr int PADR = TPN - 1;                     // zero rows above the Y tile
+  static constexpr int YR = PADR + BH + TPNe - 1;
+  static constexpr int YWS = 34;                           // row pitch: keeps the shifted B reads conflict-free
+  static constexpr int XF = XR * XWS * CXS, YF = YR * YWS * CYS;
+  static constexpr size_t LDS_MAIN = (size_t)(XF + YF) * 4;
+  static constexpr size_t LDS_RED = (size_t)4 * 64 * 4 * 4;
+  static constexpr size_t LDS = LDS_MAIN > LDS_RED ? LDS_MAIN : LDS_RED;
+};
+
+template <int K, int CXS, int CYS, int BH>
+__global__ __launch_bounds__(256) void wgrad_small_kernel(WsArgs a) {
+  using C = WsCfg<K, CXS, CYS, BH>;
+  constexpr int TPM = C::TPM, TPN = C::TPN, GX = C::GX, GY = C::GY, RS = C::RS, XR = C::XR, XW = C::XW;
+  constexpr int XWS = C::XWS, PADR = C::PADR, YWS = C::YWS;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* xs = smem;
+  float* ys = smem + C::XF;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wk = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, kq = lane >> 4;
+  const int split = blockIdx.x;
+
+  v4f acc[GY][GX];
+#pragma unroll
+  for (int i = 0; i < GY; ++i)
+#pragma unroll
+    for (int j = 0; j < GX; ++j) acc[i][j] = v4f{0.f, 0.f, 0.f, 0.f};
+
+  // zero the whole Y image once: the pad rows stay zero, the interior is rewritten per tile
+  for (int e = tid; e < C::YF; e += 256) ys[e] = 0.f;
+
+  const int a_lane = kq * CXS + li;                                 // (4 pixels) x (16 consecutive floats)
+  const int b_lane = (kq - (li / CYS) * YWS) * CYS + (li % CYS);    // column (tpy, cy): row shifted up by tpy
+
+  const PW4 px4 = pw4_load(a.pwx, (tid % (CXS >= 4 ? CXS / 4 : 1)) * 4, a.cx);
+  const PW4 py4 = pw4_load(a.pwy, (tid % (CYS >= 4 ? CYS / 4 : 1)) * 4, a.cy);
+  const int tiles_per_img = a.tiles_x * a.tiles_y;
+  const int ntiles = a.n * tiles_per_img;
+  for (int tile = split; tile < ntiles; tile += a.nsplit) {
+    const int n = tile / tiles_per_img;
+    const int trem = tile - n * tiles_per_img;
+    const int ty_ = trem / a.tiles_x, tx_ = trem - ty_ * a.tiles_x;
+    const int qy0 = ty_ * BH, qx0 = tx_ * 32;
+    __syncthreads();
+    // ---- stage X rows [qy0-p, qy0-p+XR) x cols [qx0-p, qx0-p+XW), channels padded to CXS
+    {
+      const float* Xn = a.X + (int64_t)n * a.xh * a.xw * a.xcs + a.xco;
+      if (CXS >= 4 && a.xvec) {
+        constexpr int C4 = CXS >= 4 ? CXS / 4 : 1;
+        const int c4 = tid % C4, ch = c4 * 4;
+        for (int e = tid; e < XR * XW * C4; e += 256) {
+          const int pix = e / C4;
+          const int c = pix % XW, r = pix / XW;
+          const int iy = qy0 - a.pad + r, ix = qx0 - a.pad + c;
+          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (ch < a.cx && iy >= 0 && iy < a.xh && ix >= 0 && ix < a.xw) {
+            v = *reinterpret_cast<const float4*>(Xn + ((int64_t)iy * a.xw + ix) * a.xcs + ch);
+            v = pw4_apply4(px4, v);
+            if (ch + 1 >= a.cx) v.y = 0.f;
+            if (ch + 2 >= a.cx) v.z = 0.f;
+            if (ch + 3 >= a.cx) v.w = 0.f;
+          }
+          *reinterpret_cast<float4*>(xs + (r * XWS + c) * CXS + ch) = v;
+        }
+      } else {
+        for (int e = tid; e < XR * XW * CXS; e += 256) {
+          const int ch = e % CXS;
+          const int pix = e / CXS;
+          const int c = pix % XW, r = pix / XW;
+          const int iy = qy0 - a.pad + r, ix = qx0 - a.pad + c;
+          float v = 0.f;
+          if (ch < a.cx && iy >= 0 && iy < a.xh && ix >= 0 && ix < a.xw)
+            v = pw_apply(a.pwx, ch, Xn[((int64_t)iy * a.xw + ix) * a.xcs + ch]);
+          xs[(r * XWS + c) * CXS + ch] = v;
+        }
+      }
+      // the 3 slack columns of each row are only read by k-steps whose outputs are discarded,
+      // but must hold finite numbers
+      for (int e = tid; e < XR * 3 * CXS; e += 256) {
+        const int ch = e % CXS, c = XW + (e / CXS) % 3, r = e / (3 * CXS);
+        xs[(r * XWS + c) * CXS + ch] = 0.f;
+      }
+    }
+    // ---- stage Y rows [qy0, qy0+BH) x cols [qx0, qx0+32)
+    {
+      const float* Yn = a.Y + (int64_t)n * a.yh * a.yw * a.ycs + a.yco;
+      if (CYS >= 4 && a.yvec) {
+        constexpr int C4 = CYS >= 4 ? CYS / 4 : 1;
+        const int c4 = tid % C4, ch = c4 * 4;
+        for (int e = tid; e < BH * 32 * C4; e += 256) {
+          const int pix = e / C4;
+          const int c = pix & 31, r = pix >> 5;
+          const int qy = qy0 + r, qx = qx0 + c;
+          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (ch < a.cy && qy < a.yh && qx < a.yw) {
+            v = *reinterpret_cast<const float4*>(Yn + ((int64_t)qy * a.yw + qx) * a.ycs + ch);
+            v = pw4_apply4(py4, v);
+            if (ch + 1 >= a.cy) v.y = 0.f;
+            if (ch + 2 >= a.cy) v.z = 0.f;
+            if (ch + 3 >= a.cy) v.w = 0.f;
+          }
+          *reinterpret_cast<float4*>(ys + ((PADR + r) * YWS + c) * CYS + ch) = v;
+        }
+      } else {
+        for (int e = tid; e < BH * 32 * CYS; e += 256) {
+          const int ch = e % CYS;
+          const int pix = e / CYS;
+          const int c = pix & 31, r = pix >> 5;
+          const int qy = qy0 + r, qx = qx0 + c;
+          float v = 0.f;
+          if (ch < a.cy && qy < a.yh && qx < a.yw)
+            v = pw_apply(a.pwy, ch, Yn[((int64_t)qy * a.yw + qx) * a.ycs + ch]);
+          ys[((PADR + r) * YWS + c) * CYS + ch] = v;
+        }
+      }
+    }
+    __syncthreads();
+    // ---- k-steps: row r' (0..RS-1), pixel group g (0..7); this wave takes every 4th
+    for (int s = wk; s < RS * 8; s += 4) {
+      const int r = s >> 3, g = s & 7;
+      const float bf = ys[((PADR + r) * YWS + 4 * g) * CYS + b_lane];
+      const float* xp = xs + (r * XWS + 4 * g) * CXS + a_lane;
+#pragma unroll
+      for (int gy = 0; gy < GY; ++gy)
+#pragma unroll
+        for (int gx = 0; gx < GX; ++gx) {
+          const float af = xp[(gy * TPN * XWS + gx * TPM) * CXS];
+          acc[gy][gx] = __builtin_amdgcn_mfma_f32_16x16x4f32(af, bf, acc[gy][gx], 0, 0, 0);
+        }
+    }
+  }
+
+  // ---- reduce the 4 waves and write: D[row = 4*(lane>>4)+r : (tpx,cx)][col = lane&15 : (tpy,cy)]
+  float* red = smem;   // [4][64][4]
+#pragma unroll
+  for (int gy = 0; gy < GY; ++gy)
+#pragma unroll
+    for (int gx = 0; gx < GX; ++gx) {
+      __syncthreads();
+      *reinterpret_cast<float4*>(red + (wk * 64 + lane) * 4) =
+          make_float4(acc[gy][gx][0], acc[gy][gx][1], acc[gy][gx][2], acc[gy][gx][3]);
+      __syncthreads();
+      {
+        const int l = tid >> 2, rr = tid & 3;          // 64 lanes x 4 registers
+        const float sum = ((red[(0 * 64 + l) * 4 + rr] + red[(1 * 64 + l) * 4 + rr]) +
+                           red[(2 * 64 + l) * 4 + rr]) + red[(3 * 64 + l) * 4 + rr];
+        const int i = 4 * (l >> 4) + rr, j = l & 15;
+        const int kx = gx * TPM + i / CXS, cxi = i % CXS;
+        const int ky = gy * TPN + j / CYS, cyi = j % CYS;
+        if (kx < K && ky < K)
+          a.ws[((((int64_t)split * K + ky) * K + kx) * CYS + cyi) * CXS + cxi] = sum;
+      }
+    }
+}
+
+template <int K, int CXS, int CYS, int BH>
+int launch(const bp_view* X, const PW& pwx, const bp_view* Y, const PW& pwy, int pad, float* ws, size_t ws_bytes,
+           size_t* need, int* nsplit, int* cxp, int* cyp, hipStream_t st, bool dry) {
+  using C = WsCfg<K, CXS, CYS, BH>;
+  static_assert(C::LDS <= 64 * 1024, "LDS budget");
+  WsArgs a{};
+  a.X = X->ptr; a.xh = X->h; a.xw = X->w; a.xcs = X->cstride; a.xco = X->coff; a.cx = X->c;
+  a.Y = Y->ptr; a.yh = Y->h; a.yw = Y->w; a.ycs = Y->cstride; a.yco = Y->coff; a.cy = Y->c;
+  a.n = X->n; a.pad = pad; a.pwx = pwx; a.pwy = pwy; a.ws = ws;
+  a.tiles_x = bp_ceil_div(Y->w, 32);
+  a.tiles_y = bp_ceil_div(Y->h, BH);
+  int64_t ntiles = (int64_t)Y->n * a.tiles_x * a.tiles_y;
+  int64_t ns = ntiles < 1024 ? ntiles : 1024;          // ~4 workgroups per CU
+  a.nsplit = (int)ns;
+  *need = (size_t)a.nsplit * K * K * CYS * CXS * sizeof(float);
+  *nsplit = a.nsplit; *cxp = CXS; *cyp = CYS;
+  if (dry) return BP_OK;
+  if (!ws || ws_bytes < *need) return BP_EWORKSPACE;
+  a.xvec = (X->cstride % 4 == 0 && X->coff % 4 == 0 && reinterpret_cast<uintptr_t>(X->ptr) % 16 == 0) ? 1 : 0;
+  a.yvec = (Y->cstride % 4 == 0 && Y->coff % 4 == 0 && reinterpret_cast<uintptr_t>(Y->ptr) % 16 == 0) ? 1 : 0;
+  hipLaunchKernelGGL((wgrad_small_kernel<K, CXS, CYS, BH>), dim3((unsigned)a.nsplit), dim3(256), C::LDS, st, a);
+  BP_CHECK_LAUNCH();
+  return BP_OK;
+}
+
+int pow2_at_least(int c) { return c <= 1 ? 1 : (c <= 2 ? 2 : (c <= 4 ? 4 : (c <= 8 ? 8 : 16))); }
+
+}  // namespace
+
+// BP_EUNSUPPORTED unless: unit stride, both channel counts <= 16, at least one < 16, k in {3,5,7}.
+int bp_wgrad_small(const bp_conv* cv, const bp_view* X, const PW& pwx, const bp_view* Y, const PW& pwy, float* ws,
+                   size_t ws_bytes, size_t* need, int* nsplit, int* cxp, int* cyp, hipStream_t st, bool dry) {
+  if (cv->stride != 1 || X->c > 16 || Y->c > 16 || (X->c == 16 && Y->c == 16)) return BP_EUNSUPPORTED;
+  const int cxs = pow2_at_least(X->c), cys = pow2_at_least(Y->c);
+#define BP_WS(K_, CX_, CY_, BH_) \
+  if (cv->k == K_ && cxs == CX_ && cys == CY_) \
+    return launch<K_, CX_, CY_, BH_>(X, pwx, Y, pwy, cv->pad, ws, ws_bytes, need, nsplit, cxp, cyp, st, dry)
+  BP_WS(7, 16, 8, 8);
+  BP_WS(5, 4, 16, 8);
+  BP_WS(5, 8, 1, 16);
+  BP_WS(3, 1, 1, 16);
+  BP_WS(5, 16, 8, 8);
+  BP_WS(3, 16, 8, 8);
+  BP_WS(3, 8, 16, 8);
+  BP_WS(3, 4, 16, 8);
+  BP_WS(3, 8, 8, 8);
+  BP_WS(5, 8, 8, 8);
+  BP_WS(5, 1, 1, 16);
+  BP_WS(7, 1, 1, 16);
+#undef BP_WS
+  return BP_EUNSUPPORTED;
+}
