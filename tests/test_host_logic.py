@@ -192,3 +192,25 @@ def test_sync_collectives_over_gloo(tmp_path):
                          capture_output=True, text=True, env=env, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "rank 0 ok" in out.stdout and "rank 1 ok" in out.stdout
+
+
+def test_lightcone_tiling_known_answers():
+    """The four known answers of the reference's tests/test_SLICS_tiling.py:72-81 + coverage."""
+    from baryon_painter_amd.lightcone import generate_tiling, get_tile, make_weight_map
+    assert len(generate_tiling(512, 256, min_tile_overlap=0.0)[0]) == 2
+    assert len(generate_tiling(512, 250, min_tile_overlap=0.0)[0]) == 3
+    assert len(generate_tiling(512, 256, min_tile_overlap=0.5)[0]) == 3
+    assert len(generate_tiling(512, 128, min_tile_overlap=0.0)[0]) == 4
+    _, tiles = generate_tiling(512, 32, min_tile_overlap=0.33)
+    cover = np.zeros((512, 512))
+    for row in tiles:
+        for s in row:
+            cover[s] += 1
+    assert cover.min() >= 1 and cover[:32, :32].max() <= 4
+    m = np.arange(64.0).reshape(8, 8)
+    t = get_tile(m, (0.75, 0.5), 0.5)
+    assert t.shape == (4, 4) and t[0, 0] == m[6, 4] and t[3, 3] == m[1, 7]      # wraps around
+    with pytest.raises(ValueError):
+        get_tile(m, (0, 0), 0.5, expansion_factor=0.5)
+    w = make_weight_map((100, 100), falloff=0.05, sigma=0.5)
+    assert w[50, 50] == 1.0 and w[0, 50] == pytest.approx(np.exp(-0.5 * 25 / 6.25)) and np.allclose(w, w.T)
