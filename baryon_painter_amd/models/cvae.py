@@ -424,6 +424,11 @@ class CVAE(torch.nn.Module):
             off += k
         self._params = params
 
+    def _bump_param_versions(self):
+        """Called after an out-of-band in-place update of the flat buffer (FlatAdam): convolution units
+        re-pack their weights when this counter changes."""
+        self._param_epoch = getattr(self, "_param_epoch", 0) + 1
+
     def _apply(self, fn, *a, **k):
         out = super()._apply(fn, *a, **k)
         if hasattr(self, "_flat_params"):

@@ -263,7 +263,7 @@ class ConvUnit:
     # ---- weights
     def maybe_pack(self):
         w = self.holder.weight
-        ver = (w._version, w.data_ptr())
+        ver = (w._version, w.data_ptr(), getattr(self.plan.model, "_param_epoch", 0))
         if ver == self._packed_version:
             return
         lib, st = self.plan.lib, _stream()

@@ -90,7 +90,9 @@ class CVAEPainter(Painter):
             batch_size = adaptive_batch_size(0)
         dataloader = self._loader(batch_size)
 
-        optimizer = torch.optim.Adam(model.parameters(), lr=learning_rate)
+        # torch.optim.Adam arithmetic, one fused launch over the flat parameter buffer
+        from .optim import FlatAdam
+        optimizer = FlatAdam(model, lr=learning_rate)
         scheduler = None
         if adaptive_learning_rate is not None:
             if callable(adaptive_learning_rate):

@@ -95,6 +95,7 @@ def main():
     ap.add_argument("--local-bn", action="store_true", help="do not all-reduce batch-norm statistics")
     ap.add_argument("--layers", action="store_true", help="also print a per-layer table to stderr")
     ap.add_argument("--no-paint", action="store_true", help="skip the paint() throughput leg")
+    ap.add_argument("--torch-adam", action="store_true", help="torch.optim.Adam instead of the fused FlatAdam")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -123,7 +124,8 @@ def main():
     import contextlib
     with contextlib.redirect_stdout(sys.stderr):     # the model announces itself like the reference does
         model = CVAE(arch, dev, sync=sync)
-    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    from baryon_painter_amd.optim import FlatAdam
+    opt = FlatAdam(model, lr=1e-3) if not args.torch_adam else torch.optim.Adam(model.parameters(), lr=1e-3)
     n = args.batch
     # synthetic tiles: a few distinct ones, tiled up to the batch (generation cost, not arithmetic)
     nb = min(n, 8)
@@ -230,7 +232,7 @@ def main():
                        "tile": args.tile, "batch_per_gpu": n, "global_batch": n * world,
                        "parallelism": f"dp{world}", "batch_norm": "local" if args.local_bn or world == 1 and False
                        else ("global (all-reduced statistics)" if world > 1 else "single device"),
-                       "optimizer": "torch.optim.Adam(lr=1e-3)", "final_elbo": final_elbo},
+                       "optimizer": "torch.optim.Adam(lr=1e-3)" if args.torch_adam else "FlatAdam(lr=1e-3) = torch.optim.Adam arithmetic, fused", "final_elbo": final_elbo},
             "roofline": roofline,
         }
         out["paint"] = paint_leg

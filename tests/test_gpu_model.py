@@ -151,6 +151,28 @@ def test_adam_step_matches_reference(golden_model):
     assert len(bad) <= 2, bad
 
 
+def test_flat_adam_equals_torch_adam():
+    from baryon_painter_amd.optim import FlatAdam
+    arch = A.fiducial_architecture(64)
+    x, y, aux = syn.synthetic_batch(2, 64, 64, seed=3)
+    eps = syn.synthetic_eps((1, 2, *arch["dim_z"]), seed=4)
+    finals = []
+    for kind in ("torch", "flat"):
+        m, _ = _model(arch)
+        m._eps_override = eps
+        opt = torch.optim.Adam(m.parameters(), lr=1e-3) if kind == "torch" else FlatAdam(m, lr=1e-3)
+        sched = torch.optim.lr_scheduler.LambdaLR(opt, lambda e: 0.5 ** e)
+        for _ in range(3):
+            elbo = m(torch.from_numpy(x), torch.from_numpy(y), torch.from_numpy(aux))
+            opt.zero_grad()
+            (-elbo).backward()
+            opt.step()
+            sched.step()
+        finals.append((float(elbo.detach()), m._flat_params.clone()))
+    assert abs(finals[0][0] - finals[1][0]) <= 1e-5 * abs(finals[0][0])
+    assert G.rel_err(finals[1][1].cpu().numpy(), finals[0][1].cpu().numpy()) < 1e-5
+
+
 def test_forward_is_deterministic_and_shape_checked():
     arch = A.fiducial_architecture(64)
     m, _ = _model(arch)
