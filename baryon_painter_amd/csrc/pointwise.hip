@@ -604,6 +604,37 @@ __global__ __launch_bounds__(RB) void loglik_backward_kernel(LoglikBwdArgs a) {
   }
 }
 
+// ---------------------------------------------------------------- device-side batch assembly
+// One descriptor per (sample, slab): where the tile starts in the HBM-resident stack and how the
+// dihedral tile permutation maps output (r,c) to source (row,col):  row = r0 + rr*r + rc*c, ...
+struct TileDesc {
+  const float* base;      // &stack[slice][tile_y*t][tile_x*t]
+  int32_t pitch;          // n_grid
+  int32_t r0, rr, rc, c0, cr, cc;
+  int32_t pad_;
+};
+struct SampleXform {      // x -> log(scale*x * inv_sigma + 1) * inv_k   (mode 1), or scale*x (mode 0)
+  double scale, inv_sigma, inv_k;
+  int32_t mode, pad_;
+};
+
+__global__ __launch_bounds__(RB) void gather_tiles_kernel(const TileDesc* d100, const TileDesc* d150,
+                                                          const SampleXform* xf, float* out, int t, int64_t total) {
+  const int64_t i = (int64_t)blockIdx.x * RB + threadIdx.x;
+  if (i >= total) return;
+  const int c = i % t;
+  const int r = (i / t) % t;
+  const int n = i / ((int64_t)t * t);
+  const TileDesc a = d100[n], b = d150[n];
+  const float va = a.base[(int64_t)(a.r0 + a.rr * r + a.rc * c) * a.pitch + (a.c0 + a.cr * r + a.cc * c)];
+  const float vb = b.base[(int64_t)(b.r0 + b.rr * r + b.rc * c) * b.pitch + (b.c0 + b.cr * r + b.cc * c)];
+  const float s = va + vb;                                   // float32 add, like the host path
+  const SampleXform x = xf[n];
+  double v = x.scale == 1.0 ? (double)s : (double)(float)(x.scale * (double)s);
+  if (x.mode == 1) v = log(v * x.inv_sigma + 1.0) * x.inv_k;
+  out[i] = (float)v;
+}
+
 // ---------------------------------------------------------------- Adam
 __global__ __launch_bounds__(RB) void adam_kernel(float* p, const float* g, float* m, float* v, int64_t n,
                                                   float lr, float b1, float b2, float eps, float bc1,
@@ -916,6 +947,17 @@ int bp_loglik_backward(const bp_loglik* ll, const float* x_nchw, const bp_view* 
   a.dmu = vd(d_mu_raw); a.dvar = vd(ll->predict_var ? d_var_raw : nullptr);
   a.total = (int64_t)ll->n * ll->L * ll->h * ll->w * ll->c;
   hipLaunchKernelGGL(loglik_backward_kernel, dim3(nblocks(a.total)), dim3(RB), 0, bp_stream(stream), a);
+  BP_CHECK_LAUNCH();
+  return BP_OK;
+}
+
+int bp_gather_tiles(const void* desc100, const void* desc150, const void* xform, int32_t n, int32_t tile,
+                    float* out_nchw, void* stream) {
+  if (!desc100 || !desc150 || !xform || n <= 0 || tile <= 0 || !out_nchw) return BP_EINVAL;
+  const int64_t total = (int64_t)n * tile * tile;
+  hipLaunchKernelGGL(gather_tiles_kernel, dim3(nblocks(total)), dim3(RB), 0, bp_stream(stream),
+                     reinterpret_cast<const TileDesc*>(desc100), reinterpret_cast<const TileDesc*>(desc150),
+                     reinterpret_cast<const SampleXform*>(xform), out_nchw, tile, total);
   BP_CHECK_LAUNCH();
   return BP_OK;
 }

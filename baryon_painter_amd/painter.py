@@ -67,7 +67,15 @@ class CVAEPainter(Painter):
     def _loader(self, batch_size):
         if self.sync is not None and self.sync.world_size > 1:
             return _ShardedLoader(self.training_data, batch_size, self.sync)
+        if getattr(self, "device_assembler", None) is not None:
+            return _DeviceLoader(self.device_assembler, len(self.training_data), batch_size)
         return torch.utils.data.DataLoader(self.training_data, batch_size=batch_size, shuffle=True)
+
+    def use_device_assembly(self, k_values, mode="shift-log"):
+        """Keep the training stacks in HBM and assemble batches with one gather launch per field
+        (utils.datasets.DeviceTileAssembler) instead of the host DataLoader; same shuffle order."""
+        self.device_assembler = datasets.DeviceTileAssembler(self.training_data, self.compute_device,
+                                                             k_values=k_values, mode=mode)
 
     def train(self, n_epoch=5, n_pepoch=None, learning_rate=1e-4, batch_size=1,
               adaptive_learning_rate=None, adaptive_batch_size=None,
@@ -319,6 +327,34 @@ class CVAEPainter(Painter):
             setattr(self, k, d[k])
         self.transform = d.get("transform")
         self.inverse_transform = d.get("inverse_transform")
+
+
+def dataloader_shuffle_order(n):
+    """The index order ``DataLoader(dataset, shuffle=True)`` would produce next, consuming the global
+    torch RNG the same way (iterator base seed first, then the RandomSampler's generator seed)."""
+    torch.empty((), dtype=torch.int64).random_()                       # _BaseDataLoaderIter._base_seed
+    seed = int(torch.empty((), dtype=torch.int64).random_().item())    # RandomSampler.__iter__
+    g = torch.Generator()
+    g.manual_seed(seed)
+    return torch.randperm(n, generator=g).tolist()
+
+
+class _DeviceLoader:
+    """Yields the same ``(fields, indices, redshifts)`` batches as the reference's DataLoader, in the
+    same shuffled order, with the tiles assembled on the GPU."""
+
+    def __init__(self, assembler, n, batch_size):
+        self.asm, self.n, self.batch_size = assembler, n, batch_size
+
+    def __iter__(self):
+        order = dataloader_shuffle_order(self.n)
+        for s in range(0, self.n, self.batch_size):
+            idx = order[s:s + self.batch_size]
+            x, y, z = self.asm.get_batch(idx)
+            yield [y, x], torch.tensor(idx), z
+
+    def __len__(self):
+        return (self.n + self.batch_size - 1) // self.batch_size
 
 
 class _ShardedLoader:

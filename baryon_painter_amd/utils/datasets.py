@@ -282,3 +282,92 @@ class SyntheticTileDataset(_TileDatasetBase):
             raise NotImplementedError("Only int indicies are supported for now.")
         dm, pr, z = self.raw_fields(int(idx))
         return [self.transform(dm, "dm", z), self.transform(pr, "pressure", z)], idx, z
+
+
+class DeviceTileAssembler:
+    """Batch assembly on the GPU for a ``BAHAMASDataset``: the stacks are uploaded to HBM once
+    (fiducial training set: 2 fields x 11 redshifts x 2 slabs x 14 x 2048^2 floats = 10 GB of the
+    288 GB) and every batch is one gather launch per field that reads the two tiles of each sample,
+    applies the tile permutation, adds them, scales and transforms them -- bit-for-bit the index
+    arithmetic of ``BAHAMASDataset.get_stack`` (computed on the host, integers only), so 8 GPUs are not
+    starved by a serial ``DataLoader(num_workers=0)`` (painter.py:88).  Supported transform: the
+    reference's "shift-log" range compression (plus identity)."""
+
+    REC100 = np.dtype([("base", np.int64), ("pitch", np.int32), ("r0", np.int32), ("rr", np.int32),
+                       ("rc", np.int32), ("c0", np.int32), ("cr", np.int32), ("cc", np.int32), ("pad", np.int32)])
+    XF = np.dtype([("scale", np.float64), ("inv_sigma", np.float64), ("inv_k", np.float64),
+                   ("mode", np.int32), ("pad", np.int32)])
+
+    def __init__(self, dataset, device="cuda:0", k_values=None, mode="shift-log"):
+        import torch
+        from .. import _lib as L
+        from . import data_transforms as T
+        self.ds, self.device, self.torch, self.L = dataset, torch.device(device), torch, L
+        self.lib = L.load()
+        if mode not in ("shift-log", None):
+            raise NotImplementedError("DeviceTileAssembler implements the 'shift-log' transform only")
+        self.mode = mode
+        self.k_values = k_values or {}
+        self._interp = T.interpolate_z
+        self.stacks = {}
+        for f in dataset.fields:
+            for z in dataset.redshifts:
+                for slab in ("100", "150"):
+                    a = np.ascontiguousarray(dataset.data[f][z][slab], dtype=np.float32)
+                    self.stacks[(f, z, slab)] = torch.from_numpy(a).to(self.device)
+
+    def _perm_affine(self, p):
+        """(r0, rr, rc, c0, cr, cc) of ``apply_tile_permutation`` for code p, from the images of three
+        index points under the very same NumPy operations."""
+        t = self.ds.tile_size
+        rows, cols = np.meshgrid(np.arange(t), np.arange(t), indexing="ij")
+        pr = self.ds.apply_tile_permutation(rows, p)
+        pc = self.ds.apply_tile_permutation(cols, p)
+        r0, c0 = int(pr[0, 0]), int(pc[0, 0])
+        return (r0, int(pr[1, 0]) - r0, int(pr[0, 1]) - r0, c0, int(pc[1, 0]) - c0, int(pc[0, 1]) - c0)
+
+    def _descriptors(self, field, indices):
+        ds, t = self.ds, self.ds.tile_size
+        d100 = np.zeros(len(indices), self.REC100)
+        d150 = np.zeros(len(indices), self.REC100)
+        xf = np.zeros(len(indices), self.XF)
+        for n, idx in enumerate(indices):
+            idx = int(idx)
+            z = ds.sample_idx_to_redshift(idx)
+            s100, y100, x100, s150, y150, x150 = ds.sample_idx_to_tile(idx)
+            p100, p150 = ds.sample_idx_to_tile_permutation(idx)
+            for rec, slab, s, ty, tx, p in ((d100, "100", s100, y100, x100, p100), (d150, "150", s150, y150, x150, p150)):
+                st = self.stacks[(field, z, slab)]
+                g = st.shape[-1]
+                rec[n]["base"] = st.data_ptr() + 4 * ((s * g + ty * t) * g + tx * t)
+                rec[n]["pitch"] = g
+                (rec[n]["r0"], rec[n]["rr"], rec[n]["rc"], rec[n]["c0"], rec[n]["cr"], rec[n]["cc"]) = self._perm_affine(p)
+            scale = slics_scale(ds.n_grid) if (field == ds.input_field and ds.scale_to_SLICS) else 1.0
+            xf[n]["scale"] = scale
+            if self.mode == "shift-log":
+                sig = np.sqrt(self._interp(ds.stats[field], z)["var"])
+                xf[n]["inv_sigma"] = 1.0 / sig
+                xf[n]["inv_k"] = 1.0 / float(self.k_values[field])
+                xf[n]["mode"] = 1
+        return d100, d150, xf
+
+    def get_batch(self, indices):
+        """-> (x = label field(s) (N,F,t,t), y = input field (N,1,t,t), aux = redshift (N,)) on the device."""
+        import ctypes as C
+        torch, L, ds, t = self.torch, self.L, self.ds, self.ds.tile_size
+        if ds.subtract_minimum:
+            raise NotImplementedError("subtract_minimum on the device path")
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        outs, keep = [], []
+        for field in [ds.input_field] + ds.label_fields:
+            d100, d150, xf = self._descriptors(field, indices)
+            dev = [torch.from_numpy(a.view(np.uint8)).to(self.device) for a in (d100, d150, xf)]
+            keep.append(dev)
+            out = torch.empty((len(indices), 1, t, t), device=self.device)
+            L.check(self.lib.bp_gather_tiles(L.ptr(dev[0]), L.ptr(dev[1]), L.ptr(dev[2]), len(indices), t,
+                                             L.ptr(out), st), "gather tiles")
+            outs.append(out)
+        torch.cuda.current_stream().synchronize()        # descriptors may be freed after this
+        z = torch.tensor([ds.sample_idx_to_redshift(int(i)) for i in indices], device=self.device,
+                         dtype=torch.float32)
+        return torch.cat(outs[1:], dim=1), outs[0], z

@@ -210,6 +210,15 @@ int bp_loglik_backward(const bp_loglik* ll, const float* x_nchw, const bp_view* 
                        const bp_view* var_raw, const float* seed, const bp_view* d_mu_raw,
                        const bp_view* d_var_raw, void* stream);
 
+/* ---- device-side batch assembly (replaces BAHAMASDataset.get_stack + transform on the host,
+ *      utils/datasets.py:305-404): the stacks live in HBM, one launch builds a field of a batch.
+ * desc100/desc150: n records {const float* base; int32 pitch; int32 r0,rr,rc,c0,cr,cc; int32 pad}
+ *   (source row = r0 + rr*r + rc*c, col = c0 + cr*r + cc*c: the dihedral tile permutation);
+ * xform: n records {double scale, inv_sigma, inv_k; int32 mode; int32 pad}, mode 1 = shift-log.
+ * out: (n,1,tile,tile) float32 = transform(scale * (tile100 + tile150)). */
+int bp_gather_tiles(const void* desc100, const void* desc150, const void* xform, int32_t n,
+                    int32_t tile, float* out_nchw, void* stream);
+
 /* ---- optimiser (replaces torch.optim.Adam.step, painter.py:93,228; same arithmetic) --------- */
 int bp_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                  float lr, float beta1, float beta2, float eps, int32_t step, void* stream);

@@ -157,3 +157,39 @@ def test_graphed_paint_matches_eager_statistics():
     with pytest.raises(RuntimeError):
         m.train(True)
         m.sample_P_graphed(yt, aux_label=at)
+
+
+def test_device_tile_assembler_matches_host_dataset():
+    """GPU batch assembly == BAHAMASDataset[idx] (index arithmetic bit-exact; transform to 1 ulp)."""
+    from baryon_painter_amd.utils import data_transforms as T
+    rng = np.random.default_rng(3)
+    data = {}
+    for field, amp in (("dm", 5.0e3), ("pressure", 0.05)):
+        data[field] = {}
+        for z in (0.0, 0.5, 1.0):
+            data[field][z] = {"100": (rng.random((5, 64, 64), dtype=np.float32) * amp),
+                              "150": (rng.random((5, 64, 64), dtype=np.float32) * amp),
+                              "mean_100": 0.5 * amp, "mean_150": 0.5 * amp,
+                              "var_100": amp * amp / 12, "var_150": amp * amp / 12}
+    fwd, inv = T.create_range_compress_transforms({"dm": 4.0, "pressure": 4}, {"dm": "shift-log", "pressure": "shift-log"})
+    tr = T.chain_transformations([fwd, T.atleast_3d, T.as_float32])
+    for fixed in (False, True):
+        ds = D.BAHAMASDataset(data=data, redshifts=[0.0, 0.5, 1.0], label_fields=["pressure"], n_stack=4,
+                              stack_offset=1, n_tile=4, tile_permutations=True, transform=tr,
+                              inverse_transform=T.chain_transformations([T.squeeze, inv]), fixed_indexing=fixed)
+        asm = D.DeviceTileAssembler(ds, "cuda:0", k_values={"dm": 4.0, "pressure": 4})
+        idx = [0, 5, 70, ds.n_sample - 1, ds.n_sample + 3, 2 * ds.n_sample + 12345, len(ds) - 1] + \
+              [int(i) for i in rng.integers(0, len(ds), 9)]
+        x, y, z = asm.get_batch(idx)
+        for n, i in enumerate(idx):
+            (dm, pr), _, zz = ds[i]
+            assert float(z[n]) == np.float32(zz)
+            for got, ref in ((y[n].cpu().numpy(), dm), (x[n].cpu().numpy(), pr)):
+                assert got.shape == ref.shape
+                ulp = np.abs(got - ref).max() / np.spacing(np.abs(ref).max())
+                assert ulp <= 1.0, (i, ulp)
+    raw = D.DeviceTileAssembler(D.BAHAMASDataset(data=data, redshifts=[0.0], label_fields=["pressure"], n_stack=4,
+                                                 tile_permutations=True, scale_to_SLICS=False), "cuda:0", mode=None)
+    ds0 = raw.ds
+    x, y, z = raw.get_batch([3, 200000])
+    assert np.array_equal(y[1, 0].cpu().numpy(), ds0[200000][0][0])          # bit-exact without transform

@@ -214,3 +214,19 @@ def test_lightcone_tiling_known_answers():
         get_tile(m, (0, 0), 0.5, expansion_factor=0.5)
     w = make_weight_map((100, 100), falloff=0.05, sigma=0.5)
     assert w[50, 50] == 1.0 and w[0, 50] == pytest.approx(np.exp(-0.5 * 25 / 6.25)) and np.allclose(w, w.T)
+
+
+def test_device_loader_reproduces_dataloader_shuffle():
+    import torch
+    from baryon_painter_amd.painter import dataloader_shuffle_order
+
+    class DS(torch.utils.data.Dataset):
+        def __len__(self):
+            return 37
+
+        def __getitem__(self, i):
+            return i
+    torch.manual_seed(5)
+    ref = [int(v) for b in torch.utils.data.DataLoader(DS(), batch_size=4, shuffle=True) for v in b]
+    torch.manual_seed(5)
+    assert dataloader_shuffle_order(37) == ref
