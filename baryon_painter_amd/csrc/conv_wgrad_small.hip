@@ -31,15 +31,19 @@ struct WsArgs {
   int xvec, yvec;
 };
 
-template <int K, int CXS, int CYS, int BH>
+template <int K, int S, int CXS, int CYS, int BH>
 struct WsCfg {
   static constexpr int TPM = 16 / CXS, TPN = 16 / CYS;
-  static constexpr int GX = (K + TPM - 1) / TPM, GY = (K + TPN - 1) / TPN;
-  static constexpr int TPNe = TPN < K ? TPN : K;
+  static constexpr int GX = (K + TPM - 1) / TPM;
+  // y-taps: ky = gy + S*(h*TPN + tpy): residue gy (0..S-1), TPN shifted rows per MFMA column set, H sets
+  static constexpr int KS = (K + S - 1) / S;               // taps per residue
+  static constexpr int H = (KS + TPN - 1) / TPN;
+  static constexpr int GY = S * H;
+  static constexpr int TPNe = TPN < KS ? TPN : KS;
   static constexpr int RS = BH + TPNe - 1;                 // k-step rows per tile
-  static constexpr int XR = RS + (GY - 1) * TPN;           // X rows staged
-  static constexpr int XW = 32 + GX * TPM - 1;             // X columns staged
-  static constexpr int XWS = XW + 3;                       // (+3: the 4-pixel k-step of the last group)
+  static constexpr int XR = S * (RS - 1) + (S - 1) + S * (H - 1) * TPN + 1;   // X rows staged
+  static constexpr int XW = S * 31 + GX * TPM;             // X columns staged
+  static constexpr int XWS = XW + 3 * S;                   // slack for the discarded lanes of the last group
   static constexpr int PADR = TPN - 1;                     // zero rows above the Y tile
   static constexpr int YR = PADR + BH + TPNe - 1;
   static constexpr int YWS = 34;                           // row pitch: keeps the shifted B reads conflict-free
@@ -49,10 +53,10 @@ struct WsCfg {
   static constexpr size_t LDS = LDS_MAIN > LDS_RED ? LDS_MAIN : LDS_RED;
 };
 
-template <int K, int CXS, int CYS, int BH>
+template <int K, int S, int CXS, int CYS, int BH>
 __global__ __launch_bounds__(256) void wgrad_small_kernel(WsArgs a) {
-  using C = WsCfg<K, CXS, CYS, BH>;
-  constexpr int TPM = C::TPM, TPN = C::TPN, GX = C::GX, GY = C::GY, RS = C::RS, XR = C::XR, XW = C::XW;
+  using C = WsCfg<K, S, CXS, CYS, BH>;
+  constexpr int TPM = C::TPM, TPN = C::TPN, GX = C::GX, GY = C::GY, RS = C::RS, XR = C::XR, XW = C::XW, H = C::H;
   constexpr int XWS = C::XWS, PADR = C::PADR, YWS = C::YWS;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* xs = smem;
@@ -73,7 +77,7 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(WsArgs a) {
   // zero the whole Y image once: the pad rows stay zero, the interior is rewritten per tile
   for (int e = tid; e < C::YF; e += 256) ys[e] = 0.f;
 
-  const int a_lane = kq * CXS + li;                                 // (4 pixels) x (16 consecutive floats)
+  const int a_lane = kq * S * CXS + li;                             // (4 pixels, S apart) x (16 consecutive floats)
   const int b_lane = (kq - (li / CYS) * YWS) * CYS + (li % CYS);    // column (tpy, cy): row shifted up by tpy
 
   const PW4 px4 = pw4_load(a.pwx, (tid % (CXS >= 4 ? CXS / 4 : 1)) * 4, a.cx);
@@ -95,7 +99,7 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(WsArgs a) {
         for (int e = tid; e < XR * XW * C4; e += 256) {
           const int pix = e / C4;
           const int c = pix % XW, r = pix / XW;
-          const int iy = qy0 - a.pad + r, ix = qx0 - a.pad + c;
+          const int iy = S * qy0 - a.pad + r, ix = S * qx0 - a.pad + c;
           float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
           if (ch < a.cx && iy >= 0 && iy < a.xh && ix >= 0 && ix < a.xw) {
             v = *reinterpret_cast<const float4*>(Xn + ((int64_t)iy * a.xw + ix) * a.xcs + ch);
@@ -111,7 +115,7 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(WsArgs a) {
           const int ch = e % CXS;
           const int pix = e / CXS;
           const int c = pix % XW, r = pix / XW;
-          const int iy = qy0 - a.pad + r, ix = qx0 - a.pad + c;
+          const int iy = S * qy0 - a.pad + r, ix = S * qx0 - a.pad + c;
           float v = 0.f;
           if (ch < a.cx && iy >= 0 && iy < a.xh && ix >= 0 && ix < a.xw)
             v = pw_apply(a.pwx, ch, Xn[((int64_t)iy * a.xw + ix) * a.xcs + ch]);
@@ -120,8 +124,8 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(WsArgs a) {
       }
       // the 3 slack columns of each row are only read by k-steps whose outputs are discarded,
       // but must hold finite numbers
-      for (int e = tid; e < XR * 3 * CXS; e += 256) {
-        const int ch = e % CXS, c = XW + (e / CXS) % 3, r = e / (3 * CXS);
+      for (int e = tid; e < XR * 3 * S * CXS; e += 256) {
+        const int ch = e % CXS, c = XW + (e / CXS) % (3 * S), r = e / (3 * S * CXS);
         xs[(r * XWS + c) * CXS + ch] = 0.f;
       }
     }
@@ -163,12 +167,13 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(WsArgs a) {
     for (int s = wk; s < RS * 8; s += 4) {
       const int r = s >> 3, g = s & 7;
       const float bf = ys[((PADR + r) * YWS + 4 * g) * CYS + b_lane];
-      const float* xp = xs + (r * XWS + 4 * g) * CXS + a_lane;
+      const float* xp = xs + (S * r * XWS + S * 4 * g) * CXS + a_lane;
 #pragma unroll
       for (int gy = 0; gy < GY; ++gy)
 #pragma unroll
         for (int gx = 0; gx < GX; ++gx) {
-          const float af = xp[(gy * TPN * XWS + gx * TPM) * CXS];
+          // group gy = (residue gy % S, set gy / S): X row offset = residue + S*set*TPN
+          const float af = xp[(((gy % S) + S * (gy / S) * TPN) * XWS + gx * TPM) * CXS];
           acc[gy][gx] = __builtin_amdgcn_mfma_f32_16x16x4f32(af, bf, acc[gy][gx], 0, 0, 0);
         }
     }
@@ -190,17 +195,17 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(WsArgs a) {
                            red[(2 * 64 + l) * 4 + rr]) + red[(3 * 64 + l) * 4 + rr];
         const int i = 4 * (l >> 4) + rr, j = l & 15;
         const int kx = gx * TPM + i / CXS, cxi = i % CXS;
-        const int ky = gy * TPN + j / CYS, cyi = j % CYS;
+        const int ky = (gy % S) + S * ((gy / S) * TPN + j / CYS), cyi = j % CYS;
         if (kx < K && ky < K)
           a.ws[((((int64_t)split * K + ky) * K + kx) * CYS + cyi) * CXS + cxi] = sum;
       }
     }
 }
 
-template <int K, int CXS, int CYS, int BH>
+template <int K, int S, int CXS, int CYS, int BH>
 int launch(const bp_view* X, const PW& pwx, const bp_view* Y, const PW& pwy, int pad, float* ws, size_t ws_bytes,
            size_t* need, int* nsplit, int* cxp, int* cyp, hipStream_t st, bool dry) {
-  using C = WsCfg<K, CXS, CYS, BH>;
+  using C = WsCfg<K, S, CXS, CYS, BH>;
   static_assert(C::LDS <= 64 * 1024, "LDS budget");
   WsArgs a{};
   a.X = X->ptr; a.xh = X->h; a.xw = X->w; a.xcs = X->cstride; a.xco = X->coff; a.cx = X->c;
@@ -217,7 +222,7 @@ int launch(const bp_view* X, const PW& pwx, const bp_view* Y, const PW& pwy, int
   if (!ws || ws_bytes < *need) return BP_EWORKSPACE;
   a.xvec = (X->cstride % 4 == 0 && X->coff % 4 == 0 && reinterpret_cast<uintptr_t>(X->ptr) % 16 == 0) ? 1 : 0;
   a.yvec = (Y->cstride % 4 == 0 && Y->coff % 4 == 0 && reinterpret_cast<uintptr_t>(Y->ptr) % 16 == 0) ? 1 : 0;
-  hipLaunchKernelGGL((wgrad_small_kernel<K, CXS, CYS, BH>), dim3((unsigned)a.nsplit), dim3(256), C::LDS, st, a);
+  hipLaunchKernelGGL((wgrad_small_kernel<K, S, CXS, CYS, BH>), dim3((unsigned)a.nsplit), dim3(256), C::LDS, st, a);
   BP_CHECK_LAUNCH();
   return BP_OK;
 }
@@ -226,26 +231,33 @@ int pow2_at_least(int c) { return c <= 1 ? 1 : (c <= 2 ? 2 : (c <= 4 ? 4 : (c <=
 
 }  // namespace
 
-// BP_EUNSUPPORTED unless: unit stride, both channel counts <= 16, at least one < 16, k in {3,5,7}.
+// BP_EUNSUPPORTED unless both channel counts are <= 16, at least one is < 16 and (k, stride, padded
+// channel counts) has an instantiation below.
 int bp_wgrad_small(const bp_conv* cv, const bp_view* X, const PW& pwx, const bp_view* Y, const PW& pwy, float* ws,
                    size_t ws_bytes, size_t* need, int* nsplit, int* cxp, int* cyp, hipStream_t st, bool dry) {
-  if (cv->stride != 1 || X->c > 16 || Y->c > 16 || (X->c == 16 && Y->c == 16)) return BP_EUNSUPPORTED;
+  if (X->c > 16 || Y->c > 16 || (X->c == 16 && Y->c == 16)) return BP_EUNSUPPORTED;
   const int cxs = pow2_at_least(X->c), cys = pow2_at_least(Y->c);
-#define BP_WS(K_, CX_, CY_, BH_) \
-  if (cv->k == K_ && cxs == CX_ && cys == CY_) \
-    return launch<K_, CX_, CY_, BH_>(X, pwx, Y, pwy, cv->pad, ws, ws_bytes, need, nsplit, cxp, cyp, st, dry)
-  BP_WS(7, 16, 8, 8);
-  BP_WS(5, 4, 16, 8);
-  BP_WS(5, 8, 1, 16);
-  BP_WS(3, 1, 1, 16);
-  BP_WS(5, 16, 8, 8);
-  BP_WS(3, 16, 8, 8);
-  BP_WS(3, 8, 16, 8);
-  BP_WS(3, 4, 16, 8);
-  BP_WS(3, 8, 8, 8);
-  BP_WS(5, 8, 8, 8);
-  BP_WS(5, 1, 1, 16);
-  BP_WS(7, 1, 1, 16);
+#define BP_WS(K_, S_, CX_, CY_, BH_) \
+  if (cv->k == K_ && cv->stride == S_ && cxs == CX_ && cys == CY_) \
+    return launch<K_, S_, CX_, CY_, BH_>(X, pwx, Y, pwy, cv->pad, ws, ws_bytes, need, nsplit, cxp, cyp, st, dry)
+  BP_WS(7, 1, 16, 8, 8);
+  BP_WS(5, 1, 4, 16, 8);
+  BP_WS(5, 1, 8, 1, 16);
+  BP_WS(3, 1, 1, 1, 16);
+  BP_WS(5, 1, 16, 8, 8);
+  BP_WS(3, 1, 16, 8, 8);
+  BP_WS(3, 1, 8, 16, 8);
+  BP_WS(3, 1, 4, 16, 8);
+  BP_WS(3, 1, 8, 8, 8);
+  BP_WS(5, 1, 8, 8, 8);
+  BP_WS(5, 1, 1, 1, 16);
+  BP_WS(7, 1, 1, 1, 16);
+  // strided ends of the encoders / the latent up-sampler
+  BP_WS(4, 2, 1, 8, 8);
+  BP_WS(4, 2, 2, 8, 8);
+  BP_WS(4, 2, 1, 1, 16);
+  BP_WS(8, 4, 8, 16, 2);
+  BP_WS(8, 4, 1, 1, 8);
 #undef BP_WS
   return BP_EUNSUPPORTED;
 }

@@ -36,8 +36,8 @@ def kernel_name(kind, unit, lib):
     if kind == "backward_weight":
         cv = unit.cv
         cx, cy = (cv.cout, cv.cin) if cv.transposed else (cv.cin, cv.cout)
-        if cv.stride == 1 and cx <= 16 and cy <= 16 and not (cx == 16 and cy == 16) and cv.k in (3, 5, 7):
-            return "wgrad_small_kernel[k%d %d->%d]" % (cv.k, cx, cy)
+        if cx <= 16 and cy <= 16 and not (cx == 16 and cy == 16) and (cv.k, cv.stride) in ((3, 1), (5, 1), (7, 1), (4, 2), (8, 4)):
+            return "wgrad_small_kernel[k%ds%d %d,%d]" % (cv.k, cv.stride, cx, cy)
         return "wgrad_tiles_kernel[k%ds%d %s]" % (cv.k, cv.stride, "wide" if (cx > 16 and cy > 16) else "thin")
     kid = lib.bp_conv_kernel_id(C.byref(unit.cv), L.PACK_FWD if kind == "forward" else L.PACK_BWD)
     return "igemm_kernel<%d,%d,%d,%d>" % (kid // 1000, kid // 100 % 10, kid // 10 % 10, kid % 10)
