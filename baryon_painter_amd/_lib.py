@@ -76,6 +76,11 @@ SIGNATURES = {
     "bp_loglik_workspace": (C.c_size_t, [C.POINTER(Loglik)]),
     "bp_loglik_forward": (C.c_int, [C.POINTER(Loglik), _P, _VP, _VP, _P, _P, _P, _P, _P, C.c_size_t, _P]),
     "bp_loglik_backward": (C.c_int, [C.POINTER(Loglik), _P, _VP, _VP, _P, _VP, _VP, _P]),
+    "bp_unary_forward": (C.c_int, [_VP, _PWP, C.c_int32, _VP, _P]),
+    "bp_bce_logits": (C.c_int, [_VP, C.c_int32, C.c_int32, C.c_float, _P, _P, C.c_size_t, _P]),
+    "bp_bce_logits_grad": (C.c_int, [_VP, C.c_int32, C.c_int32, C.c_float, C.c_float, _VP, _P]),
+    "bp_l1_sum": (C.c_int, [_VP, _P, _P, _P, C.c_size_t, _P]),
+    "bp_tanh_l1_backward": (C.c_int, [_VP, _P, _VP, C.c_float, _VP, _P]),
     "bp_gather_tiles": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, _P, _P]),
     "bp_adam_step": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float,
                                C.c_int32, _P]),

@@ -604,6 +604,89 @@ __global__ __launch_bounds__(RB) void loglik_backward_kernel(LoglikBwdArgs a) {
   }
 }
 
+// ---------------------------------------------------------------- GAN heads (CGAN rows g1-g5 of SURVEY.md 8a)
+// out = tanh(act(in)) or sigmoid(act(in)), view -> view (e.g. the generator's Tanh output written
+// straight into the pressure channel of the discriminator's input concatenation).
+__global__ __launch_bounds__(RB) void unary_forward_kernel(ViewD in, PW pw, int kind, ViewD out, int64_t total) {
+  const int64_t i = (int64_t)blockIdx.x * RB + threadIdx.x;
+  if (i >= total) return;
+  const int c = in.c;
+  const int ch = i % c;
+  const int64_t p = i / c;
+  const float v = pw_apply(pw, ch, in.p[p * in.cs + in.co + ch]);
+  out.p[p * out.cs + out.co + ch] = kind == 1 ? tanhf(v) : (kind == 2 ? 1.f / (1.f + expf(-v)) : v);
+}
+
+// Binary cross entropy on logits: target 1 -> softplus(-x), target 0 -> softplus(x); partial sums.
+__global__ __launch_bounds__(RB) void bce_logits_kernel(ViewD raw, int n0, int n1, float target, double* partial) {
+  __shared__ double sh[RB];
+  const int64_t per = (int64_t)raw.h * raw.w * raw.c;
+  const int64_t total = (int64_t)(n1 - n0) * per;
+  double acc = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * RB + threadIdx.x; i < total; i += (int64_t)gridDim.x * RB) {
+    const int ch = i % raw.c;
+    const int64_t p = (int64_t)n0 * raw.h * raw.w + i / raw.c;
+    const float x = raw.p[p * raw.cs + raw.co + ch];
+    const float z = target > 0.5f ? -x : x;
+    acc += (double)(z > 20.f ? z : log1pf(expf(z)));
+  }
+  sh[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = RB / 2; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial[blockIdx.x] = sh[0];
+}
+
+// d/dx of scale * BCE: scale * (sigmoid(x) - target), samples [n0, n1) of the view.
+__global__ __launch_bounds__(RB) void bce_logits_grad_kernel(ViewD raw, int n0, int n1, float target, float scale,
+                                                             ViewD d) {
+  const int64_t per = (int64_t)raw.h * raw.w * raw.c;
+  const int64_t i = (int64_t)blockIdx.x * RB + threadIdx.x;
+  if (i >= (int64_t)(n1 - n0) * per) return;
+  const int ch = i % raw.c;
+  const int64_t p = (int64_t)n0 * raw.h * raw.w + i / raw.c;
+  const float x = raw.p[p * raw.cs + raw.co + ch];
+  d.p[p * d.cs + d.co + ch] = scale * (1.f / (1.f + expf(-x)) - target);
+}
+
+// L1 distance between fake (a view) and the real field (NCHW): partial sums of |fake - x|.
+__global__ __launch_bounds__(RB) void l1_kernel(ViewD fake, const float* x, double* partial) {
+  __shared__ double sh[RB];
+  const int c = fake.c;
+  const int64_t hw = (int64_t)fake.h * fake.w, total = fake.npix * c;
+  double acc = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * RB + threadIdx.x; i < total; i += (int64_t)gridDim.x * RB) {
+    const int ch = i % c;
+    const int64_t p = i / c, n = p / hw, yx = p % hw;
+    acc += fabs((double)fake.p[p * fake.cs + fake.co + ch] - (double)x[(n * c + ch) * hw + yx]);
+  }
+  sh[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = RB / 2; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial[blockIdx.x] = sh[0];
+}
+
+// d_graw = (d_fake + l1_scale * sign(fake - x)) * (1 - fake^2)     (through the Tanh output layer)
+__global__ __launch_bounds__(RB) void tanh_l1_backward_kernel(ViewD fake, const float* x, ViewD dfake, float l1_scale,
+                                                              ViewD d, int64_t total) {
+  const int64_t i = (int64_t)blockIdx.x * RB + threadIdx.x;
+  if (i >= total) return;
+  const int c = fake.c;
+  const int ch = i % c;
+  const int64_t hw = (int64_t)fake.h * fake.w;
+  const int64_t p = i / c, n = p / hw, yx = p % hw;
+  const float f = fake.p[p * fake.cs + fake.co + ch];
+  const float diff = f - x[(n * c + ch) * hw + yx];
+  float g = dfake.p ? dfake.p[p * dfake.cs + dfake.co + ch] : 0.f;
+  g += l1_scale * (diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f));
+  d.p[p * d.cs + d.co + ch] = g * (1.f - f * f);
+}
+
 // ---------------------------------------------------------------- device-side batch assembly
 // One descriptor per (sample, slab): where the tile starts in the HBM-resident stack and how the
 // dihedral tile permutation maps output (r,c) to source (row,col):  row = r0 + rr*r + rc*c, ...
@@ -947,6 +1030,64 @@ int bp_loglik_backward(const bp_loglik* ll, const float* x_nchw, const bp_view* 
   a.dmu = vd(d_mu_raw); a.dvar = vd(ll->predict_var ? d_var_raw : nullptr);
   a.total = (int64_t)ll->n * ll->L * ll->h * ll->w * ll->c;
   hipLaunchKernelGGL(loglik_backward_kernel, dim3(nblocks(a.total)), dim3(RB), 0, bp_stream(stream), a);
+  BP_CHECK_LAUNCH();
+  return BP_OK;
+}
+
+int bp_unary_forward(const bp_view* in, const bp_pointwise* pw, int32_t kind, const bp_view* out, void* stream) {
+  if (!bp_view_ok(in) || !bp_view_ok(out) || !same_grid(in, out) || kind < 0 || kind > 2) return BP_EINVAL;
+  const int64_t total = bp_view_pixels(in) * in->c;
+  hipLaunchKernelGGL(unary_forward_kernel, dim3(nblocks(total)), dim3(RB), 0, bp_stream(stream), vd(in), bp_pw(pw),
+                     kind, vd(out), total);
+  BP_CHECK_LAUNCH();
+  return BP_OK;
+}
+
+int bp_bce_logits(const bp_view* raw, int32_t n0, int32_t n1, float target, double* sum, void* workspace,
+                  size_t workspace_bytes, void* stream) {
+  if (!bp_view_ok(raw) || n0 < 0 || n1 > raw->n || n0 >= n1 || !sum) return BP_EINVAL;
+  const int nblk = 256;
+  if (!workspace || workspace_bytes < nblk * sizeof(double)) return BP_EWORKSPACE;
+  hipStream_t st = bp_stream(stream);
+  hipLaunchKernelGGL(bce_logits_kernel, dim3(nblk), dim3(RB), 0, st, vd(raw), n0, n1, target,
+                     reinterpret_cast<double*>(workspace));
+  BP_CHECK_LAUNCH();
+  hipLaunchKernelGGL(sum_partials_wave_kernel, dim3(1), dim3(64), 0, st, reinterpret_cast<double*>(workspace), nblk, 1, sum);
+  BP_CHECK_LAUNCH();
+  return BP_OK;
+}
+
+int bp_bce_logits_grad(const bp_view* raw, int32_t n0, int32_t n1, float target, float scale, const bp_view* d_raw,
+                       void* stream) {
+  if (!bp_view_ok(raw) || !bp_view_ok(d_raw) || !same_grid(raw, d_raw) || n0 < 0 || n1 > raw->n || n0 >= n1)
+    return BP_EINVAL;
+  const int64_t total = (int64_t)(n1 - n0) * raw->h * raw->w * raw->c;
+  hipLaunchKernelGGL(bce_logits_grad_kernel, dim3(nblocks(total)), dim3(RB), 0, bp_stream(stream), vd(raw), n0, n1,
+                     target, scale, vd(d_raw));
+  BP_CHECK_LAUNCH();
+  return BP_OK;
+}
+
+int bp_l1_sum(const bp_view* fake, const float* x_nchw, double* sum, void* workspace, size_t workspace_bytes,
+              void* stream) {
+  if (!bp_view_ok(fake) || !x_nchw || !sum) return BP_EINVAL;
+  const int nblk = 256;
+  if (!workspace || workspace_bytes < nblk * sizeof(double)) return BP_EWORKSPACE;
+  hipStream_t st = bp_stream(stream);
+  hipLaunchKernelGGL(l1_kernel, dim3(nblk), dim3(RB), 0, st, vd(fake), x_nchw, reinterpret_cast<double*>(workspace));
+  BP_CHECK_LAUNCH();
+  hipLaunchKernelGGL(sum_partials_wave_kernel, dim3(1), dim3(64), 0, st, reinterpret_cast<double*>(workspace), nblk, 1, sum);
+  BP_CHECK_LAUNCH();
+  return BP_OK;
+}
+
+int bp_tanh_l1_backward(const bp_view* fake, const float* x_nchw, const bp_view* d_fake, float l1_scale,
+                        const bp_view* d_raw, void* stream) {
+  if (!bp_view_ok(fake) || !x_nchw || !bp_view_ok(d_raw) || !same_grid(fake, d_raw)) return BP_EINVAL;
+  if (d_fake && (!bp_view_ok(d_fake) || !same_grid(fake, d_fake))) return BP_EINVAL;
+  const int64_t total = bp_view_pixels(fake) * fake->c;
+  hipLaunchKernelGGL(tanh_l1_backward_kernel, dim3(nblocks(total)), dim3(RB), 0, bp_stream(stream), vd(fake), x_nchw,
+                     vd(d_fake), l1_scale, vd(d_raw), total);
   BP_CHECK_LAUNCH();
   return BP_OK;
 }

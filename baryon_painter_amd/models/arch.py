@@ -124,3 +124,41 @@ def fiducial_architecture(tile_size=512, predict_var=False, n_res=4):
         "L": 1,
     }
     return arch
+
+
+# ----------------------------------------------------------------------------------- CGAN
+# The reference repository documents its CGAN but holds no code for it (SURVEY.md key fact 2):
+# the layer tables below restate trained_models/README.md:106-128 and the pickled generator
+# structure (rows g1, g2 of SURVEY.md 8a) in the same architecture language.
+def leaky_res_block(n_channel, slope=0.2):
+    """``res_block`` with LeakyReLU instead of ReLU (generator's residual blocks, README.md:121)."""
+    body, _ = res_block(n_channel)
+    body[2] = ("Leaky ReLU", slope)
+    return (body, ("Leaky ReLU", slope))
+
+
+def cgan_generator_architecture(n_res=9, slope=0.2):
+    """``resnet_translator``: k9 stem, two stride-2 encoders, n_res residual blocks, two
+    transposed-conv decoders (output_padding 1), k9 head + Tanh."""
+    def cbl(kind, cin, cout, k, s, p, bias, **extra):
+        cfg = {"in_channels": cin, "out_channels": cout, "kernel_size": k, "padding": p, "stride": s, "bias": bias}
+        cfg.update(extra)
+        return [(kind, cfg), ("batchnorm", {"num_features": cout}), ("Leaky ReLU", slope)]
+    layers = cbl("conv", 2, 32, 9, 1, 4, False) + cbl("conv", 32, 64, 3, 2, 1, True) + cbl("conv", 64, 128, 3, 2, 1, True)
+    layers += [("residual block", leaky_res_block(128, slope)) for _ in range(n_res)]
+    layers += cbl("transp conv", 128, 64, 3, 2, 1, True, output_padding=1)
+    layers += cbl("transp conv", 64, 32, 3, 2, 1, True, output_padding=1)
+    layers += [("conv", {"in_channels": 32, "out_channels": 1, "kernel_size": 9, "padding": 4, "stride": 1,
+                         "bias": True}), ("tanh",)]
+    return layers
+
+
+def cgan_discriminator_architecture(slope=0.2):
+    """pix2pix-style PatchGAN with spectral normalisation on every layer, no batch-norm
+    (README.md:101,106-114); padding 1 assumed (unspecified in the reference)."""
+    def sn(cin, cout, s, bias):
+        return ("sn conv", {"in_channels": cin, "out_channels": cout, "kernel_size": 4, "padding": 1, "stride": s,
+                            "bias": bias})
+    return [sn(3, 64, 2, True), ("Leaky ReLU", slope), sn(64, 128, 2, True), ("Leaky ReLU", slope),
+            sn(128, 256, 2, False), ("Leaky ReLU", slope), sn(256, 512, 1, True), ("Leaky ReLU", slope),
+            sn(512, 1, 1, True), ("sigmoid",)]

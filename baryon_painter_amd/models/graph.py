@@ -51,6 +51,43 @@ class ParamLinear(_NoForward, torch.nn.Linear):
     pass
 
 
+class SNConv2d(_NoForward, torch.nn.Conv2d):
+    """Conv2d under spectral normalisation (``torch.nn.utils.spectral_norm`` semantics: parameter
+    ``weight_orig``, buffers ``weight_u`` / ``weight_v``, one power iteration per training forward,
+    ``weight = weight_orig / sigma``).  The power iteration and the chain rule through sigma are a few
+    mat-vecs on the weight matrix -- parameter-side glue, done with torch ops; the convolution itself
+    reads the normalised ``weight`` through the HIP kernels."""
+
+    def __init__(self, **config):
+        super().__init__(**config)
+        w = self.weight.data
+        del self.weight
+        self.weight_orig = torch.nn.Parameter(w)
+        self.register_buffer("weight", w.clone())
+        co = w.shape[0]
+        self.register_buffer("weight_u", torch.nn.functional.normalize(torch.randn(co), dim=0, eps=1e-12))
+        self.register_buffer("weight_v", torch.nn.functional.normalize(torch.randn(w[0].numel()), dim=0, eps=1e-12))
+        self.register_buffer("weight_grad", torch.zeros_like(w), persistent=False)
+        self.sigma = None
+
+    @torch.no_grad()
+    def refresh(self, training):
+        wm = self.weight_orig.reshape(self.weight_orig.shape[0], -1)
+        if training:
+            self.weight_v.copy_(torch.nn.functional.normalize(torch.mv(wm.t(), self.weight_u), dim=0, eps=1e-12))
+            self.weight_u.copy_(torch.nn.functional.normalize(torch.mv(wm, self.weight_v), dim=0, eps=1e-12))
+        self.sigma = torch.dot(self.weight_u, torch.mv(wm, self.weight_v))
+        self.weight.copy_(self.weight_orig / self.sigma)
+
+    @torch.no_grad()
+    def finish_backward(self):
+        """d/d weight_orig from d/d weight (u, v constant):  (G - <G, W> u v^T) / sigma."""
+        g = self.weight_grad
+        inner = (g * self.weight).sum()
+        uv = torch.outer(self.weight_u, self.weight_v).view_as(g)
+        self.weight_orig.grad = (g - inner * uv) / self.sigma
+
+
 class Marker(_NoForward, torch.nn.Module):
     """Parameter-free layer; keeps the reference's module indices in state_dict keys."""
 
@@ -96,6 +133,8 @@ def build_holders(architecture):
         name = name.lower()
         if name == "conv":
             mods.append(ParamConv2d(**config))
+        elif name == "sn conv":                      # extension: spectrally normalised conv (CGAN discriminator)
+            mods.append(SNConv2d(**config))
         elif name == "transp conv":
             mods.append(ParamConvTranspose2d(**config))
         elif name == "linear":
@@ -426,14 +465,14 @@ def compile_sequential(plan, prefix, architecture, holders, inp, out_slot=None, 
         name = layer[0].lower()
         layers.append((name, layer[1] if len(layer) == 2 else None))
     # index of the last conv-like layer (its output may go to a concat slot)
-    conv_like = [i for i, (n, _) in enumerate(layers) if n in ("conv", "transp conv", "residual block")]
+    conv_like = [i for i, (n, _) in enumerate(layers) if n in ("conv", "sn conv", "transp conv", "residual block")]
     last_conv = conv_like[-1] if conv_like else -1
     cur = inp
     i = 0
     first = True
     while i < len(layers):
         name, cfg = layers[i]
-        if name in ("conv", "transp conv"):
+        if name in ("conv", "sn conv", "transp conv"):
             holder = holders[i]
             j = i + 1
             bn = act = act_arg = act_holder = None
@@ -478,10 +517,10 @@ def probe_output(architecture, c, h, w):
     """(c,h,w) produced by a layer list, without building anything."""
     for layer in architecture or []:
         name = layer[0].lower()
-        if name in ("conv", "transp conv"):
+        if name in ("conv", "sn conv", "transp conv"):
             cfg = layer[1]
             k, st, pd = cfg["kernel_size"], cfg.get("stride", 1), cfg.get("padding", 0)
-            if name == "conv":
+            if name in ("conv", "sn conv"):
                 h, w = (h + 2 * pd - k) // st + 1, (w + 2 * pd - k) // st + 1
             else:
                 op = cfg.get("output_padding", 0)

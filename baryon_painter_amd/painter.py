@@ -433,3 +433,85 @@ class TrainingStats:
                 out += "\n"
                 in_row = 0
         return out
+
+
+class CGANPainter(Painter):
+    """Painter around the conditional GAN (models/cgan.py) with the ``paint`` keywords of the
+    reference's external ``GAN_Painter`` (scripts/create_lightcone.py:47-54,
+    process_SLICS.py:170-172).  Field transform: the reference's CGAN used a "shift-log-cam" map into
+    the tanh range (trained_models/CGAN/fiducial/transform.pickle: log(x/sigma+1)/k0 - k1 with
+    k = [4, 1]); it is applied here on top of the dataset's statistics."""
+
+    K = (4.0, 1.0)
+
+    def __init__(self, training_data_set=None, tile_size=512, compute_device="cuda:0", n_res=9, filename=None):
+        from .models.cgan import CGAN
+        self.compute_device = compute_device
+        self.model = CGAN(tile_size=tile_size, device=compute_device, n_res=n_res)
+        self.training_data = training_data_set
+        self.stats = None if training_data_set is None else training_data_set.stats
+        self.input_field, self.label_fields = "dm", ["pressure"]
+        if filename is not None:
+            self.load_state_from_file(filename, compute_device)
+
+    # ---- the CGAN's own field transform
+    def _sigma(self, field, z):
+        from .utils.data_transforms import interpolate_z
+        return float(np.sqrt(interpolate_z(self.stats[field], z)["var"]))
+
+    def transform(self, x, field, z):
+        return (np.log(np.asarray(x, np.float64) / self._sigma(field, z) + 1) / self.K[0] - self.K[1]).astype(np.float32)
+
+    def inverse_transform(self, y, field, z):
+        return (np.exp((np.asarray(y, np.float64) + self.K[1]) * self.K[0]) - 1) * self._sigma(field, z)
+
+    def train(self, n_iter=1000, batch_size=6, learning_rate=5e-5, lr_decay=0.85, lr_decay_every=1568, verbose=False):
+        """Alternating D / G iterations (README.md:97,130-139): Adam(betas=(0.5, 0.999)), lr x0.85 every
+        1568 iterations, batch 6.  Returns the list of loss dicts."""
+        if self.training_data is None:
+            raise RuntimeError("Trying to train but no training data specified.")
+        m = self.model
+        m.train(True)
+        opt_g = torch.optim.Adam(m.g_parameters(), lr=learning_rate, betas=(0.5, 0.999))
+        opt_d = torch.optim.Adam(m.d_parameters(), lr=learning_rate, betas=(0.5, 0.999))
+        sched = [torch.optim.lr_scheduler.StepLR(o, step_size=lr_decay_every, gamma=lr_decay) for o in (opt_g, opt_d)]
+        ds, log = self.training_data, []
+        rng = np.random.default_rng(0)
+        for it in range(n_iter):
+            idx = rng.integers(0, len(ds), batch_size)
+            dm, pr, zs = [], [], []
+            for i in idx:
+                d, p, z = ds.raw_fields(int(i)) if hasattr(ds, "raw_fields") else self._raw(ds, int(i))
+                dm.append(self.transform(d, "dm", z)[None])
+                pr.append(self.transform(p, "pressure", z)[None])
+                zs.append(z)
+            losses = m.train_step(torch.from_numpy(np.stack(pr)), torch.from_numpy(np.stack(dm)),
+                                  torch.tensor(zs, dtype=torch.float32), opt_g, opt_d)
+            for s in sched:
+                s.step()
+            log.append({k: float(v) for k, v in losses.items()})
+            if verbose and it % 50 == 0:
+                print(it, log[-1])
+        return log
+
+    @staticmethod
+    def _raw(ds, i):
+        z = ds.sample_idx_to_redshift(i)
+        return ds.get_input_sample(i, transform=False), ds.get_label_sample(i, transform=False)[0], z
+
+    def paint(self, input, z=0.0, transform=True, inverse_transform=True):
+        self.model.train(False)
+        y = self.transform(input, "dm", z) if transform else np.asarray(input, np.float32)
+        t = self.model.tile_size
+        if y.shape != (t, t):
+            raise ValueError(f"Shape mismatch between input and model: {np.shape(input)} vs {(1, t, t)}")
+        pred = self.model.generate(torch.from_numpy(y.reshape(1, 1, t, t)), torch.tensor([z])).cpu().numpy()
+        if inverse_transform:
+            return self.inverse_transform(pred[0, 0], "pressure", z)
+        return pred
+
+    def save_state_to_file(self, filename):
+        torch.save({k: v.detach().cpu() for k, v in self.model.state_dict().items()}, filename)
+
+    def load_state_from_file(self, filename, compute_device="cuda:0"):
+        self.model.load_state_dict(torch.load(filename, map_location=torch.device(compute_device)))

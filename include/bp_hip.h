@@ -210,6 +210,22 @@ int bp_loglik_backward(const bp_loglik* ll, const float* x_nchw, const bp_view* 
                        const bp_view* var_raw, const float* seed, const bp_view* d_mu_raw,
                        const bp_view* d_var_raw, void* stream);
 
+/* ---- GAN heads (the CGAN of trained_models/README.md:95-144; no code in the reference) ------ */
+/* out = f(act(in)), kind 0 identity, 1 tanh (generator output, README.md:128), 2 sigmoid. */
+int bp_unary_forward(const bp_view* in, const bp_pointwise* pw, int32_t kind, const bp_view* out,
+                     void* stream);
+/* sum over samples [n0,n1) of BCE(sigmoid(raw), target) evaluated on the logits; and its gradient
+ * d_raw = scale * (sigmoid(raw) - target) for those samples. */
+int bp_bce_logits(const bp_view* raw, int32_t n0, int32_t n1, float target, double* sum,
+                  void* workspace, size_t workspace_bytes, void* stream);
+int bp_bce_logits_grad(const bp_view* raw, int32_t n0, int32_t n1, float target, float scale,
+                       const bp_view* d_raw, void* stream);
+/* sum |fake - x| ; d_raw = (d_fake + l1_scale*sign(fake - x)) * (1 - fake^2) through the Tanh. */
+int bp_l1_sum(const bp_view* fake, const float* x_nchw, double* sum, void* workspace,
+              size_t workspace_bytes, void* stream);
+int bp_tanh_l1_backward(const bp_view* fake, const float* x_nchw, const bp_view* d_fake,
+                        float l1_scale, const bp_view* d_raw, void* stream);
+
 /* ---- device-side batch assembly (replaces BAHAMASDataset.get_stack + transform on the host,
  *      utils/datasets.py:305-404): the stacks live in HBM, one launch builds a field of a batch.
  * desc100/desc150: n records {const float* base; int32 pitch; int32 r0,rr,rc,c0,cr,cc; int32 pad}
