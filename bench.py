@@ -84,6 +84,42 @@ def cpu_baseline(arch, seconds_budget=20.0):
                       f"oracle/torch_ref.py (torch.nn.functional on CPU), median {med:.3f} s/step"}
 
 
+def bench_cgan(args, dev, world, rank):
+    """BASELINE.json configs[2]: CGAN fiducial, alternating discriminator / generator iteration."""
+    import contextlib
+    from baryon_painter_amd.models.cgan import CGAN
+    from baryon_painter_amd.utils import synthetic as syn
+    if world > 1:
+        raise SystemExit("the CGAN leg is single-GPU in this round")
+    torch.manual_seed(1234)
+    with contextlib.redirect_stdout(sys.stderr):
+        model = CGAN(tile_size=args.tile, device=dev)
+    n = args.batch
+    nb = min(n, 8)
+    x, y, z = syn.synthetic_batch(nb, args.tile, args.tile, seed=1234)
+    reps = (n + nb - 1) // nb
+    x = torch.from_numpy(np.tanh(3 * np.tile(x, (reps, 1, 1, 1))[:n] - 0.5).astype(np.float32)).to(dev)
+    y = torch.from_numpy(np.tile(y, (reps, 1, 1, 1))[:n]).to(dev)
+    z = torch.from_numpy(np.tile(z, reps)[:n]).to(dev)
+    opt_g = torch.optim.Adam(model.g_parameters(), lr=5e-5, betas=(0.5, 0.999))
+    opt_d = torch.optim.Adam(model.d_parameters(), lr=5e-5, betas=(0.5, 0.999))
+    for _ in range(args.warmup):
+        model.train_step(x, y, z, opt_g, opt_d)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        losses = model.train_step(x, y, z, opt_g, opt_d)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print(json.dumps({
+        "metric": "cgan_train_tiles_per_sec", "value": round(n * args.steps / dt, 2), "unit": "tiles/s", "n_gpus": 1,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"CGAN fiducial alternating D+G iteration, batch {n} of {args.tile}x{args.tile} tiles, fp32 "
+                               "(BASELINE.json configs[2]); parity vs own restatement only (no reference code)",
+                   "losses": {k: float(v) for k, v in losses.items()}}}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -96,6 +132,8 @@ def main():
     ap.add_argument("--layers", action="store_true", help="also print a per-layer table to stderr")
     ap.add_argument("--no-paint", action="store_true", help="skip the paint() throughput leg")
     ap.add_argument("--torch-adam", action="store_true", help="torch.optim.Adam instead of the fused FlatAdam")
+    ap.add_argument("--workload", choices=["cvae", "cgan"], default="cvae",
+                    help="cvae: BASELINE.json configs[1] (the headline); cgan: configs[2] (alternating D/G step)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -118,6 +156,9 @@ def main():
     from baryon_painter_amd.models import arch as A
     from baryon_painter_amd.models.cvae import CVAE
     from baryon_painter_amd.utils import synthetic as syn
+
+    if args.workload == "cgan":
+        return bench_cgan(args, dev, world, rank)
 
     arch = A.fiducial_architecture(args.tile)
     torch.manual_seed(1234)                      # same initial weights on every rank
