@@ -143,13 +143,19 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if args.gpus > 1 and world == 1:
         raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    if os.environ.get("BP_DIST_BACKEND", "nccl") != "nccl":
+        local_rank = 0                                             # rehearsal: all ranks share GPU 0
     torch.cuda.set_device(local_rank)
     dev = f"cuda:{local_rank}"
     sync = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev))
+        backend = os.environ.get("BP_DIST_BACKEND", "nccl")       # "gloo" only to rehearse on a one-GPU box
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
         from baryon_painter_amd.dist import Sync
         sync = Sync(sync_bn=not args.local_bn)
 
