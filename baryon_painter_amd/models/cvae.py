@@ -319,7 +319,7 @@ class _ELBOFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, plan, x, y, aux, eps, *params):
         plan.forward_train(x, y, aux, eps, training=model.training)
-        ctx.model, ctx.plan = model, plan
+        ctx.model, ctx.plan, ctx.was_training = model, plan, model.training
         return plan.stats[0].clone()
 
     @staticmethod
@@ -327,6 +327,9 @@ class _ELBOFunction(torch.autograd.Function):
         model, plan = ctx.model, ctx.plan
         if not plan.with_grad:
             raise RuntimeError("this forward was run without gradient buffers")
+        if not ctx.was_training:
+            raise RuntimeError("backward through an eval-mode forward (batch-norm on running statistics) is not "
+                               "implemented; the reference never does it (painter.py:85,372)")
         flat = model._flat_grads
         plan.backward(grad_out.detach().to(torch.float32), model._grad_views_by_id)
         if model.sync is not None:

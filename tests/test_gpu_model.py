@@ -187,3 +187,37 @@ def test_forward_is_deterministic_and_shape_checked():
         m(torch.from_numpy(x[:, :, :32]), torch.from_numpy(y), torch.from_numpy(aux))
     with pytest.raises(ValueError):
         m(torch.from_numpy(x), torch.from_numpy(y), torch.from_numpy(aux[:1]))
+
+
+@pytest.mark.parametrize("n,L,train", [(1, 1, True), (5, 1, True), (2, 2, True), (3, 1, False)])
+def test_batch_sizes_L_and_eval_mode_against_oracle(n, L, train):
+    """Shapes the fixtures do not cover (batch 1, odd batch, L = 2 samples per datum, eval-mode
+    forward) against the float64 NumPy oracle."""
+    arch = A.fiducial_architecture(64)
+    arch["L"] = L
+    m, P = _model(arch)
+    ora = CVAEOracle(arch, dtype=np.float64)
+    ora.load_params(P)
+    x, y, aux = syn.synthetic_batch(n, 64, 64, seed=40 + n)
+    eps = syn.synthetic_eps((L, n, *arch["dim_z"]), seed=41)
+    if not train:      # give the running statistics non-trivial values first (one train-mode forward each)
+        m._eps_override = eps
+        with torch.no_grad():
+            m(torch.from_numpy(x), torch.from_numpy(y), torch.from_numpy(aux))
+        ora.forward(x, y, aux, eps)
+    m.train(train)
+    ora.training = train
+    m._eps_override = eps
+    elbo = m(torch.from_numpy(x), torch.from_numpy(y), torch.from_numpy(aux))
+    ora.forward(x, y, aux, eps)
+    got, ref = np.array(m.get_stats()), np.array(ora.get_stats())
+    assert np.abs(got - ref).max() <= 2e-5 * np.abs(ref).max(), (got, ref)
+    assert G.rel_err(m.x_mu.cpu().numpy(), ora.x_mu) < 1e-4
+    if not train:
+        with pytest.raises(RuntimeError, match="eval-mode"):
+            (-elbo).backward()
+        return
+    (-elbo).backward()
+    g = ora.backward(seed=-1.0)
+    errs = sorted(((G.rel_err(p.grad.cpu().numpy(), g[k]), k) for k, p in m.named_parameters()), reverse=True)
+    assert errs[0][0] < 5e-3, errs[:4]
