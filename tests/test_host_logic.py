@@ -175,7 +175,7 @@ mean = st[:5] / n
 var = st[5:] / n - mean ** 2
 assert torch.allclose(mean, full.mean(dim=(0, 2, 3))) and torch.allclose(var, full.var(dim=(0, 2, 3), unbiased=False))
 dist.destroy_process_group()
-print("rank", r, "ok")
+open(os.path.join(sys.argv[2], f"rank{r}.ok"), "w").write("ok")      # stdout of the ranks interleaves
 """
 
 
@@ -188,10 +188,10 @@ def test_sync_collectives_over_gloo(tmp_path):
         port = sk.getsockname()[1]
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-                          "--master-addr", "127.0.0.1", "--master-port", str(port), str(script), ROOT],
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), str(script), ROOT, str(tmp_path)],
                          capture_output=True, text=True, env=env, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
-    assert "rank 0 ok" in out.stdout and "rank 1 ok" in out.stdout
+    assert (tmp_path / "rank0.ok").exists() and (tmp_path / "rank1.ok").exists()
 
 
 def test_lightcone_tiling_known_answers():
