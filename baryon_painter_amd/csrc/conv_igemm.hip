@@ -14,6 +14,7 @@
 // Lane l supplies k-slice (l>>4): it reads CC/4 consecutive channels (b32/b64/b128) of its pixel
 // (A) and of its produced channel (B) and issues CC/4 MFMAs from them.
 #include "common.hpp"
+#include <cstdlib>
 
 namespace {
 
@@ -30,6 +31,8 @@ struct IgemmArgs {
   int nchunk, cout_padP;
   int IH, IW, IWq;
   int vec_ok;
+  int out_vec;   // 16-byte stores allowed
+  int in_pad4;   // DMA variant: float4 groups per input buffer, padded to whole 1-KiB pieces
 };
 
 template <int VW> struct Frag;
@@ -50,8 +53,49 @@ __device__ __forceinline__ void lds_read(const float* p, float (&v)[VW]) {
   }
 }
 
+template <int NT, int MT>
+__device__ __forceinline__ void igemm_store(const IgemmArgs& a, const v4f (&acc)[MT][NT], float* out_n, int wm, int wn,
+                                            int lm, int kq, int co0, int qy0, int qx0, int qh, int qw, int py,
+                                            int px) {
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int t = wm * MT + mt;
+    const int tr = t / a.TPR, tc = t % a.TPR;
+    const int qy = qy0 + tr;
+    const int qx = qx0 + tc * 16 + lm;
+    const int Y = py + a.OS * qy;
+    if (qy >= qh || qx >= qw) continue;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int j0 = co0 + (wn * NT + nt) * 16 + kq * 4;
+      if (a.PP == 1) {
+        const int X = px + a.OS * qx;
+        float* o = out_n + ((int64_t)Y * a.out_w + X) * a.out_cs + j0;
+        if (a.out_vec && j0 + 3 < a.cout) {
+          float4 v = make_float4(acc[mt][nt][0], acc[mt][nt][1], acc[mt][nt][2], acc[mt][nt][3]);
+          if (a.bias) { v.x += a.bias[j0]; v.y += a.bias[j0 + 1]; v.z += a.bias[j0 + 2]; v.w += a.bias[j0 + 3]; }
+          *reinterpret_cast<float4*>(o) = v;
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (j0 + r < a.cout) o[r] = acc[mt][nt][r] + (a.bias ? a.bias[j0 + r] : 0.f);
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int j = j0 + r;
+          const int co = j % a.COP, pp = j / a.COP;
+          const int X = a.PP * qx + pp;
+          if (X < a.out_w && co < a.cout)
+            out_n[((int64_t)Y * a.out_w + X) * a.out_cs + co] = acc[mt][nt][r] + (a.bias ? a.bias[co] : 0.f);
+        }
+      }
+    }
+  }
+}
+
 template <int CC, int NT, int WN, int MT>
-__global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
+__global__ __launch_bounds__(256, (MT == 4 && NT == 4) ? 4 : 1) void igemm_kernel(IgemmArgs a) {
   constexpr int VW = CC / 4;
   constexpr int WM = 4 / WN;
   constexpr int COB = 16 * NT * WN;
@@ -109,36 +153,71 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
   const float* in_n = a.in + (int64_t)n * a.in_h * a.in_w * a.in_cs + a.in_co;
   const int in_elems4 = a.IH * a.IW * VW;  // float4 groups per chunk
 
+  // Staging slots of this thread: the (row, column) of each halo element it copies is the same for every
+  // channel chunk, so the global offset (or -1 outside the image) and the LDS offset are computed once.
+  constexpr int SLOTS = NT == 4 ? 3 : (NT == 2 ? 8 : 1);   // NT 1: few channels, occupancy matters more
+  constexpr int SG = SLOTS < 4 ? SLOTS : 4;                // loads in flight per thread
+  const int c4 = tid % VW;                                 // 256 % VW == 0: fixed channel quad per thread
+  const bool slots_ok = NT > 1 && in_elems4 <= SLOTS * 256;
+  int s_g[SLOTS], s_l[SLOTS];
+#pragma unroll
+  for (int i = 0; i < SLOTS; ++i) {
+    const int e = tid + i * 256;
+    s_g[i] = -1; s_l[i] = -1;
+    if (slots_ok && e < in_elems4) {
+      const int pix = e / VW;
+      const int c = pix % a.IW;
+      const int r = pix / a.IW;
+      const int iy = gy0 + r, ix = gx0 + c;
+      s_l[i] = ((r * a.ISx + c % a.ISx) * a.IWq + c / a.ISx) * CC + c4 * 4;
+      if (iy >= 0 && iy < a.in_h && ix >= 0 && ix < a.in_w) s_g[i] = (iy * a.in_w + ix) * a.in_cs;
+    }
+  }
+
   for (int chunk = 0; chunk < a.nchunk; ++chunk) {
     __syncthreads();  // previous chunk's readers are done with lds_in / lds_w
     // ---- stage the input halo tile for channels [chunk*CC, chunk*CC+CC)
     {
-      const int c4 = tid % VW;                   // 256 % VW == 0: fixed channel quad per thread
       const int ch = chunk * CC + c4 * 4;
       const PW4 p4 = pw4_load(a.pw, ch, a.cin);
-      for (int e = tid; e < in_elems4; e += 256) {
-        const int pix = e / VW;
-        const int c = pix % a.IW;
-        const int r = pix / a.IW;
-        const int iy = gy0 + r, ix = gx0 + c;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (iy >= 0 && iy < a.in_h && ix >= 0 && ix < a.in_w && ch < a.cin) {
-          const float* p = in_n + ((int64_t)iy * a.in_w + ix) * a.in_cs + ch;
-          if (a.vec_ok) {
-            v = *reinterpret_cast<const float4*>(p);
-          } else {
-            v.x = p[0];
-            if (ch + 1 < a.cin) v.y = p[1];
-            if (ch + 2 < a.cin) v.z = p[2];
-            if (ch + 3 < a.cin) v.w = p[3];
-          }
-          v = pw4_apply4(p4, v);
-          if (ch + 1 >= a.cin) v.y = 0.f;
-          if (ch + 2 >= a.cin) v.z = 0.f;
-          if (ch + 3 >= a.cin) v.w = 0.f;
+      if (slots_ok && a.vec_ok && ch + 3 < a.cin) {
+#pragma unroll
+        for (int i0 = 0; i0 < SLOTS; i0 += SG) {
+          float4 v[SG];
+#pragma unroll
+          for (int i = 0; i < SG; ++i)
+            if (s_g[i0 + i] >= 0) v[i] = *reinterpret_cast<const float4*>(in_n + s_g[i0 + i] + ch);
+#pragma unroll
+          for (int i = 0; i < SG; ++i)
+            if (s_l[i0 + i] >= 0)
+              *reinterpret_cast<float4*>(lds_in + s_l[i0 + i]) =
+                  s_g[i0 + i] >= 0 ? pw4_apply4(p4, v[i]) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        const int li = ((r * a.ISx + c % a.ISx) * a.IWq + c / a.ISx) * CC + c4 * 4;
-        *reinterpret_cast<float4*>(lds_in + li) = v;
+      } else {
+        for (int e = tid; e < in_elems4; e += 256) {
+          const int pix = e / VW;
+          const int c = pix % a.IW;
+          const int r = pix / a.IW;
+          const int iy = gy0 + r, ix = gx0 + c;
+          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (iy >= 0 && iy < a.in_h && ix >= 0 && ix < a.in_w && ch < a.cin) {
+            const float* p = in_n + ((int64_t)iy * a.in_w + ix) * a.in_cs + ch;
+            if (a.vec_ok) {
+              v = *reinterpret_cast<const float4*>(p);
+            } else {
+              v.x = p[0];
+              if (ch + 1 < a.cin) v.y = p[1];
+              if (ch + 2 < a.cin) v.z = p[2];
+              if (ch + 3 < a.cin) v.w = p[3];
+            }
+            v = pw4_apply4(p4, v);
+            if (ch + 1 >= a.cin) v.y = 0.f;
+            if (ch + 2 >= a.cin) v.z = 0.f;
+            if (ch + 3 >= a.cin) v.w = 0.f;
+          }
+          const int li = ((r * a.ISx + c % a.ISx) * a.IWq + c / a.ISx) * CC + c4 * 4;
+          *reinterpret_cast<float4*>(lds_in + li) = v;
+        }
       }
     }
     for (int ty = 0; ty < a.tapsy; ++ty) {
@@ -168,34 +247,188 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
           for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
-              acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mt][s], bf[nt][s], acc[mt][nt], 0, 0, 0);
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[nt][s], af[mt][s], acc[mt][nt], 0, 0, 0);
       }
     }
   }
 
-  // ---- epilogue: D[row = 4*(lane>>4)+r (pixel or pixel group)][col = lane&15 (channel, or (pp,channel))]
+  // ---- epilogue.  The MFMA is issued as D = W^T-tile x X-tile, so D[row = 4*(lane>>4)+r][col = lane&15] holds
+  // produced channel (or (pp, channel)) `row` of pixel (or pixel group) `col`: a lane owns 4 consecutive
+  // channels of one pixel, which is one 16-byte store in NHWC.
   float* out_n = a.out + (int64_t)n * a.out_h * a.out_w * a.out_cs + a.out_co;
+  igemm_store<NT, MT>(a, acc, out_n, wm, wn, lm, kq, co0, qy0, qx0, qh, qw, py, px);
+}
+
+// ------------------------------------------------------------------------------------------------
+// The same contraction with both operands brought in by LDS-DMA (global_load_lds_dwordx4: no staging
+// registers, no ds_write) one step ahead of their use:
+//   * weights: one tap slab [COB][CC] per step into a 2-deep ring; the slab of step s+1 is issued right
+//     after the barrier that opens step s, so it has the whole of step s's MFMAs to land;
+//   * input halo tile: the tile of chunk c+1 is issued at the first tap of chunk c into the other of two
+//     buffers.  A DMA cannot apply the pending activation or the zero padding, so in the last tap of
+//     chunk c every thread rewrites in place exactly the elements its own lanes fetched (they were
+//     retired by the vmcnt(0) of an earlier barrier; nobody reads that buffer before the next barrier).
+// One barrier per tap; its vmcnt(0) retires this wave's DMAs, the barrier publishes them.
+// LDS image of the input is the one of igemm_kernel, enumerated in LDS order so that the 64 lanes of a
+// wave-instruction land on 1 KiB of consecutive LDS (destination = wave-uniform base + lane * 16).
+typedef __attribute__((address_space(3))) void* lds_vp;
+typedef const __attribute__((address_space(1))) void* glb_vp;
+__device__ __forceinline__ void glds16(const float* g, float* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((glb_vp)g, (lds_vp)lds_wave_base, 16, 0, 0);
+}
+
+template <int CC, int NT, int WN, int SLOTS, int NW>
+__global__ __launch_bounds__(64 * NW, NT == 4 ? ((SLOTS == 3 && WN == 2) ? 4 : 3) : 2) void igemm_dma_kernel(IgemmArgs a) {
+  constexpr int MT = 4;
+  constexpr int VW = CC / 4;
+  constexpr int WM = NW / WN;
+  constexpr int NTH = 64 * NW;
+  constexpr int COB = 16 * NT * WN;
+  constexpr int SLAB = COB * CC;          // floats per tap slab
+  constexpr int SLAB_I = SLAB / 256;      // 1-KiB pieces per slab
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int in_f = a.in_pad4 * 4;
+  float* lds_w = smem + 2 * in_f;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int lm = lane & 15, kq = lane >> 4;
+
+  const int tile = blockIdx.x;
+  const int tile_x = tile % a.tiles_x, tile_y = tile / a.tiles_x;
+  const int co0 = blockIdx.y * COB;
+  const int ph = blockIdx.z % (a.nphase * a.nphase);
+  const int n = blockIdx.z / (a.nphase * a.nphase);
+  const int py = ph / a.nphase, px = ph % a.nphase;
+
+  const int BW = 16 * a.TPR;
+  const int qy0 = tile_y * a.BH, qx0 = tile_x * BW;
+  const int qh = (a.out_h - py + a.OS - 1) / a.OS;
+  const int qw = (a.out_w - px + a.OS - 1) / a.OS;
+  if (qy0 >= qh || qx0 >= qw) return;  // uniform per block
+
+  int iy0, ix0;
+  if (a.transposed) {
+    iy0 = bp_t_i0(py, a.pad, a.stride, a.tapsy);
+    ix0 = bp_t_i0(px, a.pad, a.stride, a.tapsy);
+  } else {
+    iy0 = -a.pad; ix0 = -a.pad;
+  }
+  const int gy0 = a.ISy * qy0 + iy0, gx0 = a.ISx * qx0 + ix0;
+
+  int abase[MT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     const int t = wm * MT + mt;
     const int tr = t / a.TPR, tc = t % a.TPR;
-    const int qy = qy0 + tr;
-    const int Y = py + a.OS * qy;
+    abase[mt] = (tr * a.ISy * a.ISx * a.IWq + tc * 16 + lm) * CC + kq * VW;
+  }
+  int bbase[NT];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      const int j = co0 + (wn * NT + nt) * 16 + lm;
-      const int co = a.PP > 1 ? j % a.COP : j;
-      const int pp = a.PP > 1 ? j / a.COP : 0;
-      const float b = (a.bias && co < a.cout) ? a.bias[co] : 0.f;
+  for (int nt = 0; nt < NT; ++nt) bbase[nt] = ((wn * NT + nt) * 16 + lm) * CC + kq * VW;
+
+  v4f acc[MT][NT];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int qx = qx0 + tc * 16 + kq * 4 + r;
-        const int X = a.PP > 1 ? a.PP * qx + pp : px + a.OS * qx;
-        if (qy < qh && qx < qw && X < a.out_w && co < a.cout)
-          out_n[((int64_t)Y * a.out_w + X) * a.out_cs + co] = acc[mt][nt][r] + b;
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = v4f{0.f, 0.f, 0.f, 0.f};
+
+  const float* in_n = a.in + (int64_t)n * a.in_h * a.in_w * a.in_cs + a.in_co;
+  const int E = a.IH * a.ISx * a.IWq * VW;   // float4 groups of the LDS image
+
+  // This thread's elements of the image: e = i * NTH + tid (LDS order).  Source offset with the
+  // coordinates clamped into the image (every lane of a DMA fetches something; what lies outside is
+  // zeroed by the rewrite), and one bit per slot for "outside".
+  const int c4 = tid % VW;
+  int s_g[SLOTS];
+  unsigned outside = 0;
+#pragma unroll
+  for (int i = 0; i < SLOTS; ++i) {
+    const int e = i * NTH + tid;
+    const int p = e / VW;
+    const int xq = p % a.IWq;
+    const int t = p / a.IWq;
+    const int xm = t % a.ISx;
+    const int r = t / a.ISx;
+    const int c = xq * a.ISx + xm;
+    const int iy = gy0 + r, ix = gx0 + c;
+    const bool in = e < E && c < a.IW && iy >= 0 && iy < a.in_h && ix >= 0 && ix < a.in_w;
+    if (!in) outside |= 1u << i;
+    const int cy = min(max(iy, 0), a.in_h - 1), cx = min(max(ix, 0), a.in_w - 1);
+    s_g[i] = (cy * a.in_w + cx) * a.in_cs + c4 * 4;
+  }
+
+  auto issue_input = [&](int chunk, int buf) {
+#pragma unroll
+    for (int i = 0; i < SLOTS; ++i) {
+      const int ebase = i * NTH + wave * 64;   // wave-uniform
+      if (ebase < a.in_pad4) glds16(in_n + s_g[i] + chunk * CC, smem + buf * in_f + ebase * 4);
+    }
+  };
+  auto rewrite_input = [&](int chunk, int buf) {
+    const PW4 p4 = pw4_load(a.pw, chunk * CC + c4 * 4, a.cin);
+#pragma unroll
+    for (int i = 0; i < SLOTS; ++i) {
+      const int e = i * NTH + tid;
+      if (e < E) {
+        float4* q = reinterpret_cast<float4*>(smem + buf * in_f + e * 4);
+        if ((outside >> i) & 1u) *q = make_float4(0.f, 0.f, 0.f, 0.f);
+        else if (p4.on) *q = pw4_apply4(p4, *q);
+      }
+    }
+  };
+  auto issue_slab = [&](int chunk, int ty, int tx, int slot) {
+    const float* src = a.wp + ((((int64_t)(ph * a.tapsy + ty) * a.tapsx + tx) * a.nchunk + chunk) *
+                                   a.cout_padP + co0) * CC;
+    for (int k = wave; k < SLAB_I; k += NW) glds16(src + (k * 64 + lane) * 4, lds_w + slot * SLAB + k * 256);
+  };
+
+  // prologue: first input tile and first slab
+  issue_input(0, 0);
+  issue_slab(0, 0, 0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  rewrite_input(0, 0);
+
+  int step = 0;
+  for (int chunk = 0; chunk < a.nchunk; ++chunk) {
+    const float* lin = smem + (chunk & 1) * in_f;
+    for (int ty = 0; ty < a.tapsy; ++ty) {
+      for (int tx = 0; tx < a.tapsx; ++tx, ++step) {
+        __syncthreads();   // vmcnt(0) + barrier: slab `step` (and a pending input tile) landed; step-1 is read out
+        {
+          int ntx = tx + 1, nty = ty, nch = chunk;
+          if (ntx == a.tapsx) { ntx = 0; ++nty; }
+          if (nty == a.tapsy) { nty = 0; ++nch; }
+          if (nch < a.nchunk) issue_slab(nch, nty, ntx, (step + 1) & 1);
+        }
+        const bool first = (ty == 0 && tx == 0), last = (ty == a.tapsy - 1 && tx == a.tapsx - 1);
+        if (first && chunk + 1 < a.nchunk) issue_input(chunk + 1, (chunk + 1) & 1);
+
+        const float* lw = lds_w + (step & 1) * SLAB;
+        const int tapoff = ((ty * a.ISx + tx % a.ISx) * a.IWq + tx / a.ISx) * CC;
+        float af[MT][VW], bf[NT][VW];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) lds_read<VW>(lin + abase[mt] + tapoff, af[mt]);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) lds_read<VW>(lw + bbase[nt], bf[nt]);
+#pragma unroll
+        for (int s = 0; s < VW; ++s)
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[nt][s], af[mt][s], acc[mt][nt], 0, 0, 0);
+
+        // the next chunk's tile was retired by an earlier barrier's vmcnt(0) (taps >= 2): activation + padding
+        if (last && chunk + 1 < a.nchunk) rewrite_input(chunk + 1, (chunk + 1) & 1);
       }
     }
   }
+
+  float* out_n = a.out + (int64_t)n * a.out_h * a.out_w * a.out_cs + a.out_co;
+  igemm_store<NT, MT>(a, acc, out_n, wm, wn, lm, kq, co0, qy0, qx0, qh, qw, py, px);
 }
 
 // weights: torch layout -> [phase][ty][tx][chunk][cout_padP][CC]
@@ -238,11 +471,33 @@ __global__ __launch_bounds__(256) void pack_kernel(PackArgs a) {
   a.dst[i] = v;
 }
 
+// Spatial tile of one workgroup and the halo it gathers.
+struct TileGeom {
+  int TPR, BH, IH, IW, IWq;
+};
+static TileGeom tile_geom(int TM, int IS, int ISx, int taps, int tapsx) {
+  TileGeom t{};
+  t.TPR = (TM >= 16) ? 2 : 1;
+  t.BH = TM / t.TPR;
+  const int BW = 16 * t.TPR;
+  t.IH = (t.BH - 1) * IS + taps;
+  t.IW = (BW - 1) * ISx + tapsx;
+  t.IWq = bp_ceil_div(t.IW, ISx);
+  return t;
+}
+
 struct IgemmConfig {
-  int CC, NT, WN, MT, TPR, BH, COB, nchunk, cout_padP, IH, IW, IWq;
+  int CC, NT, WN, MT, COB, nchunk, cout_padP;
+  TileGeom t;
   int PP, COP, tapsx, ISx;
   size_t lds_bytes;
   bool ok;
+  // LDS-DMA variant (igemm_dma_kernel), taken when the view is 16-byte addressable at run time; it shares
+  // CC (hence the packed weight image) with the plain kernel above, which stays the fallback.
+  bool dma;
+  int NW, in_pad4, slots;
+  TileGeom td;
+  size_t lds_dma;
 };
 
 IgemmConfig igemm_config(const ConvGeom& g) {
@@ -265,18 +520,42 @@ IgemmConfig igemm_config(const ConvGeom& g) {
   }
   const int cin4 = bp_round_up(g.cin_g, 4);
   const int cc_first = cin4 >= 16 ? 16 : (cin4 >= 8 ? 8 : 4);
+  auto plain_lds = [&](const TileGeom& t, int CC) {
+    return ((size_t)t.IH * c.ISx * t.IWq * CC + (size_t)c.tapsx * c.COB * CC) * sizeof(float);
+  };
+  // First choice: the DMA-pipelined kernel (MT 4).  Eight waves per workgroup where the produced-channel
+  // block is 128 wide (each weight slab then serves 256 pixels), else four; the chunk width that keeps at
+  // least two (eight waves) or three (four waves) workgroups per CU.
+  static const bool no_dma = getenv("BP_IGEMM_NODMA") != nullptr;
+  static const bool no_nw8 = getenv("BP_IGEMM_NONW8") != nullptr;
+  if (c.PP == 1 && g.taps * c.tapsx >= 2 && !no_dma) {
+    for (int NW = (c.NT == 4 && c.WN == 2 && !no_nw8) ? 8 : 4; NW >= 4 && !c.dma; NW -= 4) {
+      for (int CC = cc_first; CC >= 8 && !c.dma; CC /= 2) {
+        if (g.cin_g % CC != 0 || (c.COB * CC) % 256 != 0) continue;
+        const TileGeom td = tile_geom((NW / c.WN) * 4, g.IS, c.ISx, g.taps, c.tapsx);
+        const int E = td.IH * c.ISx * td.IWq * (CC / 4);
+        const int in_pad4 = bp_round_up(E, 64);
+        const size_t lds_dma = ((size_t)2 * in_pad4 * 4 + (size_t)2 * c.COB * CC) * sizeof(float);
+        const int per_thread = bp_ceil_div(in_pad4, 64 * NW);
+        // the plain fallback with this CC must exist too
+        const TileGeom t4 = tile_geom((4 / c.WN) * 4, g.IS, c.ISx, g.taps, c.tapsx);
+        if (lds_dma <= (size_t)(NW == 8 ? 64 : 54) * 1024 && per_thread <= 6 && plain_lds(t4, CC) <= 64 * 1024) {
+          c.dma = true; c.NW = NW; c.td = td; c.in_pad4 = in_pad4; c.slots = per_thread <= 3 ? 3 : 6;
+          c.lds_dma = lds_dma;
+          c.CC = CC;
+        }
+      }
+    }
+  }
   const int mts[2] = {4, 1};
   for (int mi = 0; mi < 2 && !c.ok; ++mi) {
     for (int CC = cc_first; CC >= 4 && !c.ok; CC /= 2) {
+      if (c.dma && CC != c.CC) continue;
       const int MT = mts[mi];
-      const int TM = (4 / c.WN) * MT;
-      const int TPR = (TM >= 16) ? 2 : 1;
-      const int BH = TM / TPR, BW = 16 * TPR;
-      const int IH = (BH - 1) * g.IS + g.taps, IW = (BW - 1) * c.ISx + c.tapsx;
-      const int IWq = bp_ceil_div(IW, c.ISx);
-      const size_t lds = ((size_t)IH * c.ISx * IWq * CC + (size_t)c.tapsx * c.COB * CC) * sizeof(float);
+      const TileGeom t = tile_geom((4 / c.WN) * MT, g.IS, c.ISx, g.taps, c.tapsx);
+      const size_t lds = plain_lds(t, CC);
       if (lds <= 64 * 1024) {
-        c.CC = CC; c.MT = MT; c.TPR = TPR; c.BH = BH; c.IH = IH; c.IW = IW; c.IWq = IWq;
+        c.CC = CC; c.MT = MT; c.t = t;
         c.nchunk = bp_ceil_div(g.cin_g, CC);
         c.lds_bytes = lds; c.ok = true;
       }
@@ -301,6 +580,30 @@ int launch_cc(const IgemmConfig& c, const IgemmArgs& a, dim3 grid, hipStream_t s
   return BP_EUNSUPPORTED;
 }
 
+template <int CC, int NT, int WN, int SLOTS, int NW>
+int launch_dma_one(const IgemmConfig& c, const IgemmArgs& a, dim3 grid, hipStream_t st) {
+  hipLaunchKernelGGL((igemm_dma_kernel<CC, NT, WN, SLOTS, NW>), grid, dim3(64 * NW), c.lds_dma, st, a);
+  BP_CHECK_LAUNCH();
+  return BP_OK;
+}
+
+template <int CC, int SLOTS>
+int launch_dma_cc(const IgemmConfig& c, const IgemmArgs& a, dim3 grid, hipStream_t st) {
+  if (c.NT == 4 && c.WN == 2 && c.NW == 8) return launch_dma_one<CC, 4, 2, SLOTS, 8>(c, a, grid, st);
+  if (c.NW != 4) return BP_EUNSUPPORTED;
+  if (c.NT == 4 && c.WN == 2) return launch_dma_one<CC, 4, 2, SLOTS, 4>(c, a, grid, st);
+  if (c.NT == 4 && c.WN == 1) return launch_dma_one<CC, 4, 1, SLOTS, 4>(c, a, grid, st);
+  if (c.NT == 2 && c.WN == 1) return launch_dma_one<CC, 2, 1, SLOTS, 4>(c, a, grid, st);
+  if (c.NT == 1 && c.WN == 1) return launch_dma_one<CC, 1, 1, SLOTS, 4>(c, a, grid, st);
+  return BP_EUNSUPPORTED;
+}
+
+int launch_dma(const IgemmConfig& c, const IgemmArgs& a, dim3 grid, hipStream_t st) {
+  if (c.CC == 16) return c.slots == 3 ? launch_dma_cc<16, 3>(c, a, grid, st) : launch_dma_cc<16, 6>(c, a, grid, st);
+  if (c.CC == 8) return c.slots == 3 ? launch_dma_cc<8, 3>(c, a, grid, st) : launch_dma_cc<8, 6>(c, a, grid, st);
+  return BP_EUNSUPPORTED;
+}
+
 template <int MT>
 int launch_mt(const IgemmConfig& c, const IgemmArgs& a, dim3 grid, hipStream_t st) {
   switch (c.CC) {
@@ -315,7 +618,7 @@ int launch_mt(const IgemmConfig& c, const IgemmArgs& a, dim3 grid, hipStream_t s
 
 int bp_igemm_kernel_id(const ConvGeom& g) {
   const IgemmConfig c = igemm_config(g);
-  return c.ok ? c.CC * 1000 + c.NT * 100 + c.WN * 10 + c.MT : -1;
+  return c.ok ? (c.dma ? 100000 * (c.NW / 4) : 0) + c.CC * 1000 + c.NT * 100 + c.WN * 10 + c.MT : -1;
 }
 
 int64_t bp_igemm_packed_floats(const ConvGeom& g) {
@@ -350,16 +653,22 @@ int bp_igemm_run(const ConvGeom& g, const bp_view* in, const PW& pw, const float
   a.tapsy = g.taps; a.tapsx = c.tapsx; a.ISy = g.IS; a.ISx = c.ISx; a.OS = g.OS; a.nphase = g.nphase;
   a.transposed = g.gather_transposed; a.PP = c.PP; a.COP = c.COP;
   a.stride = g.stride; a.pad = g.pad;
-  a.TPR = c.TPR; a.BH = c.BH; a.nchunk = c.nchunk; a.cout_padP = c.cout_padP;
-  a.IH = c.IH; a.IW = c.IW; a.IWq = c.IWq;
+  a.nchunk = c.nchunk; a.cout_padP = c.cout_padP;
   a.vec_ok = (in->cstride % 4 == 0 && in->coff % 4 == 0 &&
               (reinterpret_cast<uintptr_t>(in->ptr) % 16 == 0)) ? 1 : 0;
+  a.out_vec = (out->cstride % 4 == 0 && out->coff % 4 == 0 && reinterpret_cast<uintptr_t>(out->ptr) % 16 == 0) ? 1 : 0;
+  const bool dma = c.dma && a.vec_ok;
+  const TileGeom& t = dma ? c.td : c.t;
+  a.TPR = t.TPR; a.BH = t.BH; a.IH = t.IH; a.IW = t.IW; a.IWq = t.IWq;
   const int qh = bp_ceil_div(out->h, g.OS), qw = c.PP > 1 ? bp_ceil_div(out->w, c.PP) : bp_ceil_div(out->w, g.OS);
-  a.tiles_x = bp_ceil_div(qw, 16 * c.TPR);
-  a.tiles_y = bp_ceil_div(qh, c.BH);
+  a.tiles_x = bp_ceil_div(qw, 16 * t.TPR);
+  a.tiles_y = bp_ceil_div(qh, t.BH);
   const int64_t gz = (int64_t)in->n * g.nphase * g.nphase;
   if (gz > 65535 || c.cout_padP / c.COB > 65535) return BP_EUNSUPPORTED;
   dim3 grid((unsigned)(a.tiles_x * a.tiles_y), (unsigned)(c.cout_padP / c.COB), (unsigned)gz);
+  a.in_pad4 = c.in_pad4;
+  if (dma) return launch_dma(c, a, grid, st);
   if (c.MT == 4) return launch_mt<4>(c, a, grid, st);
   return launch_mt<1>(c, a, grid, st);
 }
+

@@ -72,7 +72,8 @@ const char* bp_strerror(int code);
 int64_t bp_conv_packed_floats(const bp_conv* cv, int dir);
 
 /* Which igemm_kernel<CC,NT,WN,MT> instantiation serves this layer/direction, encoded as
- * CC*1000 + NT*100 + WN*10 + MT (so a profile's kernel names can be matched to layers). */
+ * CC*1000 + NT*100 + WN*10 + MT, plus 100000 x (waves per workgroup / 4) when it is the LDS-DMA pipelined igemm_dma_kernel
+ * (so a profile's kernel names can be matched to layers). */
 int bp_conv_kernel_id(const bp_conv* cv, int dir);
 
 /* Re-layout torch-format weights (Conv2d: [cout][cin][k][k]; ConvTranspose2d: [cin][cout][k][k])

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     assert b"invalid" in lib.bp_strerror(-1)
     cv = L.Conv(0, 128, 128, 3, 1, 1, 0)
     assert lib.bp_conv_packed_floats(ctypes.byref(cv), L.PACK_FWD) == 9 * 128 * 128
-    assert lib.bp_conv_kernel_id(ctypes.byref(cv), L.PACK_FWD) == 16424
+    assert lib.bp_conv_kernel_id(ctypes.byref(cv), L.PACK_FWD) == 216424   # LDS-DMA igemm with 8 waves, CC 16, NT 4, WN 2, MT 4
 
 
 def test_model_refuses_cpu_and_missing_library(monkeypatch, tmp_path):
