@@ -271,10 +271,26 @@ __global__ __launch_bounds__(256, (MT == 4 && NT == 4) ? 4 : 1) void igemm_kerne
 // One barrier per tap; its vmcnt(0) retires this wave's DMAs, the barrier publishes them.
 // LDS image of the input is the one of igemm_kernel, enumerated in LDS order so that the 64 lanes of a
 // wave-instruction land on 1 KiB of consecutive LDS (destination = wave-uniform base + lane * 16).
-typedef __attribute__((address_space(3))) void* lds_vp;
-typedef const __attribute__((address_space(1))) void* glb_vp;
-__device__ __forceinline__ void glds16(const float* g, float* lds_wave_base) {
-  __builtin_amdgcn_global_load_lds((glb_vp)g, (lds_vp)lds_wave_base, 16, 0, 0);
+// The DMA is issued from inline assembly: hipcc would otherwise treat every ds_read that follows a
+// __builtin_amdgcn_global_load_lds as possibly aliasing it and wait vmcnt(0) right there, which serialises the
+// pipeline.  All waits on these loads are therefore written by hand (wait_dma below); the compiler's own counted
+// waits for ordinary loads can only over-wait because of them (retirement is in order).
+// `lds_float_off`: wave-uniform offset (in floats) into the dynamic LDS array, which starts right after the
+// static LDS of the kernel (none here).
+// Source = wave-uniform base (SGPR pair) + per-lane byte offset (one VGPR).
+__device__ __forceinline__ void glds16(const float* sbase, unsigned voff_bytes, int lds_float_off) {
+  const unsigned l = __builtin_amdgcn_readfirstlane(__builtin_amdgcn_groupstaticsize() + 4u * (unsigned)lds_float_off);
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff_bytes), "s"(l), "s"(sbase) : "memory");
+}
+// Retire this wave's DMAs, then the workgroup barrier that publishes the landed tiles (and this wave's LDS
+// writes) to the other waves.
+__device__ __forceinline__ void wait_dma_barrier() {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
 }
 
 template <int CC, int NT, int WN, int SLOTS, int NW>
@@ -283,6 +299,7 @@ __global__ __launch_bounds__(64 * NW, NT == 4 ? ((SLOTS == 3 && WN == 2) ? 4 : 3
   constexpr int VW = CC / 4;
   constexpr int WM = NW / WN;
   constexpr int NTH = 64 * NW;
+  constexpr int RING = 2;                 // weight slabs in LDS (a ring of three measured slower)
   constexpr int COB = 16 * NT * WN;
   constexpr int SLAB = COB * CC;          // floats per tap slab
   constexpr int SLAB_I = SLAB / 256;      // 1-KiB pieces per slab
@@ -357,18 +374,39 @@ __global__ __launch_bounds__(64 * NW, NT == 4 ? ((SLOTS == 3 && WN == 2) ? 4 : 3
     const bool in = e < E && c < a.IW && iy >= 0 && iy < a.in_h && ix >= 0 && ix < a.in_w;
     if (!in) outside |= 1u << i;
     const int cy = min(max(iy, 0), a.in_h - 1), cx = min(max(ix, 0), a.in_w - 1);
-    s_g[i] = (cy * a.in_w + cx) * a.in_cs + c4 * 4;
+    s_g[i] = ((cy * a.in_w + cx) * a.in_cs + c4 * 4) * 4;   // bytes
   }
 
   auto issue_input = [&](int chunk, int buf) {
 #pragma unroll
     for (int i = 0; i < SLOTS; ++i) {
       const int ebase = i * NTH + wave * 64;   // wave-uniform
-      if (ebase < a.in_pad4) glds16(in_n + s_g[i] + chunk * CC, smem + buf * in_f + ebase * 4);
+      if (ebase < a.in_pad4) glds16(in_n + chunk * CC, (unsigned)s_g[i], buf * in_f + ebase * 4);
     }
   };
+  // The pending activation's per-channel parameters live in LDS ([scale | shift | slope][cin], after the ring):
+  // an ordinary global load inside the loop would make the compiler wait vmcnt(0) -- and with it every DMA in
+  // flight -- at the next reuse of its destination registers.
+  float* lpw = smem + 2 * in_f + RING * SLAB;
+  const bool pw_on = a.pw.scale != nullptr;
+  if (pw_on) {
+    for (int i = tid; i < a.cin; i += NTH) {
+      lpw[i] = a.pw.scale[i]; lpw[a.cin + i] = a.pw.shift[i]; lpw[2 * a.cin + i] = a.pw.slope[i];
+    }
+    __syncthreads();
+  }
   auto rewrite_input = [&](int chunk, int buf) {
-    const PW4 p4 = pw4_load(a.pw, chunk * CC + c4 * 4, a.cin);
+    PW4 p4;
+    p4.on = pw_on;
+    if (pw_on) {
+      const int ch = chunk * CC + c4 * 4;
+      const float4 sc = *reinterpret_cast<const float4*>(lpw + ch);
+      const float4 sf = *reinterpret_cast<const float4*>(lpw + a.cin + ch);
+      const float4 sl = *reinterpret_cast<const float4*>(lpw + 2 * a.cin + ch);
+      p4.sc[0] = sc.x; p4.sc[1] = sc.y; p4.sc[2] = sc.z; p4.sc[3] = sc.w;
+      p4.sf[0] = sf.x; p4.sf[1] = sf.y; p4.sf[2] = sf.z; p4.sf[3] = sf.w;
+      p4.sl[0] = sl.x; p4.sl[1] = sl.y; p4.sl[2] = sl.z; p4.sl[3] = sl.w;
+    }
 #pragma unroll
     for (int i = 0; i < SLOTS; ++i) {
       const int e = i * NTH + tid;
@@ -382,31 +420,36 @@ __global__ __launch_bounds__(64 * NW, NT == 4 ? ((SLOTS == 3 && WN == 2) ? 4 : 3
   auto issue_slab = [&](int chunk, int ty, int tx, int slot) {
     const float* src = a.wp + ((((int64_t)(ph * a.tapsy + ty) * a.tapsx + tx) * a.nchunk + chunk) *
                                    a.cout_padP + co0) * CC;
-    for (int k = wave; k < SLAB_I; k += NW) glds16(src + (k * 64 + lane) * 4, lds_w + slot * SLAB + k * 256);
+    for (int k = wave; k < SLAB_I; k += NW) glds16(src + k * 256, (unsigned)lane * 16u, 2 * in_f + slot * SLAB + k * 256);
   };
 
+  auto advance = [&](int& ch, int& ty, int& tx) {
+    if (++tx == a.tapsx) { tx = 0; ++ty; }
+    if (ty == a.tapsy) { ty = 0; ++ch; }
+  };
   // prologue: first input tile and first slab
   issue_input(0, 0);
   issue_slab(0, 0, 0, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   rewrite_input(0, 0);
 
-  int step = 0;
+  int slot = 0;
   for (int chunk = 0; chunk < a.nchunk; ++chunk) {
     const float* lin = smem + (chunk & 1) * in_f;
     for (int ty = 0; ty < a.tapsy; ++ty) {
-      for (int tx = 0; tx < a.tapsx; ++tx, ++step) {
-        __syncthreads();   // vmcnt(0) + barrier: slab `step` (and a pending input tile) landed; step-1 is read out
-        {
-          int ntx = tx + 1, nty = ty, nch = chunk;
-          if (ntx == a.tapsx) { ntx = 0; ++nty; }
-          if (nty == a.tapsy) { nty = 0; ++nch; }
-          if (nch < a.nchunk) issue_slab(nch, nty, ntx, (step + 1) & 1);
-        }
+      for (int tx = 0; tx < a.tapsx; ++tx) {
+        // slab `step` (and a pending input tile) has landed, step-1 is read out
+        wait_dma_barrier();
         const bool first = (ty == 0 && tx == 0), last = (ty == a.tapsy - 1 && tx == a.tapsx - 1);
         if (first && chunk + 1 < a.nchunk) issue_input(chunk + 1, (chunk + 1) & 1);
+        {
+          int nch = chunk, nty = ty, ntx = tx;
+          advance(nch, nty, ntx);
+          if (nch < a.nchunk) issue_slab(nch, nty, ntx, slot ^ 1);
+        }
 
-        const float* lw = lds_w + (step & 1) * SLAB;
+        const float* lw = lds_w + slot * SLAB;
+        slot ^= 1;
         const int tapoff = ((ty * a.ISx + tx % a.ISx) * a.IWq + tx / a.ISx) * CC;
         float af[MT][VW], bf[NT][VW];
 #pragma unroll
@@ -535,11 +578,14 @@ IgemmConfig igemm_config(const ConvGeom& g) {
         const TileGeom td = tile_geom((NW / c.WN) * 4, g.IS, c.ISx, g.taps, c.tapsx);
         const int E = td.IH * c.ISx * td.IWq * (CC / 4);
         const int in_pad4 = bp_round_up(E, 64);
-        const size_t lds_dma = ((size_t)2 * in_pad4 * 4 + (size_t)2 * c.COB * CC) * sizeof(float);
+        const size_t lds_in2 = (size_t)2 * in_pad4 * 4 * sizeof(float) + (size_t)3 * g.cin_g * sizeof(float);   // + activation parameters
+        const size_t lds_slab = (size_t)c.COB * CC * sizeof(float);
+        const size_t lds_cap = (size_t)(NW == 8 ? 64 : 53) * 1024;   // two / three workgroups per CU
+        const size_t lds_dma = lds_in2 + 2 * lds_slab;
         const int per_thread = bp_ceil_div(in_pad4, 64 * NW);
         // the plain fallback with this CC must exist too
         const TileGeom t4 = tile_geom((4 / c.WN) * 4, g.IS, c.ISx, g.taps, c.tapsx);
-        if (lds_dma <= (size_t)(NW == 8 ? 64 : 54) * 1024 && per_thread <= 6 && plain_lds(t4, CC) <= 64 * 1024) {
+        if (lds_dma <= lds_cap && per_thread <= 6 && plain_lds(t4, CC) <= 64 * 1024) {
           c.dma = true; c.NW = NW; c.td = td; c.in_pad4 = in_pad4; c.slots = per_thread <= 3 ? 3 : 6;
           c.lds_dma = lds_dma;
           c.CC = CC;
