@@ -16,6 +16,11 @@ static inline bool bp_view_ok(const bp_view* v) {
          v->coff >= 0 && v->coff + v->c <= v->cstride;
 }
 
+// every pixel's channel slice starts on a 16-byte boundary
+static inline bool bp_view_vec4(const bp_view* v) {
+  return v->cstride % 4 == 0 && v->coff % 4 == 0 && reinterpret_cast<uintptr_t>(v->ptr) % 16 == 0;
+}
+
 static inline int64_t bp_view_pixels(const bp_view* v) { return (int64_t)v->n * v->h * v->w; }
 
 static inline int bp_ceil_div(int a, int b) { return (a + b - 1) / b; }
@@ -64,6 +69,31 @@ __device__ __forceinline__ float pw4_apply(const PW4& p, int j, float x) {
 __device__ __forceinline__ float4 pw4_apply4(const PW4& p, float4 v) {
   if (!p.on) return v;
   return make_float4(pw4_apply(p, 0, v.x), pw4_apply(p, 1, v.y), pw4_apply(p, 2, v.z), pw4_apply(p, 3, v.w));
+}
+
+// ---- LDS-DMA (global_load_lds_dwordx4): 64 lanes x 16 bytes from per-lane global addresses to 1 KiB of
+// consecutive LDS, no staging registers.  Issued from inline assembly: hipcc would otherwise treat every ds_read
+// that follows a __builtin_amdgcn_global_load_lds as possibly aliasing it and wait vmcnt(0) right there, which
+// serialises the pipeline.  All waits on these loads are therefore written by hand; the compiler's own counted
+// waits for ordinary loads can only over-wait because of them (retirement is in order).  Keep ordinary global
+// loads out of loops that hold a DMA in flight: their destination registers make the compiler drain vmcnt.
+//   sbase          wave-uniform base (SGPR pair);  voff_bytes  per-lane byte offset (one VGPR)
+//   lds_float_off  wave-uniform offset in floats into the dynamic LDS array, which starts right after the
+//                  kernel's static LDS (lane l lands at that offset + 4*l floats)
+__device__ __forceinline__ void bp_glds16(const float* sbase, unsigned voff_bytes, int lds_float_off) {
+  const unsigned l = __builtin_amdgcn_readfirstlane(__builtin_amdgcn_groupstaticsize() + 4u * (unsigned)lds_float_off);
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff_bytes), "s"(l), "s"(sbase) : "memory");
+}
+// Retire this wave's DMAs (its own lanes' bytes are then readable by this wave).
+__device__ __forceinline__ void bp_wait_dma() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// ... then the workgroup barrier that publishes the landed tiles (and this wave's LDS writes) to the other waves.
+__device__ __forceinline__ void bp_wait_dma_barrier() {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
 }
 
 // Geometry of one (transposed) convolution expressed as a stride-IS correlation over an output

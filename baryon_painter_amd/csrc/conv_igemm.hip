@@ -271,28 +271,6 @@ __global__ __launch_bounds__(256, (MT == 4 && NT == 4) ? 4 : 1) void igemm_kerne
 // One barrier per tap; its vmcnt(0) retires this wave's DMAs, the barrier publishes them.
 // LDS image of the input is the one of igemm_kernel, enumerated in LDS order so that the 64 lanes of a
 // wave-instruction land on 1 KiB of consecutive LDS (destination = wave-uniform base + lane * 16).
-// The DMA is issued from inline assembly: hipcc would otherwise treat every ds_read that follows a
-// __builtin_amdgcn_global_load_lds as possibly aliasing it and wait vmcnt(0) right there, which serialises the
-// pipeline.  All waits on these loads are therefore written by hand (wait_dma below); the compiler's own counted
-// waits for ordinary loads can only over-wait because of them (retirement is in order).
-// `lds_float_off`: wave-uniform offset (in floats) into the dynamic LDS array, which starts right after the
-// static LDS of the kernel (none here).
-// Source = wave-uniform base (SGPR pair) + per-lane byte offset (one VGPR).
-__device__ __forceinline__ void glds16(const float* sbase, unsigned voff_bytes, int lds_float_off) {
-  const unsigned l = __builtin_amdgcn_readfirstlane(__builtin_amdgcn_groupstaticsize() + 4u * (unsigned)lds_float_off);
-  unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(voff_bytes), "s"(l), "s"(sbase) : "memory");
-}
-// Retire this wave's DMAs, then the workgroup barrier that publishes the landed tiles (and this wave's LDS
-// writes) to the other waves.
-__device__ __forceinline__ void wait_dma_barrier() {
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-}
-
 template <int CC, int NT, int WN, int SLOTS, int NW>
 __global__ __launch_bounds__(64 * NW, NT == 4 ? ((SLOTS == 3 && WN == 2) ? 4 : 3) : 2) void igemm_dma_kernel(IgemmArgs a) {
   constexpr int MT = 4;
@@ -381,7 +359,7 @@ __global__ __launch_bounds__(64 * NW, NT == 4 ? ((SLOTS == 3 && WN == 2) ? 4 : 3
 #pragma unroll
     for (int i = 0; i < SLOTS; ++i) {
       const int ebase = i * NTH + wave * 64;   // wave-uniform
-      if (ebase < a.in_pad4) glds16(in_n + chunk * CC, (unsigned)s_g[i], buf * in_f + ebase * 4);
+      if (ebase < a.in_pad4) bp_glds16(in_n + chunk * CC, (unsigned)s_g[i], buf * in_f + ebase * 4);
     }
   };
   // The pending activation's per-channel parameters live in LDS ([scale | shift | slope][cin], after the ring):
@@ -420,7 +398,7 @@ __global__ __launch_bounds__(64 * NW, NT == 4 ? ((SLOTS == 3 && WN == 2) ? 4 : 3
   auto issue_slab = [&](int chunk, int ty, int tx, int slot) {
     const float* src = a.wp + ((((int64_t)(ph * a.tapsy + ty) * a.tapsx + tx) * a.nchunk + chunk) *
                                    a.cout_padP + co0) * CC;
-    for (int k = wave; k < SLAB_I; k += NW) glds16(src + k * 256, (unsigned)lane * 16u, 2 * in_f + slot * SLAB + k * 256);
+    for (int k = wave; k < SLAB_I; k += NW) bp_glds16(src + k * 256, (unsigned)lane * 16u, 2 * in_f + slot * SLAB + k * 256);
   };
 
   auto advance = [&](int& ch, int& ty, int& tx) {
@@ -430,7 +408,7 @@ __global__ __launch_bounds__(64 * NW, NT == 4 ? ((SLOTS == 3 && WN == 2) ? 4 : 3
   // prologue: first input tile and first slab
   issue_input(0, 0);
   issue_slab(0, 0, 0, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  bp_wait_dma();
   rewrite_input(0, 0);
 
   int slot = 0;
@@ -439,7 +417,7 @@ __global__ __launch_bounds__(64 * NW, NT == 4 ? ((SLOTS == 3 && WN == 2) ? 4 : 3
     for (int ty = 0; ty < a.tapsy; ++ty) {
       for (int tx = 0; tx < a.tapsx; ++tx) {
         // slab `step` (and a pending input tile) has landed, step-1 is read out
-        wait_dma_barrier();
+        bp_wait_dma_barrier();
         const bool first = (ty == 0 && tx == 0), last = (ty == a.tapsy - 1 && tx == a.tapsx - 1);
         if (first && chunk + 1 < a.nchunk) issue_input(chunk + 1, (chunk + 1) & 1);
         {
