@@ -134,6 +134,71 @@ def test_conv_lazy_activation_and_zero_padding(impl):
     assert G.rel_err(dw.cpu().numpy(), dw_ref) < 1e-4
 
 
+# (transposed, cin, cout, k, stride, pad, (n, h, w)): layers wide enough for the LDS-DMA pipelined kernels
+# (igemm_dma_kernel, wgrad_tiles_dma_kernel), at sizes that leave ragged tiles and partial channel blocks.
+DMA_CASES = [
+    (0, 48, 80, 3, 1, 1, (3, 13, 19)),
+    (0, 128, 128, 3, 1, 1, (2, 22, 37)),
+    (0, 32, 64, 4, 2, 1, (2, 14, 22)),
+    (0, 64, 128, 4, 2, 1, (2, 10, 38)),
+    (1, 64, 32, 4, 2, 1, (3, 5, 9)),
+    (1, 128, 64, 4, 2, 1, (2, 7, 18)),
+]
+
+
+@pytest.mark.parametrize("case", DMA_CASES, ids=lambda c: "%s%d_%d_k%ds%d" % ("T" if c[0] else "C", *c[1:5]))
+def test_dma_pipelined_kernels_ragged_views_and_activation(case):
+    """Forward, data gradient and weight gradient of the wide layers, reading the input as a channel slice of
+    a wider buffer (16-byte aligned, as the networks' concat buffers are) with a pending affine + leaky-ReLU
+    whose act(0) != 0, against the float64 oracle."""
+    lib = L.load()
+    tr, ci, co, k, s, p, (n, h, w) = case
+    rng = np.random.default_rng(ci * 7 + co + k)
+    x = rng.standard_normal((n, ci, h, w)).astype(np.float32)
+    wt = (rng.standard_normal(((ci, co) if tr else (co, ci)) + (k, k)) * 0.1).astype(np.float32)
+    scale = rng.uniform(0.5, 1.5, ci).astype(np.float32)
+    shift = rng.uniform(0.2, 0.6, ci).astype(np.float32)
+    slope = rng.uniform(0.0, 0.3, ci).astype(np.float32)
+    t = x * scale[None, :, None, None] + shift[None, :, None, None]
+    xa = np.where(t > 0, t, t * slope[None, :, None, None]).astype(np.float64)
+    w64 = wt.astype(np.float64)
+    y_ref = ops.convT2d_fwd(xa, w64, s, p, 0) if tr else ops.conv2d_fwd(xa, w64, s, p)
+    _, _, ho, wo = y_ref.shape
+    cv = L.Conv(tr, ci, co, k, s, p, 0)
+    assert max(lib.bp_conv_kernel_id(C.byref(cv), d) for d in (L.PACK_FWD, L.PACK_BWD)) >= 100000, \
+        "case is meant for the DMA kernels"
+    st = G.stream()
+    xb, xv = G.to_nhwc(x, cstride=ci + 24, coff=8)
+    yb, yv = G.empty_nhwc(n, ho, wo, co, cstride=co + 12, coff=4)
+    keep, pw = G.pointwise(scale, shift, slope)
+    wd = G.dev(wt)
+    pf = torch.zeros(lib.bp_conv_packed_floats(C.byref(cv), L.PACK_FWD), device="cuda")
+    pb = torch.zeros(lib.bp_conv_packed_floats(C.byref(cv), L.PACK_BWD), device="cuda")
+    L.check(lib.bp_conv_pack(C.byref(cv), L.PACK_FWD, L.ptr(wd), L.ptr(pf), st))
+    L.check(lib.bp_conv_pack(C.byref(cv), L.PACK_BWD, L.ptr(wd), L.ptr(pb), st))
+    L.check(lib.bp_conv_forward(C.byref(cv), C.byref(xv), C.byref(pw), L.ptr(pf), L.ptr(wd), None, C.byref(yv),
+                                L.IMPL_MFMA, st), "forward")
+    assert G.rel_err(G.from_nhwc(yb, co, coff=4), y_ref) < 2e-5
+    assert torch.isnan(yb[..., :4]).all() and torch.isnan(yb[..., 4 + co:]).all(), "stores outside the view"
+
+    dy = rng.standard_normal(y_ref.shape).astype(np.float32)
+    dy64 = dy.astype(np.float64)
+    dyb, dyv = G.to_nhwc(dy, cstride=co + 4, coff=4)
+    dxb, dxv = G.empty_nhwc(n, h, w, ci)
+    L.check(lib.bp_conv_backward_data(C.byref(cv), C.byref(dyv), L.ptr(pb), L.ptr(wd), C.byref(dxv), L.IMPL_MFMA,
+                                      st), "backward_data")
+    dx_ref = ops.convT2d_bwd_data(dy64, w64, s, p) if tr else ops.conv2d_bwd_data(dy64, w64, s, p, h, w)
+    assert G.rel_err(G.from_nhwc(dxb, ci), dx_ref) < 2e-5
+
+    ws_bytes = lib.bp_conv_backward_weight_workspace(C.byref(cv), C.byref(xv), C.byref(dyv))
+    ws = torch.zeros(ws_bytes // 8 + 8, dtype=torch.float64, device="cuda")
+    dw = torch.full(wt.shape, float("nan"), device="cuda")
+    L.check(lib.bp_conv_backward_weight(C.byref(cv), C.byref(xv), C.byref(pw), C.byref(dyv), L.ptr(dw), None,
+                                        L.ptr(ws), ws.numel() * 8, L.IMPL_MFMA, st), "backward_weight")
+    dw_ref = ops.convT2d_bwd_weight(xa, dy64, s, p, k, k) if tr else ops.conv2d_bwd_weight(xa, dy64, s, p, k, k)
+    assert G.rel_err(dw.cpu().numpy(), dw_ref) < 1e-4
+
+
 def test_conv_rejects_bad_shapes():
     lib = L.load()
     cv = L.Conv(0, 16, 32, 3, 1, 1, 0)
