@@ -64,6 +64,7 @@ SIGNATURES = {
     "bp_act_backward": (C.c_int, [_VP, _VP, _VP, _PWP, _VP, _VP, _P, _P, C.c_size_t, _P]),
     "bp_bn_backward_finalize": (C.c_int, [_P, C.c_double, C.c_int32, _P, _P, _P, C.c_float, _P, _P, _P, _P]),
     "bp_bn_backward_apply": (C.c_int, [_VP, _VP, _P, _VP, _P]),
+    "bp_act_bn_backward_apply": (C.c_int, [_VP, _VP, _VP, _PWP, _VP, _P, _VP, _P]),
     "bp_sums_to_float": (C.c_int, [_P, C.c_int32, _P, _P]),
     "bp_prelu_slope_grad": (C.c_int, [_P, C.c_int32, _P, _P]),
     "bp_residual_forward": (C.c_int, [_VP, _PWP, _VP, _PWP, C.c_float, _VP, _P]),

@@ -153,7 +153,7 @@ __global__ __launch_bounds__(RB) void act_backward_fast_kernel(ActBwdFast a) {
       acc[1][j] += (double)g[j] * r[j];
       if (!pos) acc[2][j] += (double)d[j] * t;
     }
-    a.g[i] = make_float4(g[0], g[1], g[2], g[3]);
+    if (a.g) a.g[i] = make_float4(g[0], g[1], g[2], g[3]);
   }
   block_reduce_store<3>(acc, c, a.partial + (int64_t)blockIdx.x * 3 * c, sh);
 }
@@ -173,6 +173,47 @@ __global__ __launch_bounds__(RB) void bn_backward_apply_fast_kernel(const float4
                          (float)(A[1] * ((double)gv.y - G[1]) + B[1] * ((double)r.y - M[1])),
                          (float)(A[2] * ((double)gv.z - G[2]) + B[2] * ((double)r.z - M[2])),
                          (float)(A[3] * ((double)gv.w - G[3]) + B[3] * ((double)r.w - M[3])));
+  }
+}
+
+// The same map with g recomputed from the incoming gradient(s) and the activation mask, so that
+// bp_act_backward need not write g at all (one tensor write and no re-read of it saved per layer).
+struct ActApplyFast {
+  const float4* dout; const float4* dout2; const float4* raw; const float4* aout; float4* out;
+  PW pw; const double* abc; int c; int64_t total4;
+};
+
+__global__ __launch_bounds__(RB) void act_bn_backward_apply_fast_kernel(ActApplyFast a) {
+  const int tid = threadIdx.x;
+  const int c = a.c;
+  double A[4], G[4], B[4], M[4];
+  float sc[4], sf[4], sl[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int ch = (4 * tid + j) % c;
+    A[j] = a.abc[ch]; G[j] = a.abc[c + ch]; B[j] = a.abc[2 * c + ch]; M[j] = a.abc[3 * c + ch];
+    sc[j] = a.pw.scale ? a.pw.scale[ch] : 1.f;
+    sf[j] = a.pw.scale ? a.pw.shift[ch] : 0.f;
+    sl[j] = a.pw.scale ? a.pw.slope[ch] : 1.f;
+  }
+  for (int64_t i = (int64_t)blockIdx.x * RB + tid; i < a.total4; i += (int64_t)gridDim.x * RB) {
+    float4 d4 = a.dout[i];
+    if (a.dout2) { const float4 e = a.dout2[i]; d4.x += e.x; d4.y += e.y; d4.z += e.z; d4.w += e.w; }
+    const float4 r4 = a.raw[i];
+    float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a.aout) s4 = a.aout[i];
+    const float d[4] = {d4.x, d4.y, d4.z, d4.w};
+    const float r[4] = {r4.x, r4.y, r4.z, r4.w};
+    const float so[4] = {s4.x, s4.y, s4.z, s4.w};
+    float o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float t = fmaf(r[j], sc[j], sf[j]);
+      const bool pos = (a.aout ? so[j] : t) > 0.f;
+      const float g = pos ? d[j] : d[j] * sl[j];
+      o[j] = (float)(A[j] * ((double)g - G[j]) + B[j] * ((double)r[j] - M[j]));
+    }
+    a.out[i] = make_float4(o[0], o[1], o[2], o[3]);
   }
 }
 
@@ -291,7 +332,7 @@ __global__ __launch_bounds__(RB) void act_backward_kernel(ActBwdArgs a) {
       const float sgn = a.aout.p ? a.aout.p[p * a.aout.cs + a.aout.co + ch] : t;
       const bool pos = sgn > 0.f;
       const float g = pos ? d : d * sl;
-      a.g.p[p * a.g.cs + a.g.co + ch] = g;
+      if (a.g.p) a.g.p[p * a.g.cs + a.g.co + ch] = g;
       v[0] += g;
       v[1] += (double)g * r;
       if (!pos) v[2] += (double)d * t;
@@ -339,6 +380,25 @@ __global__ __launch_bounds__(RB) void bn_backward_apply_kernel(ViewD g, ViewD ra
   const float r = raw.p[p * raw.cs + raw.co + ch];
   out.p[p * out.cs + out.co + ch] =
       (float)(abc[ch] * ((double)gv - abc[c + ch]) + abc[2 * c + ch] * ((double)r - abc[3 * c + ch]));
+}
+
+__global__ __launch_bounds__(RB) void act_bn_backward_apply_kernel(ViewD dout, ViewD dout2, ViewD raw, ViewD aout, PW pw,
+                                                                   const double* abc, ViewD out, int64_t total) {
+  const int64_t i = (int64_t)blockIdx.x * RB + threadIdx.x;
+  if (i >= total) return;
+  const int c = raw.c;
+  const int ch = i % c;
+  const int64_t p = i / c;
+  float d = dout.p[p * dout.cs + dout.co + ch];
+  if (dout2.p) d += dout2.p[p * dout2.cs + dout2.co + ch];
+  const float r = raw.p[p * raw.cs + raw.co + ch];
+  float sc = 1.f, sf = 0.f, sl = 1.f;
+  if (pw.scale) { sc = pw.scale[ch]; sf = pw.shift[ch]; sl = pw.slope[ch]; }
+  const float t = fmaf(r, sc, sf);
+  const float sgn = aout.p ? aout.p[p * aout.cs + aout.co + ch] : t;
+  const float g = sgn > 0.f ? d : d * sl;
+  out.p[p * out.cs + out.co + ch] =
+      (float)(abc[ch] * ((double)g - abc[c + ch]) + abc[2 * c + ch] * ((double)r - abc[3 * c + ch]));
 }
 
 __global__ void prelu_slope_grad_kernel(const double* sums, int c, float* dslope) {
@@ -818,21 +878,21 @@ static bool same_grid(const bp_view* a, const bp_view* b) {
 int bp_act_backward(const bp_view* dout, const bp_view* dout2, const bp_view* raw, const bp_pointwise* pw,
                     const bp_view* act_out, const bp_view* g, double* sums, void* workspace,
                     size_t workspace_bytes, void* stream) {
-  if (!bp_view_ok(dout) || !bp_view_ok(raw) || !bp_view_ok(g) || !sums) return BP_EINVAL;
-  if (!same_grid(dout, raw) || !same_grid(g, raw)) return BP_EINVAL;
+  if (!bp_view_ok(dout) || !bp_view_ok(raw) || (g && !bp_view_ok(g)) || !sums) return BP_EINVAL;
+  if (!same_grid(dout, raw) || (g && !same_grid(g, raw))) return BP_EINVAL;
   if (dout2 && (!bp_view_ok(dout2) || !same_grid(dout2, raw))) return BP_EINVAL;
   if (act_out && (!bp_view_ok(act_out) || !same_grid(act_out, raw))) return BP_EINVAL;
   if (!workspace || workspace_bytes < bp_act_backward_workspace(raw)) return BP_EWORKSPACE;
   const RedPlan r = red_plan(raw->c, bp_view_pixels(raw));
   hipStream_t st = bp_stream(stream);
-  if (dense_ok(raw) && dense_ok(dout) && dense_ok(g) && (!dout2 || dense_ok(dout2)) && (!act_out || dense_ok(act_out))) {
+  if (dense_ok(raw) && dense_ok(dout) && (!g || dense_ok(g)) && (!dout2 || dense_ok(dout2)) && (!act_out || dense_ok(act_out))) {
     const FastPlan f = fast_plan(bp_view_pixels(raw) * raw->c);
     ActBwdFast fa{};
     fa.dout = reinterpret_cast<const float4*>(dout->ptr);
     fa.dout2 = dout2 ? reinterpret_cast<const float4*>(dout2->ptr) : nullptr;
     fa.raw = reinterpret_cast<const float4*>(raw->ptr);
     fa.aout = act_out ? reinterpret_cast<const float4*>(act_out->ptr) : nullptr;
-    fa.g = reinterpret_cast<float4*>(g->ptr);
+    fa.g = g ? reinterpret_cast<float4*>(g->ptr) : nullptr;
     fa.pw = bp_pw(pw); fa.c = raw->c; fa.total4 = f.total4; fa.chunk4 = f.chunk4;
     fa.partial = reinterpret_cast<double*>(workspace);
     hipLaunchKernelGGL(act_backward_fast_kernel, dim3(f.nblk), dim3(RB), 0, st, fa);
@@ -882,6 +942,33 @@ int bp_bn_backward_apply(const bp_view* g, const bp_view* raw, const double* coe
   }
   hipLaunchKernelGGL(bn_backward_apply_kernel, dim3(nblocks(total)), dim3(RB), 0, bp_stream(stream), vd(g), vd(raw),
                      coef_abc, vd(out), total);
+  BP_CHECK_LAUNCH();
+  return BP_OK;
+}
+
+int bp_act_bn_backward_apply(const bp_view* dout, const bp_view* dout2, const bp_view* raw, const bp_pointwise* pw,
+                             const bp_view* act_out, const double* coef_abc, const bp_view* out, void* stream) {
+  if (!bp_view_ok(dout) || !bp_view_ok(raw) || !bp_view_ok(out) || !coef_abc) return BP_EINVAL;
+  if (!same_grid(dout, raw) || !same_grid(out, raw)) return BP_EINVAL;
+  if (dout2 && (!bp_view_ok(dout2) || !same_grid(dout2, raw))) return BP_EINVAL;
+  if (act_out && (!bp_view_ok(act_out) || !same_grid(act_out, raw))) return BP_EINVAL;
+  const int64_t total = bp_view_pixels(raw) * raw->c;
+  if (dense_ok(raw) && dense_ok(dout) && dense_ok(out) && (!dout2 || dense_ok(dout2)) && (!act_out || dense_ok(act_out))) {
+    ActApplyFast fa{};
+    fa.dout = reinterpret_cast<const float4*>(dout->ptr);
+    fa.dout2 = dout2 ? reinterpret_cast<const float4*>(dout2->ptr) : nullptr;
+    fa.raw = reinterpret_cast<const float4*>(raw->ptr);
+    fa.aout = act_out ? reinterpret_cast<const float4*>(act_out->ptr) : nullptr;
+    fa.out = reinterpret_cast<float4*>(out->ptr);
+    fa.pw = bp_pw(pw); fa.abc = coef_abc; fa.c = raw->c; fa.total4 = total / 4;
+    int64_t nb = (fa.total4 + RB * 4 - 1) / (RB * 4);
+    if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(act_bn_backward_apply_fast_kernel, dim3((unsigned)nb), dim3(RB), 0, bp_stream(stream), fa);
+    BP_CHECK_LAUNCH();
+    return BP_OK;
+  }
+  hipLaunchKernelGGL(act_bn_backward_apply_kernel, dim3(nblocks(total)), dim3(RB), 0, bp_stream(stream), vd(dout),
+                     vd(dout2), vd(raw), vd(act_out), bp_pw(pw), coef_abc, vd(out), total);
   BP_CHECK_LAUNCH();
   return BP_OK;
 }

@@ -361,21 +361,27 @@ class ConvUnit:
         out = self.out
         if self.has_pw or out.grad2 is not None:
             pw = None if self.out_pw is None else C.byref(self.out_pw.struct)
-            self.activation_backward(out.grad, out.grad2, pw, None, out.grad, out.grad, grads)
+            self.activation_backward(out.grad, out.grad2, pw, None, None if self.bn is not None else out.grad,
+                                     out.grad, grads)
         self.conv_backward(grads)
 
     def activation_backward(self, dout, dout2, pw, act_out, g_out, d_raw_out, grads):
-        """g = (dout+dout2)*act'(t) -> g_out;  batch-norm backward of g -> d_raw_out."""
+        """g = (dout+dout2)*act'(t) -> g_out;  batch-norm backward of g -> d_raw_out.
+        ``g_out`` None (batch-norm layers whose g nobody else reads): g is not stored, the apply pass
+        recomputes it from dout / the activation mask."""
         plan, lib, st = self.plan, self.plan.lib, _stream()
         c = self.cv.cout
-        L.check(lib.bp_act_backward(C.byref(dout), None if dout2 is None else C.byref(dout2),
-                                    C.byref(self.out.view), pw, None if act_out is None else C.byref(act_out),
-                                    C.byref(g_out), L.ptr(self.sums), L.ptr(plan.ws), plan.ws_bytes, st),
-                f"{self.name} act backward")
+        bn = self.bn
+        if g_out is None and bn is None:
+            raise ValueError("without batch-norm g IS the result: it must be stored")
+        aout = None if act_out is None else C.byref(act_out)
+        d2 = None if dout2 is None else C.byref(dout2)
+        L.check(lib.bp_act_backward(C.byref(dout), d2, C.byref(self.out.view), pw, aout,
+                                    None if g_out is None else C.byref(g_out), L.ptr(self.sums), L.ptr(plan.ws),
+                                    plan.ws_bytes, st), f"{self.name} act backward")
         if self.act == "prelu":
             L.check(lib.bp_prelu_slope_grad(L.ptr(self.sums), c, L.ptr(grads[id(self.act_holder.weight)]), st),
                     f"{self.name} prelu grad")
-        bn = self.bn
         if bn is not None:
             pscale = 1.0
             if plan.sync is not None and plan.sync.sync_bn:
@@ -385,8 +391,13 @@ class ConvUnit:
                                                 L.ptr(self.save_mean), L.ptr(self.save_invstd), pscale,
                                                 L.ptr(grads[id(bn.weight)]), L.ptr(grads[id(bn.bias)]),
                                                 L.ptr(self.abc), st), f"{self.name} bn backward")
-            L.check(lib.bp_bn_backward_apply(C.byref(g_out), C.byref(self.out.view), L.ptr(self.abc),
-                                             C.byref(d_raw_out), st), f"{self.name} bn backward apply")
+            if g_out is None:
+                L.check(lib.bp_act_bn_backward_apply(C.byref(dout), d2, C.byref(self.out.view), pw, aout,
+                                                     L.ptr(self.abc), C.byref(d_raw_out), st),
+                        f"{self.name} act+bn backward apply")
+            else:
+                L.check(lib.bp_bn_backward_apply(C.byref(g_out), C.byref(self.out.view), L.ptr(self.abc),
+                                                 C.byref(d_raw_out), st), f"{self.name} bn backward apply")
             return True
         return False
 

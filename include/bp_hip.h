@@ -123,7 +123,8 @@ int bp_bn_eval_pointwise(int32_t c, const float* gamma, const float* beta,
 /* ---- activation / batch-norm backward ------------------------------------------------------ */
 
 /* Backward through y = leaky(raw*scale+shift [+ skip], slope):
- *   g = (dout [+ dout2]) * act'(t)           written to `g` (may alias dout)
+ *   g = (dout [+ dout2]) * act'(t)           written to `g` (may alias dout; NULL: sums only, for
+ *                                            layers that continue with bp_act_bn_backward_apply)
  *   sums[3*c] (double) = { sum g, sum g*raw, sum (dout[+dout2]) * t * [t<=0] }  (third: d slope)
  * `act_out`, if given, is the saved activated output and supplies the sign of t (residual
  * blocks, where t includes the skip); otherwise t is recomputed from raw and `pw`. */
@@ -145,6 +146,13 @@ int bp_bn_backward_finalize(const double* sums, double count, int32_t c, const f
 /* out = A*(g - mg) + B*(raw - mean)  (out may alias g). */
 int bp_bn_backward_apply(const bp_view* g, const bp_view* raw, const double* coef_abc,
                          const bp_view* out, void* stream);
+
+/* The same map with g recomputed on the fly from (dout [+ dout2], raw, pw, act_out) exactly as
+ * bp_act_backward defines it: pairs with bp_act_backward(..., g = NULL, ...) so that g never
+ * travels through HBM (out may alias dout). */
+int bp_act_bn_backward_apply(const bp_view* dout, const bp_view* dout2, const bp_view* raw,
+                             const bp_pointwise* pw, const bp_view* act_out, const double* coef_abc,
+                             const bp_view* out, void* stream);
 
 /* dst[ch] = (float) sums[ch]  (e.g. a bias gradient from bp_channel_sums of dy). */
 int bp_sums_to_float(const double* sums, int32_t c, float* dst, void* stream);
