@@ -32,7 +32,8 @@ struct IgemmArgs {
   int IH, IW, IWq;
   int vec_ok;
   int out_vec;   // 16-byte stores allowed
-  int in_pad4;   // DMA variant: float4 groups per input buffer, padded to whole 1-KiB pieces
+  int in_pad4;   // DMA variants: float4 groups per input buffer, padded to whole 1-KiB pieces
+  int ts, in_bufs;   // igemm_dmaf_kernel: taps per step, input buffers (1 or 2)
 };
 
 template <int VW> struct Frag;
@@ -452,6 +453,224 @@ __global__ __launch_bounds__(64 * NW, NT == 4 ? ((SLOTS == 3 && WN == 2) ? 4 : 3
   igemm_store<NT, MT>(a, acc, out_n, wm, wn, lm, kq, co0, qy0, qx0, qh, qw, py, px);
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// LDS-DMA pipeline for layers with at most 32 produced channels (NT <= 2), where one tap is too little work
+// per barrier and the input tile, not the weights, is the traffic:
+//   * a step covers TS consecutive taps (a tap row, or all taps) -> >= 64 MFMAs per wave between barriers;
+//   * transposed forms (ConvTranspose2d forward, data gradient of a strided Conv2d) compute all stride^2
+//     output phases in one workgroup from ONE staged input tile (the union of the phases' halos), with one
+//     accumulator set per phase, instead of staging the tile once per phase;
+//   * a single input buffer when the layer has one channel chunk (nothing to prefetch).
+// Four waves, each 4 M tiles (64 pixels of the phase grid) x all NT channel tiles.
+template <int CC, int NT, int SLOTS, int NPH>
+__global__ __launch_bounds__(256, 2) void igemm_dmaf_kernel(IgemmArgs a) {
+  constexpr int MT = 4;
+  constexpr int VW = CC / 4;
+  constexpr int COB = 16 * NT;
+  constexpr int SLAB = COB * CC;          // floats per tap slab
+  constexpr int SLAB_I = SLAB / 256;      // 1-KiB pieces per slab
+  static_assert(SLAB % 256 == 0, "a tap slab is whole 1-KiB pieces");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int in_f = a.in_pad4 * 4;
+  const int ring0 = a.in_bufs * in_f;               // float offset of the slab ring
+  const int grp = a.ts * SLAB;                      // floats per ring slot
+  float* lpw = smem + ring0 + 2 * grp;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave;
+  const int lm = lane & 15, kq = lane >> 4;
+
+  const int tile = blockIdx.x;
+  const int tile_x = tile % a.tiles_x, tile_y = tile / a.tiles_x;
+  const int co0 = blockIdx.y * COB;
+  const int nph2 = a.nphase * a.nphase;
+  const int ph0 = NPH == 1 ? blockIdx.z % nph2 : 0;
+  const int n = NPH == 1 ? blockIdx.z / nph2 : blockIdx.z;
+  const int py0 = ph0 / a.nphase, px0 = ph0 % a.nphase;
+
+  const int BW = 16 * a.TPR;
+  const int qy0 = tile_y * a.BH, qx0 = tile_x * BW;
+  {
+    // extents of the (largest) phase grid this workgroup works on
+    const int qh = (a.out_h - py0 + a.OS - 1) / a.OS;
+    const int qw = a.PP > 1 ? (a.out_w + a.PP - 1) / a.PP : (a.out_w - px0 + a.OS - 1) / a.OS;
+    if (qy0 >= qh || qx0 >= qw) return;  // uniform per block
+  }
+
+  // origin of the staged tile: the first gathered row/column of phase (py0, px0) -- with fused phases that is
+  // phase 0, whose origin is the smallest; phase p starts dy(p) rows / dx(p) columns further in
+  int iy0, ix0;
+  if (a.transposed) {
+    iy0 = bp_t_i0(py0, a.pad, a.stride, a.tapsy);
+    ix0 = bp_t_i0(px0, a.pad, a.stride, a.tapsy);
+  } else {
+    iy0 = -a.pad; ix0 = -a.pad;
+  }
+  const int gy0 = a.ISy * qy0 + iy0, gx0 = a.ISx * qx0 + ix0;
+
+  int abase[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int t = wm * MT + mt;
+    const int tr = t / a.TPR, tc = t % a.TPR;
+    abase[mt] = (tr * a.ISy * a.ISx * a.IWq + tc * 16 + lm) * CC + kq * VW;
+  }
+  int bbase[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) bbase[nt] = (nt * 16 + lm) * CC + kq * VW;
+
+  v4f acc[NPH][MT][NT];
+#pragma unroll
+  for (int p = 0; p < NPH; ++p)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[p][mt][nt] = v4f{0.f, 0.f, 0.f, 0.f};
+
+  const float* in_n = a.in + (int64_t)n * a.in_h * a.in_w * a.in_cs + a.in_co;
+  const int E = a.IH * a.ISx * a.IWq * VW;   // float4 groups of the LDS image
+
+  const int c4 = tid % VW;
+  int s_g[SLOTS];
+  unsigned outside = 0;
+#pragma unroll
+  for (int i = 0; i < SLOTS; ++i) {
+    const int e = i * 256 + tid;
+    const int p = e / VW;
+    const int xq = p % a.IWq;
+    const int t = p / a.IWq;
+    const int xm = t % a.ISx;
+    const int r = t / a.ISx;
+    const int c = xq * a.ISx + xm;
+    const int iy = gy0 + r, ix = gx0 + c;
+    const bool in = e < E && c < a.IW && iy >= 0 && iy < a.in_h && ix >= 0 && ix < a.in_w;
+    if (!in) outside |= 1u << i;
+    const int cy = min(max(iy, 0), a.in_h - 1), cx = min(max(ix, 0), a.in_w - 1);
+    s_g[i] = ((cy * a.in_w + cx) * a.in_cs + c4 * 4) * 4;   // bytes
+  }
+
+  auto issue_input = [&](int chunk, int buf) {
+#pragma unroll
+    for (int i = 0; i < SLOTS; ++i) {
+      const int ebase = i * 256 + wave * 64;   // wave-uniform
+      if (ebase < a.in_pad4) bp_glds16(in_n + chunk * CC, (unsigned)s_g[i], buf * in_f + ebase * 4);
+    }
+  };
+  const bool pw_on = a.pw.scale != nullptr;
+  if (pw_on) {
+    for (int i = tid; i < a.cin; i += 256) {
+      lpw[i] = a.pw.scale[i]; lpw[a.cin + i] = a.pw.shift[i]; lpw[2 * a.cin + i] = a.pw.slope[i];
+    }
+    __syncthreads();
+  }
+  auto rewrite_input = [&](int chunk, int buf) {
+    PW4 p4;
+    p4.on = pw_on;
+    if (pw_on) {
+      const int ch = chunk * CC + c4 * 4;
+      const float4 sc = *reinterpret_cast<const float4*>(lpw + ch);
+      const float4 sf = *reinterpret_cast<const float4*>(lpw + a.cin + ch);
+      const float4 sl = *reinterpret_cast<const float4*>(lpw + 2 * a.cin + ch);
+      p4.sc[0] = sc.x; p4.sc[1] = sc.y; p4.sc[2] = sc.z; p4.sc[3] = sc.w;
+      p4.sf[0] = sf.x; p4.sf[1] = sf.y; p4.sf[2] = sf.z; p4.sf[3] = sf.w;
+      p4.sl[0] = sl.x; p4.sl[1] = sl.y; p4.sl[2] = sl.z; p4.sl[3] = sl.w;
+    }
+#pragma unroll
+    for (int i = 0; i < SLOTS; ++i) {
+      const int e = i * 256 + tid;
+      if (e < E) {
+        float4* q = reinterpret_cast<float4*>(smem + buf * in_f + e * 4);
+        if ((outside >> i) & 1u) *q = make_float4(0.f, 0.f, 0.f, 0.f);
+        else if (p4.on) *q = pw4_apply4(p4, *q);
+      }
+    }
+  };
+  // the TS tap slabs of group g of phase ph, channel chunk `chunk` -> ring slot
+  auto issue_group = [&](int chunk, int ph, int g, int slot) {
+    for (int k = wave; k < a.ts * SLAB_I; k += 4) {
+      const int tap = g * a.ts + k / SLAB_I, part = k % SLAB_I;
+      const int ty = tap / a.tapsx, tx = tap - ty * a.tapsx;
+      const float* src = a.wp + ((((int64_t)(ph * a.tapsy + ty) * a.tapsx + tx) * a.nchunk + chunk) *
+                                     a.cout_padP + co0) * CC + part * 256;
+      bp_glds16(src, (unsigned)lane * 16u, ring0 + slot * grp + k * 256);
+    }
+  };
+
+  const int G = a.tapsy * a.tapsx / a.ts;          // steps per (chunk, phase)
+  const bool single_step = NPH * G == 1;            // the next tile is issued and rewritten in the same step
+
+  issue_input(0, 0);
+  issue_group(0, NPH == 1 ? ph0 : 0, 0, 0);
+  bp_wait_dma();
+  rewrite_input(0, 0);
+
+  int slot = 0;
+  for (int chunk = 0; chunk < a.nchunk; ++chunk) {
+    const float* lin = smem + (a.in_bufs == 2 ? (chunk & 1) * in_f : 0);
+#pragma unroll
+    for (int p = 0; p < NPH; ++p) {
+      const int ph = NPH == 1 ? ph0 : p;
+      const int ppy = ph / a.nphase, ppx = ph % a.nphase;
+      // this phase's first gathered row / column relative to the tile origin
+      const int dy = (NPH > 1 && a.transposed) ? bp_t_i0(ppy, a.pad, a.stride, a.tapsy) - iy0 : 0;
+      const int dx = (NPH > 1 && a.transposed) ? bp_t_i0(ppx, a.pad, a.stride, a.tapsy) - ix0 : 0;
+      for (int g = 0; g < G; ++g) {
+        bp_wait_dma_barrier();   // group (chunk, p, g) and a pending input tile have landed; the previous step is read out
+        const bool first = (p == 0 && g == 0), last = (p == NPH - 1 && g == G - 1);
+        if (first && chunk + 1 < a.nchunk) issue_input(chunk + 1, (chunk + 1) & 1);
+        {
+          int ng = g + 1, nch = chunk;
+          int nph = ph;
+          if (ng == G) {
+            ng = 0;
+            if (NPH == 1) ++nch;
+            else if (p + 1 < NPH) nph = p + 1;
+            else { nph = 0; ++nch; }
+          }
+          if (nch < a.nchunk) issue_group(nch, nph, ng, slot ^ 1);
+        }
+        const float* lw = smem + ring0 + slot * grp;
+        slot ^= 1;
+        for (int t = 0; t < a.ts; ++t) {
+          const int tap = g * a.ts + t;
+          const int ty = tap / a.tapsx, tx = tap - ty * a.tapsx;
+          const int ey = dy + ty, ex = dx + tx;
+          const int tapoff = ((ey * a.ISx + ex % a.ISx) * a.IWq + ex / a.ISx) * CC;
+          float af[MT][VW], bf[NT][VW];
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) lds_read<VW>(lin + abase[mt] + tapoff, af[mt]);
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) lds_read<VW>(lw + t * SLAB + bbase[nt], bf[nt]);
+#pragma unroll
+          for (int s = 0; s < VW; ++s)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+              for (int nt = 0; nt < NT; ++nt)
+                acc[p][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[nt][s], af[mt][s], acc[p][mt][nt], 0, 0, 0);
+        }
+        if (last && chunk + 1 < a.nchunk) {
+          if (single_step) bp_wait_dma();
+          rewrite_input(chunk + 1, (chunk + 1) & 1);
+        }
+      }
+    }
+  }
+
+  float* out_n = a.out + (int64_t)n * a.out_h * a.out_w * a.out_cs + a.out_co;
+#pragma unroll
+  for (int p = 0; p < NPH; ++p) {
+    const int ph = NPH == 1 ? ph0 : p;
+    const int py = ph / a.nphase, px = ph % a.nphase;
+    const int qh = (a.out_h - py + a.OS - 1) / a.OS;
+    const int qw = a.PP > 1 ? (a.out_w + a.PP - 1) / a.PP : (a.out_w - px + a.OS - 1) / a.OS;
+    igemm_store<NT, MT>(a, acc[p], out_n, wm, 0, lm, kq, co0, qy0, qx0, qh, qw, py, px);
+  }
+}
+
 // weights: torch layout -> [phase][ty][tx][chunk][cout_padP][CC]
 struct PackArgs {
   const float* w; float* dst;
@@ -519,6 +738,9 @@ struct IgemmConfig {
   int NW, in_pad4, slots;
   TileGeom td;
   size_t lds_dma;
+  // igemm_dmaf_kernel (NT <= 2): taps per step, fused output phases (1 or 4), input buffers
+  bool dmaf;
+  int ts, nph, in_bufs;
 };
 
 IgemmConfig igemm_config(const ConvGeom& g) {
@@ -549,7 +771,39 @@ IgemmConfig igemm_config(const ConvGeom& g) {
   // least two (eight waves) or three (four waves) workgroups per CU.
   static const bool no_dma = getenv("BP_IGEMM_NODMA") != nullptr;
   static const bool no_nw8 = getenv("BP_IGEMM_NONW8") != nullptr;
-  if (c.PP == 1 && g.taps * c.tapsx >= 2 && !no_dma) {
+  static const bool no_dmaf = getenv("BP_IGEMM_NODMAF") != nullptr;
+  if (c.NT <= 2 && c.PP == 1 && !no_dma && !no_dmaf) {   // (pixel-packed heads measured slower here)
+    const int T = g.taps * c.tapsx;
+    for (int CC = cc_first; CC >= 8 && !c.dma; CC /= 2) {
+      if (g.cin_g % CC != 0 || (c.COB * CC) % 256 != 0) continue;
+      // all stride^2 phases of a transposed form in one workgroup (one accumulator set per phase)
+      const int nph = (g.gather_transposed && g.nphase == 2) ? 4 : 1;
+      const int need = bp_ceil_div(64, c.NT * CC);              // taps per step for >= 64 MFMAs per wave
+      const int ts = need <= 1 ? 1 : (need <= c.tapsx ? c.tapsx : T);
+      TileGeom td = tile_geom(16, g.IS, c.ISx, g.taps, c.tapsx);
+      if (nph > 1) {
+        const int spread = bp_t_i0(g.nphase - 1, g.pad, g.stride, g.taps) - bp_t_i0(0, g.pad, g.stride, g.taps);
+        td.IH += spread; td.IW += spread;
+        td.IWq = bp_ceil_div(td.IW, c.ISx);
+      }
+      const int nchunk = g.cin_g / CC;
+      const int in_bufs = nchunk > 1 ? 2 : 1;
+      const int E = td.IH * c.ISx * td.IWq * (CC / 4);
+      const int in_pad4 = bp_round_up(E, 64);
+      const int per_thread = bp_ceil_div(in_pad4, 256);
+      const size_t lds_dma = ((size_t)in_bufs * in_pad4 * 4 + (size_t)2 * ts * c.COB * CC + (size_t)3 * g.cin_g) * sizeof(float);
+      const TileGeom t4 = tile_geom(16, g.IS, c.ISx, g.taps, c.tapsx);
+      const bool plain_ok = plain_lds(t4, CC) <= 64 * 1024 ||
+                            plain_lds(tile_geom(4, g.IS, c.ISx, g.taps, c.tapsx), CC) <= 64 * 1024;
+      if (lds_dma <= 80 * 1024 && per_thread <= 16 && plain_ok) {
+        c.dma = true; c.dmaf = true; c.NW = 4; c.td = td; c.in_pad4 = in_pad4;
+        c.slots = per_thread <= 3 ? 3 : (per_thread <= 6 ? 6 : 16);
+        c.lds_dma = lds_dma; c.ts = ts; c.nph = nph; c.in_bufs = in_bufs;
+        c.CC = CC;
+      }
+    }
+  }
+  if (!c.dma && c.PP == 1 && g.taps * c.tapsx >= 2 && !no_dma) {
     for (int NW = (c.NT == 4 && c.WN == 2 && !no_nw8) ? 8 : 4; NW >= 4 && !c.dma; NW -= 4) {
       for (int CC = cc_first; CC >= 8 && !c.dma; CC /= 2) {
         if (g.cin_g % CC != 0 || (c.COB * CC) % 256 != 0) continue;
@@ -622,6 +876,36 @@ int launch_dma_cc(const IgemmConfig& c, const IgemmArgs& a, dim3 grid, hipStream
   return BP_EUNSUPPORTED;
 }
 
+template <int CC, int NT, int SLOTS, int NPH>
+int launch_dmaf_one(const IgemmConfig& c, const IgemmArgs& a, dim3 grid, hipStream_t st) {
+  static const hipError_t optin = hipFuncSetAttribute(
+      reinterpret_cast<const void*>(&igemm_dmaf_kernel<CC, NT, SLOTS, NPH>),
+      hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+  if (optin != hipSuccess) return BP_ELAUNCH;
+  hipLaunchKernelGGL((igemm_dmaf_kernel<CC, NT, SLOTS, NPH>), grid, dim3(256), c.lds_dma, st, a);
+  BP_CHECK_LAUNCH();
+  return BP_OK;
+}
+
+template <int CC, int NT>
+int launch_dmaf_nt(const IgemmConfig& c, const IgemmArgs& a, dim3 grid, hipStream_t st) {
+  if (c.nph == 4) {
+    if (c.slots == 3) return launch_dmaf_one<CC, NT, 3, 4>(c, a, grid, st);
+    if (c.slots == 6) return launch_dmaf_one<CC, NT, 6, 4>(c, a, grid, st);
+    return launch_dmaf_one<CC, NT, 16, 4>(c, a, grid, st);
+  }
+  if (c.slots == 3) return launch_dmaf_one<CC, NT, 3, 1>(c, a, grid, st);
+  if (c.slots == 6) return launch_dmaf_one<CC, NT, 6, 1>(c, a, grid, st);
+  return launch_dmaf_one<CC, NT, 16, 1>(c, a, grid, st);
+}
+
+int launch_dmaf(const IgemmConfig& c, const IgemmArgs& a, dim3 grid, hipStream_t st) {
+  if (c.CC == 16 && c.NT == 1) return launch_dmaf_nt<16, 1>(c, a, grid, st);
+  if (c.CC == 16 && c.NT == 2) return launch_dmaf_nt<16, 2>(c, a, grid, st);
+  if (c.CC == 8 && c.NT == 2) return launch_dmaf_nt<8, 2>(c, a, grid, st);
+  return BP_EUNSUPPORTED;
+}
+
 int launch_dma(const IgemmConfig& c, const IgemmArgs& a, dim3 grid, hipStream_t st) {
   if (c.CC == 16) return c.slots == 3 ? launch_dma_cc<16, 3>(c, a, grid, st) : launch_dma_cc<16, 6>(c, a, grid, st);
   if (c.CC == 8) return c.slots == 3 ? launch_dma_cc<8, 3>(c, a, grid, st) : launch_dma_cc<8, 6>(c, a, grid, st);
@@ -642,7 +926,7 @@ int launch_mt(const IgemmConfig& c, const IgemmArgs& a, dim3 grid, hipStream_t s
 
 int bp_igemm_kernel_id(const ConvGeom& g) {
   const IgemmConfig c = igemm_config(g);
-  return c.ok ? (c.dma ? 100000 * (c.NW / 4) : 0) + c.CC * 1000 + c.NT * 100 + c.WN * 10 + c.MT : -1;
+  return c.ok ? (c.dma ? 100000 * (c.dmaf ? 3 : c.NW / 4) : 0) + c.CC * 1000 + c.NT * 100 + c.WN * 10 + c.MT : -1;
 }
 
 int64_t bp_igemm_packed_floats(const ConvGeom& g) {
@@ -687,10 +971,11 @@ int bp_igemm_run(const ConvGeom& g, const bp_view* in, const PW& pw, const float
   const int qh = bp_ceil_div(out->h, g.OS), qw = c.PP > 1 ? bp_ceil_div(out->w, c.PP) : bp_ceil_div(out->w, g.OS);
   a.tiles_x = bp_ceil_div(qw, 16 * t.TPR);
   a.tiles_y = bp_ceil_div(qh, t.BH);
-  const int64_t gz = (int64_t)in->n * g.nphase * g.nphase;
+  const int64_t gz = (int64_t)in->n * ((dma && c.dmaf && c.nph > 1) ? 1 : g.nphase * g.nphase);
   if (gz > 65535 || c.cout_padP / c.COB > 65535) return BP_EUNSUPPORTED;
   dim3 grid((unsigned)(a.tiles_x * a.tiles_y), (unsigned)(c.cout_padP / c.COB), (unsigned)gz);
-  a.in_pad4 = c.in_pad4;
+  a.in_pad4 = c.in_pad4; a.ts = c.ts; a.in_bufs = c.in_bufs;
+  if (dma && c.dmaf) return launch_dmaf(c, a, grid, st);
   if (dma) return launch_dma(c, a, grid, st);
   if (c.MT == 4) return launch_mt<4>(c, a, grid, st);
   return launch_mt<1>(c, a, grid, st);

@@ -72,7 +72,8 @@ const char* bp_strerror(int code);
 int64_t bp_conv_packed_floats(const bp_conv* cv, int dir);
 
 /* Which igemm_kernel<CC,NT,WN,MT> instantiation serves this layer/direction, encoded as
- * CC*1000 + NT*100 + WN*10 + MT, plus 100000 x (waves per workgroup / 4) when it is the LDS-DMA pipelined igemm_dma_kernel
+ * CC*1000 + NT*100 + WN*10 + MT, plus 100000 / 200000 for the LDS-DMA pipelined igemm_dma_kernel with 4 / 8 waves and 300000 for
+ * igemm_dmaf_kernel (tap groups, fused output phases)
  * (so a profile's kernel names can be matched to layers). */
 int bp_conv_kernel_id(const bp_conv* cv, int dir);
 
