@@ -4,7 +4,7 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SOURCES = ["conv_direct.hip", "conv_igemm.hip", "conv_wgrad.hip", "conv_wgrad_tiles.hip", "conv_wgrad_small.hip", "pointwise.hip", "capi.hip"]
+SOURCES = ["conv_direct.hip", "conv_igemm.hip", "conv_small.hip", "conv_wgrad.hip", "conv_wgrad_tiles.hip", "conv_wgrad_small.hip", "pointwise.hip", "capi.hip"]
 OUT = os.path.join(os.path.dirname(HERE), "libbp_hip.so")
 
 

@@ -924,12 +924,22 @@ int launch_mt(const IgemmConfig& c, const IgemmArgs& a, dim3 grid, hipStream_t s
 
 }  // namespace
 
+// conv_small.hip: vector-ALU kernel for unit-stride layers with cin*cout <= 8
+bool bp_small_ok(const ConvGeom& g);
+int64_t bp_small_packed_floats(const ConvGeom& g);
+int bp_small_kernel_id(const ConvGeom& g);
+int bp_small_pack(const ConvGeom& g, const WeightMap& wm, const float* w_torch, float* packed, hipStream_t st);
+int bp_small_run(const ConvGeom& g, const bp_view* in, const PW& pw, const float* packed, const float* bias,
+                 const bp_view* out, hipStream_t st);
+
 int bp_igemm_kernel_id(const ConvGeom& g) {
+  if (bp_small_ok(g)) return bp_small_kernel_id(g);
   const IgemmConfig c = igemm_config(g);
   return c.ok ? (c.dma ? 100000 * (c.dmaf ? 3 : c.NW / 4) : 0) + c.CC * 1000 + c.NT * 100 + c.WN * 10 + c.MT : -1;
 }
 
 int64_t bp_igemm_packed_floats(const ConvGeom& g) {
+  if (bp_small_ok(g)) return bp_small_packed_floats(g);
   const IgemmConfig c = igemm_config(g);
   if (!c.ok) return -1;
   return (int64_t)g.nphase * g.nphase * g.taps * c.tapsx * c.nchunk * c.cout_padP * c.CC;
@@ -937,6 +947,7 @@ int64_t bp_igemm_packed_floats(const ConvGeom& g) {
 
 int bp_igemm_pack(const ConvGeom& g, const WeightMap& wm, const float* w_torch, float* packed,
                   hipStream_t st) {
+  if (bp_small_ok(g)) return bp_small_pack(g, wm, w_torch, packed, st);
   const IgemmConfig c = igemm_config(g);
   if (!c.ok) return BP_EUNSUPPORTED;
   PackArgs a{};
@@ -952,6 +963,7 @@ int bp_igemm_pack(const ConvGeom& g, const WeightMap& wm, const float* w_torch, 
 
 int bp_igemm_run(const ConvGeom& g, const bp_view* in, const PW& pw, const float* packed,
                  const float* bias, const bp_view* out, hipStream_t st) {
+  if (bp_small_ok(g)) return bp_small_run(g, in, pw, packed, bias, out, st);
   const IgemmConfig c = igemm_config(g);
   if (!c.ok) return BP_EUNSUPPORTED;
   IgemmArgs a{};

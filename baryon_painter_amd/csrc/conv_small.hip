@@ -1,0 +1,202 @@
+// Unit-stride convolutions with a handful of channel pairs (8->1 k5, 1->8 k5, 1->1 k3: the last layers of
+// the generator heads and their data gradients) on the vector ALUs, NHWC.
+//
+// With cin*cout <= 8 a 16x16x4 matrix tile is >= 87 % padding and the layer is bound by the bytes of its
+// full-resolution tensors, so this kernel is built around HBM and LDS traffic instead:
+//   * a workgroup stages a (16+K-1) x (64+K-1) input tile once, applying the producer's pending activation and
+//     the zero padding, as channel-quad planes [row][quad][x][4] (adjacent lanes -> adjacent 16 bytes);
+//   * a thread owns ONE column and 4 consecutive output rows: it walks the 4+K-1 input rows of its column
+//     window once, and every value it reads feeds up to 4 rows x CO accumulators (vertical sliding window),
+//     so all lanes of a wave read consecutive LDS addresses: conflict-free b128/b32 reads;
+//   * the K*K*CI*CO weights are pre-packed in correlation order [ty][tx][ci][co]; their addresses are
+//     compile-time offsets from a kernel argument, i.e. scalar loads: FMA operands come from SGPRs.
+// The same kernel serves the forward of a Conv2d (taps ascending, origin -pad) and the data gradient of a
+// unit-stride Conv2d (taps reversed by the packing, origin pad-(K-1)).
+#include "common.hpp"
+#include <cstdlib>
+
+namespace {
+
+struct SmallArgs {
+  const float* in; int in_h, in_w, in_cs, in_co;
+  float* out; int out_h, out_w, out_cs, out_co;
+  const float* wp; const float* bias;
+  PW pw;
+  int i0;            // first gathered row/column relative to the output position
+  int tiles_x, tiles_y;
+  int in_vec, out_vec;
+};
+
+template <int K, int CI, int CO>
+__global__ __launch_bounds__(256) void small_conv_kernel(SmallArgs a) {
+  constexpr int TW = 64, TH = 16, PXR = 4;
+  constexpr int IW = TW + K - 1, IH = TH + K - 1;
+  constexpr int CQ = CI >= 4 ? CI / 4 : 1;      // channel quads
+  constexpr int CV = CI >= 4 ? 4 : CI;          // floats per LDS element
+  __shared__ __attribute__((aligned(16))) float tile[IH * CQ * IW * CV];
+
+  const int tid = threadIdx.x;
+  const int tx_ = blockIdx.x % a.tiles_x, ty_ = blockIdx.x / a.tiles_x;
+  const int n = blockIdx.y;
+  const int x0 = tx_ * TW, y0 = ty_ * TH;
+  const float* in_n = a.in + (int64_t)n * a.in_h * a.in_w * a.in_cs + a.in_co;
+
+  // ---- stage the tile (activation applied, zero outside the image)
+  if (CI >= 4) {
+    const int c4 = tid % CQ;
+    const PW4 p4 = pw4_load(a.pw, c4 * 4, CI);
+    for (int e = tid; e < IH * IW * CQ; e += 256) {
+      const int pix = e / CQ;
+      const int c = pix % IW, r = pix / IW;
+      const int iy = y0 + a.i0 + r, ix = x0 + a.i0 + c;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (iy >= 0 && iy < a.in_h && ix >= 0 && ix < a.in_w) {
+        const float* p = in_n + ((int64_t)iy * a.in_w + ix) * a.in_cs + c4 * 4;
+        if (a.in_vec) v = *reinterpret_cast<const float4*>(p);
+        else v = make_float4(p[0], p[1], p[2], p[3]);
+        v = pw4_apply4(p4, v);
+      }
+      *reinterpret_cast<float4*>(tile + ((r * CQ + c4) * IW + c) * 4) = v;
+    }
+  } else {
+    for (int e = tid; e < IH * IW * CI; e += 256) {
+      const int ch = e % CI;
+      const int pix = e / CI;
+      const int c = pix % IW, r = pix / IW;
+      const int iy = y0 + a.i0 + r, ix = x0 + a.i0 + c;
+      float v = 0.f;
+      if (iy >= 0 && iy < a.in_h && ix >= 0 && ix < a.in_w)
+        v = pw_apply(a.pw, ch, in_n[((int64_t)iy * a.in_w + ix) * a.in_cs + ch]);
+      tile[(r * IW + c) * CI + ch] = v;
+    }
+  }
+  __syncthreads();
+
+  // ---- thread = column `col`, output rows r0 .. r0+3
+  const int col = tid & 63, r0 = (tid >> 6) * PXR;
+  float acc[PXR][CO];
+#pragma unroll
+  for (int j = 0; j < PXR; ++j)
+#pragma unroll
+    for (int co = 0; co < CO; ++co) acc[j][co] = a.bias ? a.bias[co] : 0.f;
+
+  // kx outermost and NOT unrolled: only the K*CI*CO weights of one tap column are live in SGPRs at a time
+  // (all K*K*CI*CO would spill).
+#pragma unroll 1
+  for (int kx = 0; kx < K; ++kx) {
+    const float* wk = a.wp + kx * CI * CO;
+#pragma unroll
+    for (int dy = 0; dy < PXR + K - 1; ++dy) {
+      float v[CI];
+      if constexpr (CI >= 4) {
+#pragma unroll
+        for (int q = 0; q < CQ; ++q) {
+          const float4 t = *reinterpret_cast<const float4*>(tile + (((r0 + dy) * CQ + q) * IW + col + kx) * 4);
+          v[q * 4 + 0] = t.x; v[q * 4 + 1] = t.y; v[q * 4 + 2] = t.z; v[q * 4 + 3] = t.w;
+        }
+      } else {
+#pragma unroll
+        for (int ci = 0; ci < CI; ++ci) v[ci] = tile[((r0 + dy) * IW + col + kx) * CI + ci];
+      }
+#pragma unroll
+      for (int j = 0; j < PXR; ++j) {
+        const int ky = dy - j;               // compile-time after unrolling
+        if (ky >= 0 && ky < K) {
+#pragma unroll
+          for (int ci = 0; ci < CI; ++ci)
+#pragma unroll
+            for (int co = 0; co < CO; ++co)
+              acc[j][co] = fmaf(v[ci], wk[(ky * K * CI + ci) * CO + co], acc[j][co]);
+        }
+      }
+    }
+  }
+
+  float* out_n = a.out + (int64_t)n * a.out_h * a.out_w * a.out_cs + a.out_co;
+  const int X = x0 + col;
+  if (X < a.out_w) {
+#pragma unroll
+    for (int j = 0; j < PXR; ++j) {
+      const int Y = y0 + r0 + j;
+      if (Y < a.out_h) {
+        float* o = out_n + ((int64_t)Y * a.out_w + X) * a.out_cs;
+        if (CO % 4 == 0 && a.out_vec) {
+#pragma unroll
+          for (int q = 0; q < CO / 4; ++q)
+            *reinterpret_cast<float4*>(o + q * 4) =
+                make_float4(acc[j][q * 4], acc[j][q * 4 + 1], acc[j][q * 4 + 2], acc[j][q * 4 + 3]);
+        } else {
+#pragma unroll
+          for (int co = 0; co < CO; ++co) o[co] = acc[j][co];
+        }
+      }
+    }
+  }
+}
+
+struct SmallPackArgs {
+  const float* w; float* dst;
+  int64_t sa, sb;
+  int k, ci, co, flip, total;
+};
+
+__global__ void small_pack_kernel(SmallPackArgs a) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.total) return;
+  int r = i;
+  const int co = r % a.co; r /= a.co;
+  const int ci = r % a.ci; r /= a.ci;
+  const int tx = r % a.k, ty = r / a.k;
+  const int ky = a.flip ? a.k - 1 - ty : ty, kx = a.flip ? a.k - 1 - tx : tx;
+  a.dst[i] = a.w[ci * a.sa + co * a.sb + ky * a.k + kx];
+}
+
+template <int K, int CI, int CO>
+int launch(const SmallArgs& a, int n, hipStream_t st) {
+  hipLaunchKernelGGL((small_conv_kernel<K, CI, CO>), dim3((unsigned)(a.tiles_x * a.tiles_y), (unsigned)n), dim3(256), 0,
+                     st, a);
+  BP_CHECK_LAUNCH();
+  return BP_OK;
+}
+
+}  // namespace
+
+// Does (k, gathered channels, produced channels) of this unit-stride correlation have an instantiation?
+bool bp_small_ok(const ConvGeom& g) {
+  static const bool off = getenv("BP_NOSMALL") != nullptr;
+  if (off || g.IS != 1 || g.OS != 1 || g.nphase != 1 || g.stride != 1) return false;
+  return (g.k == 5 && g.cin_g == 8 && g.cout_g == 1) || (g.k == 5 && g.cin_g == 1 && g.cout_g == 8) ||
+         (g.k == 3 && g.cin_g == 1 && g.cout_g == 1);
+}
+
+int64_t bp_small_packed_floats(const ConvGeom& g) { return (int64_t)g.k * g.k * g.cin_g * g.cout_g; }
+
+int bp_small_kernel_id(const ConvGeom& g) { return 900000 + g.k * 100 + g.cin_g * 10 + g.cout_g; }
+
+int bp_small_pack(const ConvGeom& g, const WeightMap& wm, const float* w_torch, float* packed, hipStream_t st) {
+  SmallPackArgs a{};
+  a.w = w_torch; a.dst = packed; a.sa = wm.sa; a.sb = wm.sb;
+  a.k = g.k; a.ci = g.cin_g; a.co = g.cout_g; a.flip = g.gather_transposed;
+  a.total = (int)bp_small_packed_floats(g);
+  hipLaunchKernelGGL(small_pack_kernel, dim3((unsigned)((a.total + 255) / 256)), dim3(256), 0, st, a);
+  BP_CHECK_LAUNCH();
+  return BP_OK;
+}
+
+int bp_small_run(const ConvGeom& g, const bp_view* in, const PW& pw, const float* packed, const float* bias,
+                 const bp_view* out, hipStream_t st) {
+  SmallArgs a{};
+  a.in = in->ptr; a.in_h = in->h; a.in_w = in->w; a.in_cs = in->cstride; a.in_co = in->coff;
+  a.out = out->ptr; a.out_h = out->h; a.out_w = out->w; a.out_cs = out->cstride; a.out_co = out->coff;
+  a.wp = packed; a.bias = bias; a.pw = pw;
+  a.i0 = g.gather_transposed ? bp_t_i0(0, g.pad, 1, g.k) : -g.pad;
+  a.tiles_x = bp_ceil_div(out->w, 64);
+  a.tiles_y = bp_ceil_div(out->h, 16);
+  a.in_vec = bp_view_vec4(in) ? 1 : 0;
+  a.out_vec = bp_view_vec4(out) ? 1 : 0;
+  if (in->n > 65535) return BP_EUNSUPPORTED;
+  if (g.k == 5 && g.cin_g == 8 && g.cout_g == 1) return launch<5, 8, 1>(a, in->n, st);
+  if (g.k == 5 && g.cin_g == 1 && g.cout_g == 8) return launch<5, 1, 8>(a, in->n, st);
+  if (g.k == 3 && g.cin_g == 1 && g.cout_g == 1) return launch<3, 1, 1>(a, in->n, st);
+  return BP_EUNSUPPORTED;
+}

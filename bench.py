@@ -40,6 +40,8 @@ def kernel_name(kind, unit, lib):
             return "wgrad_small_kernel[k%ds%d %d,%d]" % (cv.k, cv.stride, cx, cy)
         return "wgrad_tiles_kernel[k%ds%d %s]" % (cv.k, cv.stride, "wide" if (cx > 16 and cy > 16) else "thin")
     kid = lib.bp_conv_kernel_id(C.byref(unit.cv), L.PACK_FWD if kind == "forward" else L.PACK_BWD)
+    if kid >= 900000:
+        return "small_conv_kernel<%d,%d,%d>" % (kid // 100 % 100, kid // 10 % 10, kid % 10)
     dma, kid = divmod(kid, 100000)
     return "%s<%d,%d,%d,%d>" % (("igemm_kernel", "igemm_dma_kernel", "igemm_dma8_kernel", "igemm_dmaf_kernel")[dma], kid // 1000,
                                 kid // 100 % 10, kid // 10 % 10, kid % 10)
