@@ -3,10 +3,10 @@
 //
 // With cin*cout <= 8 a 16x16x4 matrix tile is >= 87 % padding and the layer is bound by the bytes of its
 // full-resolution tensors, so this kernel is built around HBM and LDS traffic instead:
-//   * a workgroup stages a (16+K-1) x (64+K-1) input tile once, applying the producer's pending activation and
+//   * a workgroup stages a (TH+K-1) x (64+K-1) input tile once (TH = 16 rows, 8 where LDS demands), applying the producer's pending activation and
 //     the zero padding, as channel-quad planes [row][quad][x][4] (adjacent lanes -> adjacent 16 bytes);
-//   * a thread owns ONE column and 4 consecutive output rows: it walks the 4+K-1 input rows of its column
-//     window once, and every value it reads feeds up to 4 rows x CO accumulators (vertical sliding window),
+//   * a thread owns ONE column and TH/4 consecutive output rows: it walks the input rows of its column
+//     window once, and every value it reads feeds up to TH/4 rows x CO accumulators (vertical sliding window),
 //     so all lanes of a wave read consecutive LDS addresses: conflict-free b128/b32 reads;
 //   * the K*K*CI*CO weights are pre-packed in correlation order [ty][tx][ci][co]; their addresses are
 //     compile-time offsets from a kernel argument, i.e. scalar loads: FMA operands come from SGPRs.
@@ -27,9 +27,9 @@ struct SmallArgs {
   int in_vec, out_vec;
 };
 
-template <int K, int CI, int CO>
+template <int K, int CI, int CO, int TH>
 __global__ __launch_bounds__(256) void small_conv_kernel(SmallArgs a) {
-  constexpr int TW = 64, TH = 16, PXR = 4;
+  constexpr int TW = 64, PXR = TH / 4;   // 4 waves x PXR rows
   constexpr int IW = TW + K - 1, IH = TH + K - 1;
   constexpr int CQ = CI >= 4 ? CI / 4 : 1;      // channel quads
   constexpr int CV = CI >= 4 ? 4 : CI;          // floats per LDS element
@@ -151,10 +151,12 @@ __global__ void small_pack_kernel(SmallPackArgs a) {
   a.dst[i] = a.w[ci * a.sa + co * a.sb + ky * a.k + kx];
 }
 
-template <int K, int CI, int CO>
-int launch(const SmallArgs& a, int n, hipStream_t st) {
-  hipLaunchKernelGGL((small_conv_kernel<K, CI, CO>), dim3((unsigned)(a.tiles_x * a.tiles_y), (unsigned)n), dim3(256), 0,
-                     st, a);
+template <int K, int CI, int CO, int TH>
+int launch(SmallArgs a, const bp_view* out, int n, hipStream_t st) {
+  a.tiles_x = bp_ceil_div(out->w, 64);
+  a.tiles_y = bp_ceil_div(out->h, TH);
+  hipLaunchKernelGGL((small_conv_kernel<K, CI, CO, TH>), dim3((unsigned)(a.tiles_x * a.tiles_y), (unsigned)n),
+                     dim3(256), 0, st, a);
   BP_CHECK_LAUNCH();
   return BP_OK;
 }
@@ -166,12 +168,12 @@ bool bp_small_ok(const ConvGeom& g) {
   static const bool off = getenv("BP_NOSMALL") != nullptr;
   if (off || g.IS != 1 || g.OS != 1 || g.nphase != 1 || g.stride != 1) return false;
   return (g.k == 5 && g.cin_g == 8 && g.cout_g == 1) || (g.k == 5 && g.cin_g == 1 && g.cout_g == 8) ||
-         (g.k == 3 && g.cin_g == 1 && g.cout_g == 1);
+         (g.k == 5 && g.cin_g == 16 && g.cout_g == 1) || (g.k == 3 && g.cin_g == 1 && g.cout_g == 1);
 }
 
 int64_t bp_small_packed_floats(const ConvGeom& g) { return (int64_t)g.k * g.k * g.cin_g * g.cout_g; }
 
-int bp_small_kernel_id(const ConvGeom& g) { return 900000 + g.k * 100 + g.cin_g * 10 + g.cout_g; }
+int bp_small_kernel_id(const ConvGeom& g) { return 900000 + g.k * 1000 + g.cin_g * 10 + g.cout_g; }
 
 int bp_small_pack(const ConvGeom& g, const WeightMap& wm, const float* w_torch, float* packed, hipStream_t st) {
   SmallPackArgs a{};
@@ -190,13 +192,12 @@ int bp_small_run(const ConvGeom& g, const bp_view* in, const PW& pw, const float
   a.out = out->ptr; a.out_h = out->h; a.out_w = out->w; a.out_cs = out->cstride; a.out_co = out->coff;
   a.wp = packed; a.bias = bias; a.pw = pw;
   a.i0 = g.gather_transposed ? bp_t_i0(0, g.pad, 1, g.k) : -g.pad;
-  a.tiles_x = bp_ceil_div(out->w, 64);
-  a.tiles_y = bp_ceil_div(out->h, 16);
   a.in_vec = bp_view_vec4(in) ? 1 : 0;
   a.out_vec = bp_view_vec4(out) ? 1 : 0;
   if (in->n > 65535) return BP_EUNSUPPORTED;
-  if (g.k == 5 && g.cin_g == 8 && g.cout_g == 1) return launch<5, 8, 1>(a, in->n, st);
-  if (g.k == 5 && g.cin_g == 1 && g.cout_g == 8) return launch<5, 1, 8>(a, in->n, st);
-  if (g.k == 3 && g.cin_g == 1 && g.cout_g == 1) return launch<3, 1, 1>(a, in->n, st);
+  if (g.k == 5 && g.cin_g == 8 && g.cout_g == 1) return launch<5, 8, 1, 16>(a, out, in->n, st);
+  if (g.k == 5 && g.cin_g == 1 && g.cout_g == 8) return launch<5, 1, 8, 16>(a, out, in->n, st);
+  if (g.k == 5 && g.cin_g == 16 && g.cout_g == 1) return launch<5, 16, 1, 8>(a, out, in->n, st);
+  if (g.k == 3 && g.cin_g == 1 && g.cout_g == 1) return launch<3, 1, 1, 16>(a, out, in->n, st);
   return BP_EUNSUPPORTED;
 }

@@ -18,7 +18,7 @@ import torch
 
 from .. import _lib as L
 from .arch import conv_block, conv_down, conv_up, res_block  # noqa: F401  (reference: ``from .utils import *``)
-from .graph import (PW, Slot, build_holders, compile_sequential, probe_output, _stream)
+from .graph import (PW, ConvUnit, Slot, build_holders, compile_sequential, probe_output, _stream)
 
 pi = math.pi
 
@@ -118,6 +118,8 @@ class _Plan:
             raise NotImplementedError("p_z_in must end in a convolution")
         ub, sb, tr = compile_sequential(self, "p_y_z_in.", a["p_y_z_in"], model.p_y_z_in, self.p_in)
         self._no_trailing(tr, "p_y_z_in")
+        if ub and isinstance(ub[0], ConvUnit):
+            ub[0].restrict_dgrad(0, c_hz)      # y and the aux label are data: only h_z carries a gradient
         self.g_units = [uz, ub]
         self.h = sb
         um, sm, tr = compile_sequential(self, "p_mu_out.", a["p_y_z_out"][0], model.p_mu_out, sb)

@@ -291,13 +291,39 @@ class ConvUnit:
         self.packed_bwd = torch.zeros(n_bwd, device=dev) if need_dgrad else None
         self._packed_version = None
         self.dx = None
+        self.dgrad_slice = None        # (c0, c1): only these input channels need a gradient
+        self._sub = None
         plan.need_ws(lib.bp_channel_sums_workspace(C.byref(self.out.view)))
 
-    def macs(self):
-        """Multiply-accumulates of one forward (= of each of the two gradients)."""
+    def restrict_dgrad(self, c0, c1):
+        """Only input channels [c0, c1) carry a gradient (the rest of a concatenated input is data): the data
+        gradient then runs as a (c1-c0)-channel layer on a copy of that weight slice."""
+        cv = self.cv
+        if not (0 <= c0 < c1 <= cv.cin) or self.dx is not None:
+            raise ValueError(f"{self.name}: bad gradient channel range or backward already prepared")
+        if (c0, c1) == (0, cv.cin) or not self.need_dgrad:
+            return
+        lib, dev = self.plan.lib, self.plan.device
+        sub = L.Conv(cv.transposed, c1 - c0, cv.cout, cv.k, cv.stride, cv.pad, cv.out_pad)
+        n_bwd = lib.bp_conv_packed_floats(C.byref(sub), L.PACK_BWD)
+        if n_bwd <= 0:
+            return                      # no kernel for the narrower layer: keep the full data gradient
+        w = self.holder.weight
+        shape = (c1 - c0, cv.cout, cv.k, cv.k) if cv.transposed else (cv.cout, c1 - c0, cv.k, cv.k)
+        self.dgrad_slice = (c0, c1)
+        self._sub = {"cv": sub, "w": torch.zeros(shape, device=dev, dtype=w.dtype),
+                     "packed": torch.zeros(n_bwd, device=dev)}
+        self.packed_bwd = None
+
+    def macs(self, kind="forward"):
+        """Multiply-accumulates of one forward (= of each of the two gradients; fewer for a data gradient
+        restricted to a channel slice)."""
         cv = self.cv
         dense = self.inp if cv.transposed else self.out       # the grid every tap visits
-        return dense.n * dense.h * dense.w * cv.k * cv.k * cv.cin * cv.cout
+        cin = cv.cin
+        if kind == "backward_data" and self.dgrad_slice is not None:
+            cin = self.dgrad_slice[1] - self.dgrad_slice[0]
+        return dense.n * dense.h * dense.w * cv.k * cv.k * cin * cv.cout
 
     # ---- weights
     def maybe_pack(self):
@@ -309,6 +335,13 @@ class ConvUnit:
         L.check(lib.bp_conv_pack(C.byref(self.cv), L.PACK_FWD, L.ptr(w), L.ptr(self.packed_fwd), st), "pack")
         if self.packed_bwd is not None:
             L.check(lib.bp_conv_pack(C.byref(self.cv), L.PACK_BWD, L.ptr(w), L.ptr(self.packed_bwd), st), "pack")
+        if self._sub is not None:
+            c0, c1 = self.dgrad_slice
+            sub = self._sub
+            with torch.no_grad():
+                sub["w"].copy_(w[c0:c1] if self.cv.transposed else w[:, c0:c1])
+            L.check(lib.bp_conv_pack(C.byref(sub["cv"]), L.PACK_BWD, L.ptr(sub["w"]), L.ptr(sub["packed"]), st),
+                    "pack")
         self._packed_version = ver
 
     # ---- forward
@@ -354,6 +387,10 @@ class ConvUnit:
         self.plan.need_ws(lib.bp_conv_backward_weight_workspace(C.byref(self.cv), C.byref(self.inp.view),
                                                                 C.byref(self.out.view)))
         self.dx = self.inp.claim_grad() if self.need_dgrad else None
+        if self.dx is not None and self._sub is not None:
+            c0, c1 = self.dgrad_slice
+            full = self.dx
+            self._sub["dx"] = L.View(full.ptr, full.n, full.h, full.w, c1 - c0, full.cstride, full.coff + c0)
 
     def backward(self, grads):
         """``out.grad`` (+``out.grad2``) hold d/d(activated out).  Writes parameter gradients into
@@ -413,9 +450,15 @@ class ConvUnit:
         plan.prof_end(t0, self, "backward_weight")
         if self.dx is not None:
             t0 = plan.prof_begin()
-            L.check(lib.bp_conv_backward_data(C.byref(self.cv), C.byref(g), L.ptr(self.packed_bwd),
-                                              L.ptr(hold.weight), C.byref(self.dx), plan.impl_of("dgrad"), st),
-                    f"{self.name} backward_data")
+            if self._sub is not None:
+                sub = self._sub
+                L.check(lib.bp_conv_backward_data(C.byref(sub["cv"]), C.byref(g), L.ptr(sub["packed"]),
+                                                  L.ptr(sub["w"]), C.byref(sub["dx"]), plan.impl_of("dgrad"), st),
+                        f"{self.name} backward_data (channels {self.dgrad_slice})")
+            else:
+                L.check(lib.bp_conv_backward_data(C.byref(self.cv), C.byref(g), L.ptr(self.packed_bwd),
+                                                  L.ptr(hold.weight), C.byref(self.dx), plan.impl_of("dgrad"), st),
+                        f"{self.name} backward_data")
             plan.prof_end(t0, self, "backward_data")
 
 

@@ -39,9 +39,12 @@ def kernel_name(kind, unit, lib):
         if cx <= 16 and cy <= 16 and not (cx == 16 and cy == 16) and (cv.k, cv.stride) in ((3, 1), (5, 1), (7, 1), (4, 2), (8, 4)):
             return "wgrad_small_kernel[k%ds%d %d,%d]" % (cv.k, cv.stride, cx, cy)
         return "wgrad_tiles_kernel[k%ds%d %s]" % (cv.k, cv.stride, "wide" if (cx > 16 and cy > 16) else "thin")
-    kid = lib.bp_conv_kernel_id(C.byref(unit.cv), L.PACK_FWD if kind == "forward" else L.PACK_BWD)
+    cv = unit.cv
+    if kind == "backward_data" and getattr(unit, "_sub", None) is not None:
+        cv = unit._sub["cv"]           # data gradient restricted to a channel slice
+    kid = lib.bp_conv_kernel_id(C.byref(cv), L.PACK_FWD if kind == "forward" else L.PACK_BWD)
     if kid >= 900000:
-        return "small_conv_kernel<%d,%d,%d>" % (kid // 100 % 100, kid // 10 % 10, kid % 10)
+        return "small_conv_kernel<%d,%d,%d>" % (kid // 1000 % 100, kid // 10 % 100, kid % 10)
     dma, kid = divmod(kid, 100000)
     return "%s<%d,%d,%d,%d>" % (("igemm_kernel", "igemm_dma_kernel", "igemm_dma8_kernel", "igemm_dmaf_kernel")[dma], kid // 1000,
                                 kid // 100 % 10, kid // 10 % 10, kid % 10)
@@ -247,11 +250,11 @@ def main():
             d = per.setdefault(name, {"ms": 0.0, "launches": 0, "flop": 0.0})
             d["ms"] += e0.elapsed_time(e1)
             d["launches"] += 1
-            d["flop"] += 2.0 * unit.macs()
+            d["flop"] += 2.0 * unit.macs(kind)
         if args.layers:
             lay = {}
             for e0, e1, unit, kind in prof_events:
-                d = lay.setdefault((unit.name, kind), [0.0, 2.0 * unit.macs(), kernel_name(kind, unit, model._lib)])
+                d = lay.setdefault((unit.name, kind), [0.0, 2.0 * unit.macs(kind), kernel_name(kind, unit, model._lib)])
                 d[0] += e0.elapsed_time(e1) / args.steps
             for (name, kind), (ms, fl, kn) in sorted(lay.items(), key=lambda kv: -kv[1][0]):
                 print(f"{name:28s} {kind:16s} {ms:8.3f} ms  {fl / ms / 1e9:7.2f} TF/s  {kn}", file=sys.stderr)

@@ -199,6 +199,52 @@ def test_dma_pipelined_kernels_ragged_views_and_activation(case):
     assert G.rel_err(dw.cpu().numpy(), dw_ref) < 1e-4
 
 
+# unit-stride layers with cin*cout <= 16 served by the vector-ALU kernel (conv_small.hip) in at least one direction
+SMALL_CASES = [(8, 1, 5, 2), (1, 8, 5, 2), (1, 16, 5, 2), (1, 1, 3, 1)]
+
+
+@pytest.mark.parametrize("case", SMALL_CASES, ids=lambda c: "%d_%d_k%d" % c[:3])
+def test_small_channel_kernels_ragged_views_and_activation(case):
+    lib = L.load()
+    ci, co, k, p = case
+    n, h, w = 3, 37, 70                       # ragged against the 16 x 64 tiles
+    rng = np.random.default_rng(ci * 13 + co)
+    x = rng.standard_normal((n, ci, h, w)).astype(np.float32)
+    wt = (rng.standard_normal((co, ci, k, k)) * 0.2).astype(np.float32)
+    bias = rng.standard_normal(co).astype(np.float32)
+    scale = rng.uniform(0.5, 1.5, ci).astype(np.float32)
+    shift = rng.uniform(0.2, 0.6, ci).astype(np.float32)
+    slope = rng.uniform(0.0, 0.3, ci).astype(np.float32)
+    t = x * scale[None, :, None, None] + shift[None, :, None, None]
+    xa = np.where(t > 0, t, t * slope[None, :, None, None]).astype(np.float64)
+    w64 = wt.astype(np.float64)
+    y_ref = ops.conv2d_fwd(xa, w64, 1, p) + bias[None, :, None, None]
+    cv = L.Conv(0, ci, co, k, 1, p, 0)
+    ids = [lib.bp_conv_kernel_id(C.byref(cv), d) for d in (L.PACK_FWD, L.PACK_BWD)]
+    assert max(ids) >= 900000, "case is meant for small_conv_kernel"
+    st = G.stream()
+    xb, xv = G.to_nhwc(x, cstride=ci + 4, coff=4)
+    yb, yv = G.empty_nhwc(n, h, w, co, cstride=co + 3, coff=2)
+    keep, pw = G.pointwise(scale, shift, slope)
+    wd, bd = G.dev(wt), G.dev(bias)
+    pf = torch.zeros(lib.bp_conv_packed_floats(C.byref(cv), L.PACK_FWD), device="cuda")
+    pb = torch.zeros(lib.bp_conv_packed_floats(C.byref(cv), L.PACK_BWD), device="cuda")
+    L.check(lib.bp_conv_pack(C.byref(cv), L.PACK_FWD, L.ptr(wd), L.ptr(pf), st))
+    L.check(lib.bp_conv_pack(C.byref(cv), L.PACK_BWD, L.ptr(wd), L.ptr(pb), st))
+    L.check(lib.bp_conv_forward(C.byref(cv), C.byref(xv), C.byref(pw), L.ptr(pf), L.ptr(wd), L.ptr(bd), C.byref(yv),
+                                L.IMPL_MFMA, st), "forward")
+    assert G.rel_err(G.from_nhwc(yb, co, coff=2), y_ref) < 2e-5
+    assert torch.isnan(yb[..., :2]).all() and torch.isnan(yb[..., 2 + co:]).all(), "stores outside the view"
+    dy = rng.standard_normal(y_ref.shape).astype(np.float32)
+    dyb, dyv = G.to_nhwc(dy, cstride=co + 1, coff=1)
+    dxb, dxv = G.empty_nhwc(n, h, w, ci, cstride=ci + 2, coff=1)
+    L.check(lib.bp_conv_backward_data(C.byref(cv), C.byref(dyv), L.ptr(pb), L.ptr(wd), C.byref(dxv), L.IMPL_MFMA,
+                                      st), "backward_data")
+    dx_ref = ops.conv2d_bwd_data(dy.astype(np.float64), w64, 1, p, h, w)
+    assert G.rel_err(G.from_nhwc(dxb, ci, coff=1), dx_ref) < 2e-5
+    assert torch.isnan(dxb[..., :1]).all() and torch.isnan(dxb[..., 1 + ci:]).all(), "stores outside the view"
+
+
 def test_conv_rejects_bad_shapes():
     lib = L.load()
     cv = L.Conv(0, 16, 32, 3, 1, 1, 0)
