@@ -812,7 +812,7 @@ IgemmConfig igemm_config(const ConvGeom& g) {
         const int in_pad4 = bp_round_up(E, 64);
         const size_t lds_in2 = (size_t)2 * in_pad4 * 4 * sizeof(float) + (size_t)3 * g.cin_g * sizeof(float);   // + activation parameters
         const size_t lds_slab = (size_t)c.COB * CC * sizeof(float);
-        const size_t lds_cap = (size_t)(NW == 8 ? 64 : 53) * 1024;   // two / three workgroups per CU
+        const size_t lds_cap = (size_t)(NW == 8 ? 80 : 53) * 1024;   // two / three workgroups per CU
         const size_t lds_dma = lds_in2 + 2 * lds_slab;
         const int per_thread = bp_ceil_div(in_pad4, 64 * NW);
         // the plain fallback with this CC must exist too
@@ -860,6 +860,10 @@ int launch_cc(const IgemmConfig& c, const IgemmArgs& a, dim3 grid, hipStream_t s
 
 template <int CC, int NT, int WN, int SLOTS, int NW>
 int launch_dma_one(const IgemmConfig& c, const IgemmArgs& a, dim3 grid, hipStream_t st) {
+  static const hipError_t optin = hipFuncSetAttribute(
+      reinterpret_cast<const void*>(&igemm_dma_kernel<CC, NT, WN, SLOTS, NW>),
+      hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+  if (optin != hipSuccess) return BP_ELAUNCH;
   hipLaunchKernelGGL((igemm_dma_kernel<CC, NT, WN, SLOTS, NW>), grid, dim3(64 * NW), c.lds_dma, st, a);
   BP_CHECK_LAUNCH();
   return BP_OK;

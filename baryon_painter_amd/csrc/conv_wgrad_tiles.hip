@@ -612,12 +612,18 @@ int bp_wgrad_tiles(const bp_conv* cv, const bp_view* X, const PW& pwx, const bp_
   }
   // CGAN kernel sizes (trained_models/README.md:106-128): k3s2 encoders/decoders, k4s1 PatchGAN tail, k9 stem/head
   if (k == 3 && s == 2) {
-    if (cx > 16 && cy > 32) BP_WT(3, 3, 2, 1, 2, 2, 2, 1, 4);
+    if (cx > 16 && cy > 32) {
+      if (dma) BP_WT(3, 3, 2, 1, 2, 2, 2, 1, 2, true);
+      BP_WT(3, 3, 2, 1, 2, 2, 2, 1, 4);
+    }
     if (cy > 16) BP_WT(3, 3, 2, 1, 2, 1, 1, 4, 4);
     BP_WT(3, 3, 2, 1, 1, 1, 1, 4, 4);
   }
   if (k == 4 && s == 1) {
-    if (cx > 16 && cy > 32) BP_WT(4, 4, 1, 1, 2, 2, 2, 1, 4);
+    if (cx > 16 && cy > 32) {
+      if (dma) BP_WT(4, 4, 1, 1, 2, 2, 2, 1, 4, true);
+      BP_WT(4, 4, 1, 1, 2, 2, 2, 1, 4);
+    }
     if (cy > 16) BP_WT(4, 4, 1, 1, 2, 1, 1, 4, 8);
     BP_WT(4, 4, 1, 1, 1, 1, 1, 4, 8);
   }
