@@ -112,9 +112,10 @@ __global__ __launch_bounds__(256, (MT == 4 && NT == 4) ? 4 : 1) void igemm_kerne
 
   const int tile = blockIdx.x;
   const int tile_x = tile % a.tiles_x, tile_y = tile / a.tiles_x;
-  const int co0 = blockIdx.y * COB;
-  const int ph = blockIdx.z % (a.nphase * a.nphase);
-  const int n = blockIdx.z / (a.nphase * a.nphase);
+  // grid = (tiles, images x phases, channel blocks): workgroups that run together read the same weight slabs
+  const int co0 = blockIdx.z * COB;
+  const int ph = blockIdx.y % (a.nphase * a.nphase);
+  const int n = blockIdx.y / (a.nphase * a.nphase);
   const int py = ph / a.nphase, px = ph % a.nphase;
 
   const int BW = 16 * a.TPR;
@@ -273,7 +274,7 @@ __global__ __launch_bounds__(256, (MT == 4 && NT == 4) ? 4 : 1) void igemm_kerne
 // LDS image of the input is the one of igemm_kernel, enumerated in LDS order so that the 64 lanes of a
 // wave-instruction land on 1 KiB of consecutive LDS (destination = wave-uniform base + lane * 16).
 template <int CC, int NT, int WN, int SLOTS, int NW>
-__global__ __launch_bounds__(64 * NW, NT == 4 ? ((SLOTS == 3 && WN == 2) ? 4 : 3) : 2) void igemm_dma_kernel(IgemmArgs a) {
+__global__ __launch_bounds__(64 * NW, NT == 4 ? ((WN == 2 && (SLOTS == 3 || NW == 8)) ? 4 : 3) : 2) void igemm_dma_kernel(IgemmArgs a) {
   constexpr int MT = 4;
   constexpr int VW = CC / 4;
   constexpr int WM = NW / WN;
@@ -294,9 +295,10 @@ __global__ __launch_bounds__(64 * NW, NT == 4 ? ((SLOTS == 3 && WN == 2) ? 4 : 3
 
   const int tile = blockIdx.x;
   const int tile_x = tile % a.tiles_x, tile_y = tile / a.tiles_x;
-  const int co0 = blockIdx.y * COB;
-  const int ph = blockIdx.z % (a.nphase * a.nphase);
-  const int n = blockIdx.z / (a.nphase * a.nphase);
+  // grid = (tiles, images x phases, channel blocks): workgroups that run together read the same weight slabs
+  const int co0 = blockIdx.z * COB;
+  const int ph = blockIdx.y % (a.nphase * a.nphase);
+  const int n = blockIdx.y / (a.nphase * a.nphase);
   const int py = ph / a.nphase, px = ph % a.nphase;
 
   const int BW = 16 * a.TPR;
@@ -485,10 +487,10 @@ __global__ __launch_bounds__(256, 2) void igemm_dmaf_kernel(IgemmArgs a) {
 
   const int tile = blockIdx.x;
   const int tile_x = tile % a.tiles_x, tile_y = tile / a.tiles_x;
-  const int co0 = blockIdx.y * COB;
+  const int co0 = blockIdx.z * COB;
   const int nph2 = a.nphase * a.nphase;
-  const int ph0 = NPH == 1 ? blockIdx.z % nph2 : 0;
-  const int n = NPH == 1 ? blockIdx.z / nph2 : blockIdx.z;
+  const int ph0 = NPH == 1 ? blockIdx.y % nph2 : 0;
+  const int n = NPH == 1 ? blockIdx.y / nph2 : blockIdx.y;
   const int py0 = ph0 / a.nphase, px0 = ph0 % a.nphase;
 
   const int BW = 16 * a.TPR;
@@ -989,7 +991,7 @@ int bp_igemm_run(const ConvGeom& g, const bp_view* in, const PW& pw, const float
   a.tiles_y = bp_ceil_div(qh, t.BH);
   const int64_t gz = (int64_t)in->n * ((dma && c.dmaf && c.nph > 1) ? 1 : g.nphase * g.nphase);
   if (gz > 65535 || c.cout_padP / c.COB > 65535) return BP_EUNSUPPORTED;
-  dim3 grid((unsigned)(a.tiles_x * a.tiles_y), (unsigned)(c.cout_padP / c.COB), (unsigned)gz);
+  dim3 grid((unsigned)(a.tiles_x * a.tiles_y), (unsigned)gz, (unsigned)(c.cout_padP / c.COB));
   a.in_pad4 = c.in_pad4; a.ts = c.ts; a.in_bufs = c.in_bufs;
   if (dma && c.dmaf) return launch_dmaf(c, a, grid, st);
   if (dma) return launch_dma(c, a, grid, st);

@@ -134,6 +134,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
 struct WreduceArgs {
   const float* ws; float* dst;
   int k, cx, cy, CXP, CYP, nsplit;
+  int cx_total, cx_off, cy_off;     // position of this (cx, cy) block inside the full weight tensor
 };
 
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(WreduceArgs a) {
@@ -163,7 +164,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(WreduceArgs a) {
   sh[grp][lane] = s;
   __syncthreads();
   if (grp == 0 && i < total)
-    a.dst[((int64_t)cy * a.cx + cx) * a.k * a.k + t] = (float)(((sh[0][lane] + sh[1][lane]) + sh[2][lane]) + sh[3][lane]);
+    a.dst[((int64_t)(a.cy_off + cy) * a.cx_total + a.cx_off + cx) * a.k * a.k + t] = (float)(((sh[0][lane] + sh[1][lane]) + sh[2][lane]) + sh[3][lane]);
 }
 
 struct WgradPlan {
@@ -216,12 +217,57 @@ static int wgrad_fast(const bp_conv* cv, const bp_view* X, const PW& pwx, const 
 }
 
 static int wgrad_reduce(const float* ws, float* dst, int k, int cx, int cy, int CXP, int CYP, int nsplit,
-                        hipStream_t st) {
+                        hipStream_t st, int cx_total = -1, int cx_off = 0, int cy_off = 0) {
   WreduceArgs r{};
   r.ws = ws; r.dst = dst; r.k = k; r.cx = cx; r.cy = cy; r.CXP = CXP; r.CYP = CYP; r.nsplit = nsplit;
+  r.cx_total = cx_total < 0 ? cx : cx_total; r.cx_off = cx_off; r.cy_off = cy_off;
   const int64_t total = (int64_t)cy * cx * k * k;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, st, r);
   BP_CHECK_LAUNCH();
+  return BP_OK;
+}
+
+// One or two channels on one side and many on the other (the k9 stem / head of the CGAN generator): the tap-packed
+// few-channel kernel runs once per 16-channel chunk of the wide side, each chunk reduced into its block of dW.
+static bool wide_side_chunks(const bp_conv* cv, const bp_view* X, const bp_view* Y, bool* on_x) {
+  if (X->c > 16 && Y->c <= 2) *on_x = true;
+  else if (Y->c > 16 && X->c <= 2) *on_x = false;
+  else return false;
+  bp_view sub = *on_x ? *X : *Y;
+  sub.c = 16;
+  size_t need = 0;
+  int ns, cxp, cyp;
+  const PW none{nullptr, nullptr, nullptr};
+  return bp_wgrad_small(cv, *on_x ? &sub : X, none, *on_x ? Y : &sub, none, nullptr, 0, &need, &ns, &cxp, &cyp, nullptr,
+                        true) == BP_OK;
+}
+
+static PW pw_offset(const PW& p, int c0) {
+  return p.scale ? PW{p.scale + c0, p.shift + c0, p.slope + c0} : p;
+}
+
+static int wgrad_chunked(const bp_conv* cv, const bp_view* X, const PW& pwx, const bp_view* Y, const PW& pwy, float* dst,
+                         float* ws, size_t ws_bytes, size_t* need_out, hipStream_t st, bool dry, bool on_x) {
+  const int wide = on_x ? X->c : Y->c;
+  size_t need_max = 0;
+  for (int c0 = 0; c0 < wide; c0 += 16) {
+    bp_view sub = on_x ? *X : *Y;
+    sub.c = wide - c0 < 16 ? wide - c0 : 16;
+    sub.coff += c0;
+    const bp_view* Xc = on_x ? &sub : X;
+    const bp_view* Yc = on_x ? Y : &sub;
+    const PW px = on_x ? pw_offset(pwx, c0) : pwx, py = on_x ? pwy : pw_offset(pwy, c0);
+    size_t need = 0;
+    int ns, cxp, cyp;
+    const int rc = bp_wgrad_small(cv, Xc, px, Yc, py, ws, ws_bytes, &need, &ns, &cxp, &cyp, st, dry);
+    if (rc != BP_OK) return rc;
+    if (need > need_max) need_max = need;
+    if (!dry) {
+      const int rr = wgrad_reduce(ws, dst, cv->k, Xc->c, Yc->c, cxp, cyp, ns, st, X->c, on_x ? c0 : 0, on_x ? 0 : c0);
+      if (rr != BP_OK) return rr;
+    }
+  }
+  *need_out = need_max;
   return BP_OK;
 }
 
@@ -229,6 +275,10 @@ size_t bp_wgrad_mfma_workspace(const bp_conv* cv, const bp_view* X, const bp_vie
   size_t need = 0;
   int ns, cxp, cyp;
   const PW none{nullptr, nullptr, nullptr};
+  bool on_x = false;
+  if (wide_side_chunks(cv, X, Y, &on_x) &&
+      wgrad_chunked(cv, X, none, Y, none, nullptr, nullptr, 0, &need, nullptr, true, on_x) == BP_OK)
+    return need;
   if (wgrad_fast(cv, X, none, Y, none, nullptr, 0, &need, &ns, &cxp, &cyp, nullptr, true) == BP_OK) return need;
   const WgradPlan p = wgrad_plan(cv, X, Y);
   return p.ok ? p.ws_bytes : 0;
@@ -236,6 +286,14 @@ size_t bp_wgrad_mfma_workspace(const bp_conv* cv, const bp_view* X, const bp_vie
 
 int bp_wgrad_mfma(const bp_conv* cv, const bp_view* X, const PW& pwx, const bp_view* Y, const PW& pwy,
                   float* dst, void* workspace, size_t workspace_bytes, hipStream_t st) {
+  {
+    bool on_x = false;
+    if (wide_side_chunks(cv, X, Y, &on_x)) {
+      size_t need = 0;
+      return wgrad_chunked(cv, X, pwx, Y, pwy, dst, reinterpret_cast<float*>(workspace), workspace_bytes, &need, st,
+                           false, on_x);
+    }
+  }
   {
     size_t need = 0;
     int ns, cxp, cyp;

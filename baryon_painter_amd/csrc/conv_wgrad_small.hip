@@ -252,6 +252,11 @@ int bp_wgrad_small(const bp_conv* cv, const bp_view* X, const PW& pwx, const bp_
   BP_WS(5, 1, 8, 8, 8);
   BP_WS(5, 1, 1, 1, 16);
   BP_WS(7, 1, 1, 1, 16);
+  // k9 stem / head of the CGAN generator, per 16-channel chunk of the wide side (conv_wgrad.hip: wide_side_chunks)
+  BP_WS(9, 1, 2, 16, 8);
+  BP_WS(9, 1, 1, 16, 8);
+  BP_WS(9, 1, 16, 1, 8);
+  BP_WS(9, 1, 16, 2, 4);
   // strided ends of the encoders / the latent up-sampler
   BP_WS(4, 2, 1, 8, 8);
   BP_WS(4, 2, 2, 8, 8);
