@@ -85,6 +85,7 @@ SIGNATURES = {
     "bp_gather_tiles": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, _P, _P]),
     "bp_adam_step": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float,
                                C.c_int32, _P]),
+    "bp_adam_step_dev": (C.c_int, [_P, _P, _P, _P, C.c_int64, _P, _P]),
 }
 
 _lib = None

@@ -807,6 +807,20 @@ static inline RedPlan red_plan(int c, int64_t npix) {
 }
 static inline unsigned nblocks(int64_t total) { return (unsigned)((total + RB - 1) / RB); }
 
+__global__ __launch_bounds__(RB) void adam_dev_kernel(float* p, const float* g, float* m, float* v, int64_t n,
+                                                      const float* hyper) {
+  const int64_t i = (int64_t)blockIdx.x * RB + threadIdx.x;
+  if (i >= n) return;
+  const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3], bc1 = hyper[4], bc2_sqrt = hyper[5];
+  const float gi = g[i];
+  const float mi = b1 * m[i] + (1.f - b1) * gi;
+  const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+  m[i] = mi;
+  v[i] = vi;
+  const float denom = sqrtf(vi) / bc2_sqrt + eps;
+  p[i] -= (lr / bc1) * (mi / denom);
+}
+
 }  // namespace
 
 extern "C" {
@@ -1186,6 +1200,16 @@ int bp_gather_tiles(const void* desc100, const void* desc150, const void* xform,
   hipLaunchKernelGGL(gather_tiles_kernel, dim3(nblocks(total)), dim3(RB), 0, bp_stream(stream),
                      reinterpret_cast<const TileDesc*>(desc100), reinterpret_cast<const TileDesc*>(desc150),
                      reinterpret_cast<const SampleXform*>(xform), out_nchw, tile, total);
+  BP_CHECK_LAUNCH();
+  return BP_OK;
+}
+
+int bp_adam_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                     const float* hyper, void* stream) {
+  if (!param || !grad || !exp_avg || !exp_avg_sq || n < 0 || !hyper) return BP_EINVAL;
+  if (n == 0) return BP_OK;
+  hipLaunchKernelGGL(adam_dev_kernel, dim3(nblocks(n)), dim3(RB), 0, bp_stream(stream), param, grad, exp_avg,
+                     exp_avg_sq, n, hyper);
   BP_CHECK_LAUNCH();
   return BP_OK;
 }

@@ -603,6 +603,100 @@ class CVAE(torch.nn.Module):
         st["graph"] = graph
         return st
 
+    # ---- the whole training step as one hipGraph (small minibatches are launch-bound: ~450 launches per step)
+    def make_graphed_train_step(self, optimizer, n):
+        """Capture forward + backward + Adam for minibatches of ``n`` tiles and return ``step(x, y, aux) -> ELBO``.
+
+        ``step`` does what ``optimizer.zero_grad(); elbo = model(x, y, aux); (-elbo).backward(); optimizer.step()``
+        does (the loop body of the reference's ``CVAEPainter.train``, painter.py:93-130) with identical arithmetic -
+        the captured launches ARE the eager ones - but replays them from a hipGraph, so the host cost of a step is
+        one graph launch plus the input copies.  ``optimizer`` must be a ``FlatAdam`` on this model; its learning
+        rate may change between steps (schedulers), the latent noise is drawn in-graph."""
+        from ..optim import FlatAdam
+        if not isinstance(optimizer, FlatAdam) or optimizer.model is not self:
+            raise TypeError("make_graphed_train_step needs the FlatAdam optimiser of this model")
+        if self.sync is not None:
+            raise NotImplementedError("graphed training steps under data parallelism (collectives inside the graph)")
+        if not self.training:
+            raise RuntimeError("graphed training step: model.train() first")
+        plan = self._plan(n, True)
+        dev = self.device
+        cy, H, W = self.dim_y
+        cx = self.dim_x[0]
+        xs = torch.zeros((n, cx, H, W), device=dev)
+        ys = torch.zeros((n, cy, H, W), device=dev)
+        auxs = torch.zeros((n, self.n_aux), device=dev) if self.use_aux_label else None
+        seed = torch.full((1,), -1.0, device=dev)            # d(loss)/d(ELBO), loss = -ELBO
+        units = []
+        for us in plan.q_units + [plan.p_units] + plan.g_units + [plan.mu_units, plan.var_units]:
+            for u in us:
+                units += u.body if hasattr(u, "body") else [u]
+
+        holder = {}
+
+        def run():
+            for u in units:
+                u._packed_version = None                     # the weights change every replay: always re-pack
+            eps = torch.randn(size=(self.L, n, *self.dim_z), device=dev)
+            holder["eps"] = eps
+            plan.forward_train(xs, ys, auxs, eps, training=True)
+            plan.backward(seed, self._grad_views_by_id)
+            optimizer.device_step()
+
+        # warm-up outside capture on a side stream (sizes workspaces, claims gradient buffers); it must not change
+        # the training state, so parameters, Adam moments and batch-norm buffers are restored afterwards
+        keep = [t.clone() for t in (self._flat_params, optimizer.exp_avg, optimizer.exp_avg_sq)]
+        bufs = [(b, b.clone()) for b in self.buffers()]
+        optimizer.upload_hyper(max(optimizer.n_steps, 1))
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side), torch.no_grad():
+            run()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.no_grad(), torch.cuda.graph(graph, stream=side):
+            run()
+        with torch.no_grad():
+            for t, k in zip((self._flat_params, optimizer.exp_avg, optimizer.exp_avg_sq), keep):
+                t.copy_(k)
+            for b, k in bufs:
+                b.copy_(k)
+        self._bump_param_versions()
+
+        def step(x, y, aux_label=None):
+            x = torch.as_tensor(x, device=dev, dtype=torch.float32)
+            y = torch.as_tensor(y, device=dev, dtype=torch.float32)
+            self._check_inputs(x, y)
+            if y.shape[0] != n:
+                raise ValueError(f"this graph was captured for minibatches of {n} tiles, got {y.shape[0]}")
+            if self._eps_override is not None:
+                raise RuntimeError("eps override is not supported on the graphed path (noise is drawn in-graph)")
+            xs.copy_(x, non_blocking=True)
+            ys.copy_(y, non_blocking=True)
+            if auxs is not None:
+                auxs.copy_(self._aux(aux_label, n), non_blocking=True)
+            optimizer.n_steps += 1
+            optimizer.upload_hyper(optimizer.n_steps)
+            graph.replay()
+            self._bump_param_versions()                      # eager paths (validation, paint) re-pack the new weights
+            for p, gv in zip(self._params, self._grad_views):
+                p.grad = gv
+            self._last = plan
+            s = plan.stats
+            self.ELBO = s[0]
+            self.KL_term = s[1]
+            self.log_likelihood = s[2:2 + cx]
+            self.x_mu = plan.x_mu
+            self.z_mu = plan.stats4[0]
+            self.z_log_var = plan.stats4[1]
+            return s[0].clone()
+
+        step.graph = graph
+        step.last_eps = lambda: holder["eps"]                # the noise of the latest replay (tests)
+        # every device tensor the captured launches read must outlive the capture: the graph holds raw pointers
+        step._keepalive = (seed, xs, ys, auxs, holder, plan)
+        return step
+
     def _head_to_nchw(self, slot, softplus, dst):
         L.check(self._lib.bp_view_to_nchw(C.byref(slot.view), None, 1 if softplus else 0, L.ptr(dst), _stream()),
                 "head layout")

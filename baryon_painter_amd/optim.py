@@ -7,6 +7,7 @@ Same arithmetic as ``torch.optim.Adam`` (the reference's optimiser, painter.py:9
 it through ``param_groups[0]["lr"]`` as usual.
 """
 import ctypes as C
+import math
 
 import torch
 
@@ -48,3 +49,31 @@ class FlatAdam(torch.optim.Optimizer):
                                        st), "adam step")
         m._bump_param_versions()                    # the convolution units re-pack their weights
         return loss
+
+    # ---- the same update as a launch that can live in a captured hipGraph (CVAE.make_graphed_train_step)
+    def _hyper_dev_buffer(self):
+        if not hasattr(self, "_hyper_dev"):
+            self._hyper_dev = torch.zeros(6, dtype=torch.float32, device=self.model._flat_params.device)
+        return self._hyper_dev
+
+    def upload_hyper(self, step):
+        """{lr, beta1, beta2, eps, 1-beta1^step, sqrt(1-beta2^step)} of update number ``step`` -> device (the
+        same double-precision bias corrections as bp_adam_step, so graph replay and eager steps agree bit for bit).
+        The source is a fresh pageable tensor: the runtime stages it before returning, so a host that runs ahead of
+        the GPU cannot overwrite the scalars of a step that has not executed yet."""
+        g = self.param_groups[0]
+        # bp_adam_step receives beta1/beta2 as C floats and forms the corrections from those in double
+        b1 = float(torch.tensor(g["betas"][0], dtype=torch.float32))
+        b2 = float(torch.tensor(g["betas"][1], dtype=torch.float32))
+        vals = [float(g["lr"]), b1, b2, float(g["eps"]), 1.0 - math.pow(b1, step), math.sqrt(1.0 - math.pow(b2, step))]
+        self._hyper_dev_buffer().copy_(torch.tensor(vals, dtype=torch.float32), non_blocking=True)
+
+    @torch.no_grad()
+    def device_step(self):
+        """Launch the update with the scalars last uploaded by ``upload_hyper`` (capturable)."""
+        m = self.model
+        dev = self._hyper_dev_buffer()
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        L.check(self._lib.bp_adam_step_dev(L.ptr(m._flat_params), L.ptr(m._flat_grads), L.ptr(self.exp_avg),
+                                           L.ptr(self.exp_avg_sq), m._flat_params.numel(), L.ptr(dev), st),
+                "adam step (device scalars)")

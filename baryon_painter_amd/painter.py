@@ -85,9 +85,13 @@ class CVAEPainter(Painter):
               loss_plot_frequency=1000, mavg_window_size=20,
               plot_sample_var=False, plot_power_spectra=["auto"], plot_histogram=["log"],
               show_plots=True, save_plots=False, output_path=None, verbose=True,
-              pepoch_size=3136, var_anneal_fn=None, KL_anneal_fn=None):
+              pepoch_size=3136, var_anneal_fn=None, KL_anneal_fn=None, graph_step=False):
         """Train.  1 pseudo epoch = ``pepoch_size`` samples (3136 by default; the checked-in
-        script uses 1568).  Returns ``(training_stats, validation_stats)``."""
+        script uses 1568).  Returns ``(training_stats, validation_stats)``.
+
+        ``graph_step=True`` (extension): forward + backward + Adam of full minibatches replay from one hipGraph
+        (``CVAE.make_graphed_train_step``) - same arithmetic, ~2x the throughput at the reference's minibatch
+        sizes of 4-24 tiles, where a step is bound by its ~450 kernel launches.  Single device only."""
         if self.training_data is None:
             raise RuntimeError("Trying to train but no training data specified.")
         if len(validation_pepochs) > 0 and self.test_data is None:
@@ -147,6 +151,7 @@ class CVAEPainter(Painter):
         i_epoch = i_pepoch = i_batch = 0
         world = 1 if self.sync is None else self.sync.world_size
         ELBO = None
+        graphed_steps = {}
 
         while i_epoch < n_epoch:
             i_epoch = n_samples // len(self.training_data)
@@ -183,10 +188,22 @@ class CVAEPainter(Painter):
                 y = batch_data[0][0].to(model.device)
                 aux = batch_data[2].to(device=model.device, dtype=y.dtype) if len(batch_data) > 2 else None
 
-                ELBO = model(x, y, aux)
-                optimizer.zero_grad()
-                (-ELBO).backward()
-                optimizer.step()
+                if graph_step and self.sync is None:
+                    n_b = int(y.shape[0])
+                    if n_b not in graphed_steps and n_b == batch_size:
+                        graphed_steps[n_b] = model.make_graphed_train_step(optimizer, n_b)
+                    stepper = graphed_steps.get(n_b)
+                else:
+                    stepper = None
+                if stepper is not None:
+                    if callable(var_anneal_fn) or callable(KL_anneal_fn):
+                        raise NotImplementedError("graph_step with annealed loss weights (they are captured constants)")
+                    ELBO = stepper(x, y, aux)
+                else:
+                    ELBO = model(x, y, aux)
+                    optimizer.zero_grad()
+                    (-ELBO).backward()
+                    optimizer.step()
 
                 n_samples += x.size(0) * world
                 n_batches += 1

@@ -248,6 +248,11 @@ int bp_gather_tiles(const void* desc100, const void* desc150, const void* xform,
 /* ---- optimiser (replaces torch.optim.Adam.step, painter.py:93,228; same arithmetic) --------- */
 int bp_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                  float lr, float beta1, float beta2, float eps, int32_t step, void* stream);
+/* The same update with its scalars read from device memory - hyper[6] = {lr, beta1, beta2, eps,
+ * 1 - beta1^step, sqrt(1 - beta2^step)} - so that the launch can sit in a captured hipGraph of the whole
+ * training step while the learning rate and the step number keep changing. */
+int bp_adam_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                     const float* hyper, void* stream);
 
 #ifdef __cplusplus
 }
