@@ -150,6 +150,13 @@ class _Plan:
             self._prepare_backward()
         self.ws = torch.zeros(max(self.ws_bytes, 256) // 8 + 32, device=dev, dtype=torch.float64)
         self.ws_bytes = self.ws.numel() * 8
+        # Weight gradients on a second stream: they depend only on a layer's d_raw and its input, not on the
+        # chain act-backward -> data gradient -> act-backward of the layers below, so their MFMA work can run
+        # beside that chain's HBM-bound passes.  They get their own workspace.
+        self.side = self._side_stream = None
+        if with_grad and os.environ.get("BP_SIDE_WGRAD", "1") != "0":
+            self.side = self._side_stream = torch.cuda.Stream(device=dev)
+            self.ws2 = torch.zeros_like(self.ws)
 
     # ---- helpers
     def need_ws(self, nbytes):
@@ -312,6 +319,8 @@ class _Plan:
         for us in reversed(self.q_units):
             for u in reversed(us):
                 u.backward(grads)
+        if self.side is not None:
+            torch.cuda.current_stream(self.device).wait_stream(self.side)    # join: every weight gradient is written
 
 
 class _ELBOFunction(torch.autograd.Function):
@@ -428,6 +437,12 @@ class CVAE(torch.nn.Module):
             self._grad_views_by_id[id(p)] = gv
             off += k
         self._params = params
+
+    def overlap_weight_gradients(self, enabled):
+        """Run the weight gradients on a second stream beside the rest of the backward pass (default), or serially
+        on the main stream (``False``: every kernel has the GPU to itself, e.g. to time kernels)."""
+        for plan in self._plans.values():
+            plan.side = plan._side_stream if enabled else None
 
     def _bump_param_versions(self):
         """Called after an out-of-band in-place update of the flat buffer (FlatAdam): convolution units
