@@ -1,12 +1,16 @@
 # Collects the round's rocprofv3 evidence on the GPU box (run through gpurun from the repo root):
-#   kernel trace + stats, and the two HBM-traffic PMC passes (separate passes: TCC has 4 slots).
+#   kernel trace + stats of the default command (weight gradients overlapped on a second stream) and of the
+#   serial schedule (BP_SIDE_WGRAD=0: every kernel alone on the GPU - the schedule bench.py times kernels in),
+#   and the two HBM-traffic PMC passes (separate passes: TCC has 4 slots) on the serial schedule.
 set -e
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/prof_round
-mkdir -p $OUT
+rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 ARGS="$R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-paint"
 timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $OUT/stats -o r --output-format csv -- python3 $ARGS > $OUT/stats.log 2>&1
+export BP_SIDE_WGRAD=0
+timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $OUT/stats_serial -o r --output-format csv -- python3 $ARGS > $OUT/stats_serial.log 2>&1
 timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/fetch -o r --output-format csv -- python3 $ARGS > $OUT/fetch.log 2>&1
 timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/write -o r --output-format csv -- python3 $ARGS > $OUT/write.log 2>&1
 ls $OUT/*
