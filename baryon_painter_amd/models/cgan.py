@@ -15,6 +15,7 @@ What is fixed by the reference's tables and what is a choice made here:
     reference -- an L1 distance between generated and true field is used            -- chosen here.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -55,6 +56,11 @@ class _GanPlan:
             u.prepare_backward()
         self.ws = torch.zeros(max(self.ws_bytes, 256) // 8 + 32, device=dev, dtype=torch.float64)
         self.ws_bytes = self.ws.numel() * 8
+        # weight gradients on a second stream beside the data-gradient chain (graph.ConvUnit.conv_backward)
+        self.side = None
+        if os.environ.get("BP_SIDE_WGRAD", "1") != "0":
+            self.side = torch.cuda.Stream(device=dev)
+            self.ws2 = torch.zeros_like(self.ws)
         n_, h_, w_ = self.d_in.n, H, W
         di = self.d_in
         self.v_real_cond = L.View(di.buf.data_ptr(), n, h_, w_, 2, di.cstride, 0)
@@ -118,6 +124,7 @@ class _GanPlan:
                 "bce grad")
         for u in reversed(self.d_units):
             u.backward(grads)
+        self._join_side()
 
     def backward_g(self, grads, l1_scale):
         lib, st = self.lib, _stream()
@@ -125,6 +132,11 @@ class _GanPlan:
                                         C.byref(self.g_raw.grad), st), "generator head backward")
         for u in reversed(self.g_units):
             u.backward(grads)
+        self._join_side()
+
+    def _join_side(self):
+        if self.side is not None:
+            torch.cuda.current_stream().wait_stream(self.side)     # every weight gradient is written
 
 
 class CGAN(torch.nn.Module):
@@ -231,7 +243,11 @@ class CGAN(torch.nn.Module):
             lib, st = self._lib, _stream()
             L.check(lib.bp_l1_sum(C.byref(plan.v_fake_x), L.ptr(plan.x_nchw), L.ptr(plan.sums[3:]), L.ptr(plan.ws),
                                   plan.ws_bytes, st), "l1")
-            plan.backward_d(self._grads, 0.0, 1.0, 0.5 / plan.cnt_d)
+            plan.skip_wgrad = True          # through D only for d(loss)/d(fake): its parameters do not step here
+            try:
+                plan.backward_d(self._grads, 0.0, 1.0, 0.5 / plan.cnt_d)
+            finally:
+                plan.skip_wgrad = False
             plan.backward_g(self._grads, self.lambda_perceptual / plan.cnt_px)
             loss_g_adv = 0.5 * plan.sums[2] / plan.cnt_d
             loss_g_perc = plan.sums[3] / plan.cnt_px

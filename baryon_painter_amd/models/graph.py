@@ -458,7 +458,9 @@ class ConvUnit:
                     f"{self.name} backward_weight")
             plan.prof_end(t0, self, "backward_weight")
 
-        if side is None:
+        if getattr(plan, "skip_wgrad", False):
+            pass        # only the data gradient is wanted (generator step through the discriminator)
+        elif side is None:
             wgrad(plan.ws)
         else:
             side.wait_stream(torch.cuda.current_stream())     # fork: d_raw of this layer is complete
