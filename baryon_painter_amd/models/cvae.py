@@ -157,8 +157,27 @@ class _Plan:
         if with_grad and os.environ.get("BP_SIDE_WGRAD", "1") != "0":
             self.side = self._side_stream = torch.cuda.Stream(device=dev)
             self.ws2 = torch.zeros_like(self.ws)
+        # q_x_in, q_y_in and the prior network are independent chains of small kernels (none fills the GPU):
+        # q_y_in and the prior run on their own streams, each with its own reduction workspace
+        self.branch = None
+        # (single device only: under data parallelism every batch-norm layer all-reduces its statistics, and
+        #  collectives of one communicator must not be in flight on several streams at once)
+        if os.environ.get("BP_BRANCH_STREAMS", "1") != "0" and self.q_units and self.p_units and model.sync is None:
+            self.branch = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+            self.ws_b, self.ws_c = torch.zeros_like(self.ws), torch.zeros_like(self.ws)
+            for u in self._flat(self.q_units[1]):
+                u.ws_name = "ws_b"
+            for u in self._flat(self.p_units):
+                u.ws_name = "ws_c"
 
     # ---- helpers
+    @staticmethod
+    def _flat(units):
+        out = []
+        for u in units:
+            out += u.body if hasattr(u, "body") else [u]
+        return out
+
     def need_ws(self, nbytes):
         self.ws_bytes = max(self.ws_bytes, int(nbytes))
 
@@ -277,10 +296,27 @@ class _Plan:
     def forward_train(self, x, y, aux, eps, training=True):
         m = self.model
         self.load_inputs(y, aux, x)
-        for us in self.q_units:
-            for u in us:
+        if self.branch is None:
+            for us in self.q_units:
+                for u in us:
+                    u.forward(training)
+            self.run_prior(training)
+        else:
+            main = torch.cuda.current_stream(self.device)
+            sy, sp = self.branch
+            ux, uy, uo = self.q_units
+            sy.wait_stream(main); sp.wait_stream(main)              # fork: the inputs are loaded
+            with torch.cuda.stream(sy):
+                for u in uy:
+                    u.forward(training)
+            with torch.cuda.stream(sp):
+                self.run_prior(training)
+            for u in ux:
                 u.forward(training)
-        self.run_prior(training)
+            main.wait_stream(sy)                                    # q_out reads [q_x_in | q_y_in]
+            for u in uo:
+                u.forward(training)
+            main.wait_stream(sp)                                    # the KL term reads the prior
         self.run_latent(eps, use_q=True)
         self.run_generator(training)
         self.ll.alpha_var = float(m.alpha_var)
@@ -314,11 +350,29 @@ class _Plan:
                                        C.byref(self.q_head.grad),
                                        None if self.p_head is None else C.byref(self.p_head.grad), st),
                 "latent backward")
-        for u in reversed(self.p_units):
-            u.backward(grads)
-        for us in reversed(self.q_units):
-            for u in reversed(us):
+        if self.branch is None:
+            for u in reversed(self.p_units):
                 u.backward(grads)
+            for us in reversed(self.q_units):
+                for u in reversed(us):
+                    u.backward(grads)
+        else:
+            main = torch.cuda.current_stream(self.device)
+            sy, sp = self.branch
+            ux, uy, uo = self.q_units
+            sp.wait_stream(main)                                    # fork: d(loss)/d(prior head) is written
+            with torch.cuda.stream(sp):
+                for u in reversed(self.p_units):
+                    u.backward(grads)
+            for u in reversed(uo):
+                u.backward(grads)
+            sy.wait_stream(main)                                    # fork: d/d[q_x_in | q_y_in] is written
+            with torch.cuda.stream(sy):
+                for u in reversed(uy):
+                    u.backward(grads)
+            for u in reversed(ux):
+                u.backward(grads)
+            main.wait_stream(sy); main.wait_stream(sp)
         if self.side is not None:
             torch.cuda.current_stream(self.device).wait_stream(self.side)    # join: every weight gradient is written
 

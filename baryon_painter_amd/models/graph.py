@@ -315,6 +315,12 @@ class ConvUnit:
                      "packed": torch.zeros(n_bwd, device=dev)}
         self.packed_bwd = None
 
+    ws_name = "ws"      # which of the plan's workspaces this unit's reductions use (branches that run on
+                        # their own stream get their own: cvae._Plan)
+
+    def _ws(self):
+        return getattr(self.plan, self.ws_name)
+
     def macs(self, kind="forward"):
         """Multiply-accumulates of one forward (= of each of the two gradients; fewer for a data gradient
         restricted to a channel slice)."""
@@ -362,7 +368,7 @@ class ConvUnit:
         if bn is None:
             return
         if training:
-            L.check(lib.bp_channel_sums(C.byref(self.out.view), L.ptr(self.sums), L.ptr(plan.ws), plan.ws_bytes,
+            L.check(lib.bp_channel_sums(C.byref(self.out.view), L.ptr(self.sums), L.ptr(self._ws()), plan.ws_bytes,
                                         st), f"{self.name} bn stats")
             count = float(self.out.n * self.out.h * self.out.w)
             if plan.sync is not None and plan.sync.sync_bn:
@@ -414,7 +420,7 @@ class ConvUnit:
         aout = None if act_out is None else C.byref(act_out)
         d2 = None if dout2 is None else C.byref(dout2)
         L.check(lib.bp_act_backward(C.byref(dout), d2, C.byref(self.out.view), pw, aout,
-                                    None if g_out is None else C.byref(g_out), L.ptr(self.sums), L.ptr(plan.ws),
+                                    None if g_out is None else C.byref(g_out), L.ptr(self.sums), L.ptr(self._ws()),
                                     plan.ws_bytes, st), f"{self.name} act backward")
         if self.act == "prelu":
             L.check(lib.bp_prelu_slope_grad(L.ptr(self.sums), c, L.ptr(grads[id(self.act_holder.weight)]), st),
@@ -461,7 +467,7 @@ class ConvUnit:
         if getattr(plan, "skip_wgrad", False):
             pass        # only the data gradient is wanted (generator step through the discriminator)
         elif side is None:
-            wgrad(plan.ws)
+            wgrad(self._ws())
         else:
             side.wait_stream(torch.cuda.current_stream())     # fork: d_raw of this layer is complete
             with torch.cuda.stream(side):
