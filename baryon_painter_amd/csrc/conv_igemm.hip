@@ -95,6 +95,21 @@ __device__ __forceinline__ void igemm_store(const IgemmArgs& a, const v4f (&acc)
   }
 }
 
+// XCD-aware workgroup -> (tile, image x phase) mapping.  Workgroups are dealt to the 8 XCDs round-robin by
+// linear id, and each XCD has its own L2: with the natural order the tiles of one image (which share halo rows
+// and columns) land on 8 different L2s and every halo is fetched from HBM once per XCD.  Here XCD x works through
+// a contiguous range of the (image, tile) sequence instead, so neighbouring tiles meet in one L2
+// (bijective for any count: the first n%8 XCDs take one more).
+__device__ __forceinline__ void igemm_tile_of_block(int* tile, int* by) {
+  const int gx = gridDim.x, n = gx * gridDim.y;
+  const int L = blockIdx.y * gx + blockIdx.x;
+  const int q = n >> 3, r = n & 7;
+  const int xcd = L & 7, idx = L >> 3;
+  const int Lp = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  *tile = Lp % gx;
+  *by = Lp / gx;
+}
+
 template <int CC, int NT, int WN, int MT>
 __global__ __launch_bounds__(256, (MT == 4 && NT == 4) ? 4 : 1) void igemm_kernel(IgemmArgs a) {
   constexpr int VW = CC / 4;
@@ -110,12 +125,13 @@ __global__ __launch_bounds__(256, (MT == 4 && NT == 4) ? 4 : 1) void igemm_kerne
   const int wm = wave / WN, wn = wave % WN;
   const int lm = lane & 15, kq = lane >> 4;
 
-  const int tile = blockIdx.x;
-  const int tile_x = tile % a.tiles_x, tile_y = tile / a.tiles_x;
   // grid = (tiles, images x phases, channel blocks): workgroups that run together read the same weight slabs
+  int tile, by;
+  igemm_tile_of_block(&tile, &by);
+  const int tile_x = tile % a.tiles_x, tile_y = tile / a.tiles_x;
   const int co0 = blockIdx.z * COB;
-  const int ph = blockIdx.y % (a.nphase * a.nphase);
-  const int n = blockIdx.y / (a.nphase * a.nphase);
+  const int ph = by % (a.nphase * a.nphase);
+  const int n = by / (a.nphase * a.nphase);
   const int py = ph / a.nphase, px = ph % a.nphase;
 
   const int BW = 16 * a.TPR;
@@ -293,12 +309,13 @@ __global__ __launch_bounds__(64 * NW, NT == 4 ? ((WN == 2 && (SLOTS == 3 || NW =
   const int wm = wave / WN, wn = wave % WN;
   const int lm = lane & 15, kq = lane >> 4;
 
-  const int tile = blockIdx.x;
-  const int tile_x = tile % a.tiles_x, tile_y = tile / a.tiles_x;
   // grid = (tiles, images x phases, channel blocks): workgroups that run together read the same weight slabs
+  int tile, by;
+  igemm_tile_of_block(&tile, &by);
+  const int tile_x = tile % a.tiles_x, tile_y = tile / a.tiles_x;
   const int co0 = blockIdx.z * COB;
-  const int ph = blockIdx.y % (a.nphase * a.nphase);
-  const int n = blockIdx.y / (a.nphase * a.nphase);
+  const int ph = by % (a.nphase * a.nphase);
+  const int n = by / (a.nphase * a.nphase);
   const int py = ph / a.nphase, px = ph % a.nphase;
 
   const int BW = 16 * a.TPR;
@@ -485,12 +502,13 @@ __global__ __launch_bounds__(256, 2) void igemm_dmaf_kernel(IgemmArgs a) {
   const int wm = wave;
   const int lm = lane & 15, kq = lane >> 4;
 
-  const int tile = blockIdx.x;
+  int tile, by;
+  igemm_tile_of_block(&tile, &by);
   const int tile_x = tile % a.tiles_x, tile_y = tile / a.tiles_x;
   const int co0 = blockIdx.z * COB;
   const int nph2 = a.nphase * a.nphase;
-  const int ph0 = NPH == 1 ? blockIdx.y % nph2 : 0;
-  const int n = NPH == 1 ? blockIdx.y / nph2 : blockIdx.y;
+  const int ph0 = NPH == 1 ? by % nph2 : 0;
+  const int n = NPH == 1 ? by / nph2 : by;
   const int py0 = ph0 / a.nphase, px0 = ph0 % a.nphase;
 
   const int BW = 16 * a.TPR;

@@ -49,6 +49,22 @@ struct WtCfg {
   static constexpr size_t LDS = LDS_MAIN > LDS_RED ? LDS_MAIN : LDS_RED;
 };
 
+// XCD-aware workgroup -> (channel-block pair, tap-row group, pixel split) mapping.  Workgroups go to the 8 XCDs
+// round-robin by linear id; the channel-block pairs and tap-row groups of ONE split read the same pixel tiles, so
+// they are made consecutive members of one XCD's share (each XCD has its own L2) instead of neighbours on
+// different XCDs: the tiles then come from HBM once instead of once per pair.
+__device__ __forceinline__ void wt_block_coords(int* bx, int* by, int* bz) {
+  const int gx = gridDim.x, gy = gridDim.y;
+  const int n = gx * gy * gridDim.z;
+  const int L = (blockIdx.z * gy + blockIdx.y) * gx + blockIdx.x;
+  const int q = n >> 3, r = n & 7;
+  const int xcd = L & 7, idx = L >> 3;
+  const int Lp = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  *bx = Lp % gx;
+  *by = (Lp / gx) % gy;
+  *bz = Lp / (gx * gy);
+}
+
 template <int KHB, int KW, int S, int NTX, int NTY, int WX, int WY, int WK, int BH>
 __global__ __launch_bounds__(256) void wgrad_tiles_kernel(WtArgs a) {
   using Cfg = WtCfg<KHB, KW, S, NTX, NTY, WX, WY, WK, BH>;
@@ -66,9 +82,10 @@ __global__ __launch_bounds__(256) void wgrad_tiles_kernel(WtArgs a) {
   const int wx = wave / (WY * WK), wy = (wave / WK) % WY, wk = wave % WK;
   const int li = lane & 15, kq = lane >> 4;
 
-  const int cxb = blockIdx.x % a.ncxb, cyb = blockIdx.x / a.ncxb;
-  const int ky0 = blockIdx.y * KHB;
-  const int split = blockIdx.z;
+  int bx, by, split;
+  wt_block_coords(&bx, &by, &split);
+  const int cxb = bx % a.ncxb, cyb = bx / a.ncxb;
+  const int ky0 = by * KHB;
   const int cx0 = cxb * CXC, cy0 = cyb * CYC;
 
   v4f acc[TAPS][NTX][NTY];
@@ -281,9 +298,10 @@ __global__ __launch_bounds__(256) void wgrad_tiles_dma_kernel(WtArgs a) {
   const int wx = wave / (WY * WK), wy = (wave / WK) % WY, wk = wave % WK;
   const int li = lane & 15, kq = lane >> 4;
 
-  const int cxb = blockIdx.x % a.ncxb, cyb = blockIdx.x / a.ncxb;
-  const int ky0 = blockIdx.y * KHB;
-  const int split = blockIdx.z;
+  int bx, by, split;
+  wt_block_coords(&bx, &by, &split);
+  const int cxb = bx % a.ncxb, cyb = bx / a.ncxb;
+  const int ky0 = by * KHB;
   const int cx0 = cxb * CXC, cy0 = cyb * CYC;
 
   v4f acc[TAPS][NTX][NTY];

@@ -163,7 +163,7 @@ class _Plan:
         # (single device only: under data parallelism every batch-norm layer all-reduces its statistics, and
         #  collectives of one communicator must not be in flight on several streams at once)
         if os.environ.get("BP_BRANCH_STREAMS", "1") != "0" and self.q_units and self.p_units and model.sync is None:
-            self.branch = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+            self.branch = self._branch_streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
             self.ws_b, self.ws_c = torch.zeros_like(self.ws), torch.zeros_like(self.ws)
             for u in self._flat(self.q_units[1]):
                 u.ws_name = "ws_b"
@@ -493,10 +493,12 @@ class CVAE(torch.nn.Module):
         self._params = params
 
     def overlap_weight_gradients(self, enabled):
-        """Run the weight gradients on a second stream beside the rest of the backward pass (default), or serially
-        on the main stream (``False``: every kernel has the GPU to itself, e.g. to time kernels)."""
+        """Run the weight gradients (and the independent q_y_in / prior branches) on their own streams beside the
+        main chain (default), or everything serially on the main stream (``False``: every kernel has the GPU to
+        itself, e.g. to time kernels)."""
         for plan in self._plans.values():
             plan.side = plan._side_stream if enabled else None
+            plan.branch = plan._branch_streams if enabled else None
 
     def _bump_param_versions(self):
         """Called after an out-of-band in-place update of the flat buffer (FlatAdam): convolution units
