@@ -644,24 +644,45 @@ class CVAE(torch.nn.Module):
         return g["out"].clone()
 
     def _capture_paint_graph(self, n):
-        plan = self._plan(n, False, False)
+        """Eval-mode layers do not couple the tiles of a batch (batch-norm runs on its running statistics), so the
+        batch is painted as BP_PAINT_STREAMS (default 4) sub-batches on as many streams inside one graph: kernels of different layers share
+        the CUs and fill each other's stalls (the effect the training step gets from its weight-gradient
+        stream)."""
         cy, H, W = self.dim_y
         cx = self.dim_x[0]
         st = {"y": torch.zeros((n, cy, H, W), device=self.device),
               "aux": torch.zeros((n, self.n_aux), device=self.device) if self.use_aux_label else None,
               "out": torch.zeros((n, cx, H, W), device=self.device)}
+        parts = int(os.environ.get("BP_PAINT_STREAMS", "4"))
+        while parts > 1 and (n % parts != 0 or n // parts < 8):
+            parts -= 1
+        h = n // parts
+        plans = [self._plan(h, False, False)] + [_Plan(self, h, False, False) for _ in range(parts - 1)]
+        st["plans"] = plans
         units = []
-        for us in [plan.p_units] + plan.g_units + [plan.mu_units]:
-            for u in us:
-                units += u.body if hasattr(u, "body") else [u]
+        for plan in plans:
+            for us in [plan.p_units] + plan.g_units + [plan.mu_units]:
+                for u in us:
+                    units += u.body if hasattr(u, "body") else [u]
         st["units"] = units
+        others = [torch.cuda.Stream(device=self.device) for _ in range(parts - 1)]
+
+        def paint(plan, lo):
+            plan.load_inputs(st["y"][lo:lo + h], None if st["aux"] is None else st["aux"][lo:lo + h])
+            plan.run_prior(False)
+            plan.run_latent(torch.randn(size=(self.L, h, *self.dim_z), device=self.device), use_q=False)
+            plan.run_generator(False)
+            self._head_to_nchw(plan.mu_head, plan.mu_softplus, st["out"][lo:lo + h])
 
         def run():
-            plan.load_inputs(st["y"], st["aux"])
-            plan.run_prior(False)
-            plan.run_latent(torch.randn(size=(self.L, n, *self.dim_z), device=self.device), use_q=False)
-            plan.run_generator(False)
-            self._head_to_nchw(plan.mu_head, plan.mu_softplus, st["out"])
+            main = torch.cuda.current_stream(self.device)
+            for k, s2 in enumerate(others):
+                s2.wait_stream(main)
+                with torch.cuda.stream(s2):
+                    paint(plans[k + 1], (k + 1) * h)
+            paint(plans[0], 0)
+            for s2 in others:
+                main.wait_stream(s2)
 
         side = torch.cuda.Stream(device=self.device)
         side.wait_stream(torch.cuda.current_stream(self.device))
