@@ -9,7 +9,7 @@ rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 ARGS="$R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-paint"
 timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $OUT/stats -o r --output-format csv -- python3 $ARGS > $OUT/stats.log 2>&1
-export BP_SIDE_WGRAD=0
+export BP_SIDE_WGRAD=0 BP_BRANCH_STREAMS=0
 timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $OUT/stats_serial -o r --output-format csv -- python3 $ARGS > $OUT/stats_serial.log 2>&1
 timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/fetch -o r --output-format csv -- python3 $ARGS > $OUT/fetch.log 2>&1
 timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/write -o r --output-format csv -- python3 $ARGS > $OUT/write.log 2>&1
