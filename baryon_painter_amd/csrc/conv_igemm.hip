@@ -1,18 +1,25 @@
 // Implicit-GEMM direct convolution on the fp32 matrix cores (v_mfma_f32_16x16x4_f32), NHWC.
 //
-// One kernel serves Conv2d forward, ConvTranspose2d forward and both data gradients: each is a
-// stride-IS correlation over an output sub-grid ("phase", see ConvGeom in common.hpp).
-//   GEMM view:  M = 16 consecutive output pixels of one row,  N = 16 produced channels,
-//               K = (tap, gathered channel), 4 channels per MFMA.
-// A workgroup (4 waves) owns BH x BW output pixels x COB produced channels.  Per channel chunk CC
-// it stages the input halo tile through registers into LDS -- applying the producer's pending
-// batch-norm affine + leaky-ReLU on the way, zero padding AFTER the activation as torch does --
-// and per tap row the matching slab of pre-packed weights.  LDS images:
-//   input  [row][x % IS][x / IS][CC]    (x de-interleaved by the stride so that the 16 pixels of
-//                                        an M tile are contiguous for every tap: conflict-free)
-//   weight [tx][COB][CC]
-// Lane l supplies k-slice (l>>4): it reads CC/4 consecutive channels (b32/b64/b128) of its pixel
-// (A) and of its produced channel (B) and issues CC/4 MFMAs from them.
+// Conv2d forward, ConvTranspose2d forward and both data gradients are ONE operation here: a stride-IS
+// correlation over an output sub-grid ("phase", see ConvGeom in common.hpp).
+//   GEMM view:  16 consecutive output pixels of one row  x  16 produced channels per MFMA,
+//               K = (tap, gathered channel), 4 channels per MFMA; issued as D = W-tile x X-tile so that a lane
+//               ends up with 4 consecutive channels of one pixel (16-byte NHWC stores).
+// LDS images:  input  [row][x % IS][x / IS][CC]   (x de-interleaved by the stride: the 16 pixels of an M tile
+//                                                  are contiguous for every tap -> conflict-free reads)
+//              weight [tap][COB][CC]
+// Lane l supplies k-slice (l>>4): it reads CC/4 consecutive channels (b32/b64/b128) of its pixel and of its
+// produced channel and issues CC/4 MFMAs from them.
+//
+// Three kernels share that formulation (igemm_config picks per layer):
+//   igemm_kernel       stages the halo tile through registers (pending activation applied on the way, zero
+//                      padding AFTER it, as torch does) and the weights per tap row; takes few-channel layers,
+//                      pixel packing (<= 8 produced channels) and strided gathers whose halo does not fit twice
+//   igemm_dma_kernel   both operands by LDS-DMA one step ahead (2-deep weight-slab ring, two input buffers,
+//                      in-place rewrite for activation / padding); 4 or 8 waves; the 64-512-channel layers
+//   igemm_dmaf_kernel  LDS-DMA with a tap row per barrier and all stride^2 phases of a transposed form from one
+//                      staged tile; layers with <= 32 produced channels
+// Workgroups are mapped to tiles XCD-aware (igemm_tile_of_block); the channel block is the slowest grid dimension.
 #include "common.hpp"
 #include <cstdlib>
 
