@@ -23,12 +23,14 @@ struct SmallArgs {
   const float* wp; const float* bias;
   PW pw;
   int i0;            // first gathered row/column relative to the output position
+  int ci_total;      // gathered channels of the layer (a multiple of the kernel's CI: it loops over chunks)
   int tiles_x, tiles_y;
   int in_vec, out_vec;
 };
 
-template <int K, int CI, int CO, int TH>
+template <int K, int CI, int CO, int TH, bool CHUNKED>
 __global__ __launch_bounds__(256) void small_conv_kernel(SmallArgs a) {
+  const int CT = CHUNKED ? a.ci_total : CI;     // gathered channels of the layer (compile-time when one tile holds them)
   constexpr int TW = 64, PXR = TH / 4;   // 4 waves x PXR rows
   constexpr int IW = TW + K - 1, IH = TH + K - 1;
   constexpr int CQ = CI >= 4 ? CI / 4 : 1;      // channel quads
@@ -41,38 +43,7 @@ __global__ __launch_bounds__(256) void small_conv_kernel(SmallArgs a) {
   const int x0 = tx_ * TW, y0 = ty_ * TH;
   const float* in_n = a.in + (int64_t)n * a.in_h * a.in_w * a.in_cs + a.in_co;
 
-  // ---- stage the tile (activation applied, zero outside the image)
-  if (CI >= 4) {
-    const int c4 = tid % CQ;
-    const PW4 p4 = pw4_load(a.pw, c4 * 4, CI);
-    for (int e = tid; e < IH * IW * CQ; e += 256) {
-      const int pix = e / CQ;
-      const int c = pix % IW, r = pix / IW;
-      const int iy = y0 + a.i0 + r, ix = x0 + a.i0 + c;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (iy >= 0 && iy < a.in_h && ix >= 0 && ix < a.in_w) {
-        const float* p = in_n + ((int64_t)iy * a.in_w + ix) * a.in_cs + c4 * 4;
-        if (a.in_vec) v = *reinterpret_cast<const float4*>(p);
-        else v = make_float4(p[0], p[1], p[2], p[3]);
-        v = pw4_apply4(p4, v);
-      }
-      *reinterpret_cast<float4*>(tile + ((r * CQ + c4) * IW + c) * 4) = v;
-    }
-  } else {
-    for (int e = tid; e < IH * IW * CI; e += 256) {
-      const int ch = e % CI;
-      const int pix = e / CI;
-      const int c = pix % IW, r = pix / IW;
-      const int iy = y0 + a.i0 + r, ix = x0 + a.i0 + c;
-      float v = 0.f;
-      if (iy >= 0 && iy < a.in_h && ix >= 0 && ix < a.in_w)
-        v = pw_apply(a.pw, ch, in_n[((int64_t)iy * a.in_w + ix) * a.in_cs + ch]);
-      tile[(r * IW + c) * CI + ch] = v;
-    }
-  }
-  __syncthreads();
-
-  // ---- thread = column `col`, output rows r0 .. r0+3
+  // ---- thread = column `col`, output rows r0 .. r0+PXR-1
   const int col = tid & 63, r0 = (tid >> 6) * PXR;
   float acc[PXR][CO];
 #pragma unroll
@@ -80,33 +51,69 @@ __global__ __launch_bounds__(256) void small_conv_kernel(SmallArgs a) {
 #pragma unroll
     for (int co = 0; co < CO; ++co) acc[j][co] = a.bias ? a.bias[co] : 0.f;
 
-  // kx outermost and NOT unrolled: only the K*CI*CO weights of one tap column are live in SGPRs at a time
-  // (all K*K*CI*CO would spill).
-#pragma unroll 1
-  for (int kx = 0; kx < K; ++kx) {
-    const float* wk = a.wp + kx * CI * CO;
-#pragma unroll
-    for (int dy = 0; dy < PXR + K - 1; ++dy) {
-      float v[CI];
-      if constexpr (CI >= 4) {
-#pragma unroll
-        for (int q = 0; q < CQ; ++q) {
-          const float4 t = *reinterpret_cast<const float4*>(tile + (((r0 + dy) * CQ + q) * IW + col + kx) * 4);
-          v[q * 4 + 0] = t.x; v[q * 4 + 1] = t.y; v[q * 4 + 2] = t.z; v[q * 4 + 3] = t.w;
+  // layers with more gathered channels than fit one tile (k9 32->1) run in chunks of CI channels
+  for (int c0 = 0; c0 < CT; c0 += CI) {
+    if (c0) __syncthreads();     // the previous chunk's tile is read out
+    // ---- stage the tile (activation applied, zero outside the image)
+    if (CI >= 4) {
+      const int c4 = tid % CQ;
+      const PW4 p4 = pw4_load(a.pw, c0 + c4 * 4, CT);
+      for (int e = tid; e < IH * IW * CQ; e += 256) {
+        const int pix = e / CQ;
+        const int c = pix % IW, r = pix / IW;
+        const int iy = y0 + a.i0 + r, ix = x0 + a.i0 + c;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (iy >= 0 && iy < a.in_h && ix >= 0 && ix < a.in_w) {
+          const float* p = in_n + ((int64_t)iy * a.in_w + ix) * a.in_cs + c0 + c4 * 4;
+          if (a.in_vec) v = *reinterpret_cast<const float4*>(p);
+          else v = make_float4(p[0], p[1], p[2], p[3]);
+          v = pw4_apply4(p4, v);
         }
-      } else {
-#pragma unroll
-        for (int ci = 0; ci < CI; ++ci) v[ci] = tile[((r0 + dy) * IW + col + kx) * CI + ci];
+        *reinterpret_cast<float4*>(tile + ((r * CQ + c4) * IW + c) * 4) = v;
       }
+    } else {
+      for (int e = tid; e < IH * IW * CI; e += 256) {
+        const int ch = e % CI;
+        const int pix = e / CI;
+        const int c = pix % IW, r = pix / IW;
+        const int iy = y0 + a.i0 + r, ix = x0 + a.i0 + c;
+        float v = 0.f;
+        if (iy >= 0 && iy < a.in_h && ix >= 0 && ix < a.in_w)
+          v = pw_apply(a.pw, c0 + ch, in_n[((int64_t)iy * a.in_w + ix) * a.in_cs + c0 + ch]);
+        tile[(r * IW + c) * CI + ch] = v;
+      }
+    }
+    __syncthreads();
+
+    // kx outermost and NOT unrolled: only the K*CI*CO weights of one tap column are live in SGPRs at a time
+    // (all K*K*CI*CO would spill).
+#pragma unroll 1
+    for (int kx = 0; kx < K; ++kx) {
+      const float* wk = a.wp + (kx * CT + c0) * CO;
+      const int wrow = K * CT * CO;                   // floats between tap rows
 #pragma unroll
-      for (int j = 0; j < PXR; ++j) {
-        const int ky = dy - j;               // compile-time after unrolling
-        if (ky >= 0 && ky < K) {
+      for (int dy = 0; dy < PXR + K - 1; ++dy) {
+        float v[CI];
+        if constexpr (CI >= 4) {
 #pragma unroll
-          for (int ci = 0; ci < CI; ++ci)
+          for (int q = 0; q < CQ; ++q) {
+            const float4 t = *reinterpret_cast<const float4*>(tile + (((r0 + dy) * CQ + q) * IW + col + kx) * 4);
+            v[q * 4 + 0] = t.x; v[q * 4 + 1] = t.y; v[q * 4 + 2] = t.z; v[q * 4 + 3] = t.w;
+          }
+        } else {
 #pragma unroll
-            for (int co = 0; co < CO; ++co)
-              acc[j][co] = fmaf(v[ci], wk[(ky * K * CI + ci) * CO + co], acc[j][co]);
+          for (int ci = 0; ci < CI; ++ci) v[ci] = tile[((r0 + dy) * IW + col + kx) * CI + ci];
+        }
+#pragma unroll
+        for (int j = 0; j < PXR; ++j) {
+          const int ky = dy - j;               // compile-time after unrolling
+          if (ky >= 0 && ky < K) {
+#pragma unroll
+            for (int ci = 0; ci < CI; ++ci)
+#pragma unroll
+              for (int co = 0; co < CO; ++co)
+                acc[j][co] = fmaf(v[ci], wk[ky * wrow + ci * CO + co], acc[j][co]);
+          }
         }
       }
     }
@@ -151,11 +158,11 @@ __global__ void small_pack_kernel(SmallPackArgs a) {
   a.dst[i] = a.w[ci * a.sa + co * a.sb + ky * a.k + kx];
 }
 
-template <int K, int CI, int CO, int TH>
+template <int K, int CI, int CO, int TH, bool CHUNKED = false>
 int launch(SmallArgs a, const bp_view* out, int n, hipStream_t st) {
   a.tiles_x = bp_ceil_div(out->w, 64);
   a.tiles_y = bp_ceil_div(out->h, TH);
-  hipLaunchKernelGGL((small_conv_kernel<K, CI, CO, TH>), dim3((unsigned)(a.tiles_x * a.tiles_y), (unsigned)n),
+  hipLaunchKernelGGL((small_conv_kernel<K, CI, CO, TH, CHUNKED>), dim3((unsigned)(a.tiles_x * a.tiles_y), (unsigned)n),
                      dim3(256), 0, st, a);
   BP_CHECK_LAUNCH();
   return BP_OK;
@@ -168,7 +175,8 @@ bool bp_small_ok(const ConvGeom& g) {
   static const bool off = getenv("BP_NOSMALL") != nullptr;
   if (off || g.IS != 1 || g.OS != 1 || g.nphase != 1 || g.stride != 1) return false;
   return (g.k == 5 && g.cin_g == 8 && g.cout_g == 1) || (g.k == 5 && g.cin_g == 1 && g.cout_g == 8) ||
-         (g.k == 5 && g.cin_g == 16 && g.cout_g == 1) || (g.k == 3 && g.cin_g == 1 && g.cout_g == 1);
+         (g.k == 5 && g.cin_g == 16 && g.cout_g == 1) || (g.k == 3 && g.cin_g == 1 && g.cout_g == 1) ||
+         (g.k == 9 && g.cin_g % 8 == 0 && g.cin_g <= 64 && g.cout_g <= 2);      // CGAN head and stem gradient
 }
 
 int64_t bp_small_packed_floats(const ConvGeom& g) { return (int64_t)g.k * g.k * g.cin_g * g.cout_g; }
@@ -190,7 +198,7 @@ int bp_small_run(const ConvGeom& g, const bp_view* in, const PW& pw, const float
   SmallArgs a{};
   a.in = in->ptr; a.in_h = in->h; a.in_w = in->w; a.in_cs = in->cstride; a.in_co = in->coff;
   a.out = out->ptr; a.out_h = out->h; a.out_w = out->w; a.out_cs = out->cstride; a.out_co = out->coff;
-  a.wp = packed; a.bias = bias; a.pw = pw;
+  a.wp = packed; a.bias = bias; a.pw = pw; a.ci_total = g.cin_g;
   a.i0 = g.gather_transposed ? bp_t_i0(0, g.pad, 1, g.k) : -g.pad;
   a.in_vec = bp_view_vec4(in) ? 1 : 0;
   a.out_vec = bp_view_vec4(out) ? 1 : 0;
@@ -199,5 +207,7 @@ int bp_small_run(const ConvGeom& g, const bp_view* in, const PW& pw, const float
   if (g.k == 5 && g.cin_g == 1 && g.cout_g == 8) return launch<5, 1, 8, 16>(a, out, in->n, st);
   if (g.k == 5 && g.cin_g == 16 && g.cout_g == 1) return launch<5, 16, 1, 8>(a, out, in->n, st);
   if (g.k == 3 && g.cin_g == 1 && g.cout_g == 1) return launch<3, 1, 1, 16>(a, out, in->n, st);
+  if (g.k == 9 && g.cout_g == 1) return launch<9, 8, 1, 8, true>(a, out, in->n, st);
+  if (g.k == 9 && g.cout_g == 2) return launch<9, 8, 2, 8, true>(a, out, in->n, st);
   return BP_EUNSUPPORTED;
 }

@@ -200,7 +200,7 @@ def test_dma_pipelined_kernels_ragged_views_and_activation(case):
 
 
 # unit-stride layers with cin*cout <= 16 served by the vector-ALU kernel (conv_small.hip) in at least one direction
-SMALL_CASES = [(8, 1, 5, 2), (1, 8, 5, 2), (1, 16, 5, 2), (1, 1, 3, 1)]
+SMALL_CASES = [(8, 1, 5, 2), (1, 8, 5, 2), (1, 16, 5, 2), (1, 1, 3, 1), (32, 1, 9, 4), (2, 32, 9, 4)]
 
 
 @pytest.mark.parametrize("case", SMALL_CASES, ids=lambda c: "%d_%d_k%d" % c[:3])
