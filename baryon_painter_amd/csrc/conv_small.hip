@@ -176,7 +176,8 @@ bool bp_small_ok(const ConvGeom& g) {
   if (off || g.IS != 1 || g.OS != 1 || g.nphase != 1 || g.stride != 1) return false;
   return (g.k == 5 && g.cin_g == 8 && g.cout_g == 1) || (g.k == 5 && g.cin_g == 1 && g.cout_g == 8) ||
          (g.k == 5 && g.cin_g == 16 && g.cout_g == 1) || (g.k == 3 && g.cin_g == 1 && g.cout_g == 1) ||
-         (g.k == 9 && g.cin_g % 8 == 0 && g.cin_g <= 64 && g.cout_g <= 2);      // CGAN head and stem gradient
+         (g.k == 9 && g.cin_g % 8 == 0 && g.cin_g <= 64 && g.cout_g <= 2) ||    // CGAN head and stem gradient
+         (g.k == 4 && g.cin_g % 8 == 0 && g.cin_g <= 1024 && g.cout_g == 1);   // PatchGAN logits (512 -> 1)
 }
 
 int64_t bp_small_packed_floats(const ConvGeom& g) { return (int64_t)g.k * g.k * g.cin_g * g.cout_g; }
@@ -207,6 +208,7 @@ int bp_small_run(const ConvGeom& g, const bp_view* in, const PW& pw, const float
   if (g.k == 5 && g.cin_g == 1 && g.cout_g == 8) return launch<5, 1, 8, 16>(a, out, in->n, st);
   if (g.k == 5 && g.cin_g == 16 && g.cout_g == 1) return launch<5, 16, 1, 8>(a, out, in->n, st);
   if (g.k == 3 && g.cin_g == 1 && g.cout_g == 1) return launch<3, 1, 1, 16>(a, out, in->n, st);
+  if (g.k == 4 && g.cout_g == 1) return launch<4, 8, 1, 16, true>(a, out, in->n, st);
   if (g.k == 9 && g.cout_g == 1) return launch<9, 8, 1, 8, true>(a, out, in->n, st);
   if (g.k == 9 && g.cout_g == 2) return launch<9, 8, 2, 8, true>(a, out, in->n, st);
   return BP_EUNSUPPORTED;

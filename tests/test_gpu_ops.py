@@ -200,7 +200,7 @@ def test_dma_pipelined_kernels_ragged_views_and_activation(case):
 
 
 # unit-stride layers with cin*cout <= 16 served by the vector-ALU kernel (conv_small.hip) in at least one direction
-SMALL_CASES = [(8, 1, 5, 2), (1, 8, 5, 2), (1, 16, 5, 2), (1, 1, 3, 1), (32, 1, 9, 4), (2, 32, 9, 4)]
+SMALL_CASES = [(8, 1, 5, 2), (1, 8, 5, 2), (1, 16, 5, 2), (1, 1, 3, 1), (32, 1, 9, 4), (2, 32, 9, 4), (64, 1, 4, 1)]
 
 
 @pytest.mark.parametrize("case", SMALL_CASES, ids=lambda c: "%d_%d_k%d" % c[:3])
@@ -224,7 +224,8 @@ def test_small_channel_kernels_ragged_views_and_activation(case):
     assert max(ids) >= 900000, "case is meant for small_conv_kernel"
     st = G.stream()
     xb, xv = G.to_nhwc(x, cstride=ci + 4, coff=4)
-    yb, yv = G.empty_nhwc(n, h, w, co, cstride=co + 3, coff=2)
+    ho, wo = y_ref.shape[2:]
+    yb, yv = G.empty_nhwc(n, ho, wo, co, cstride=co + 3, coff=2)
     keep, pw = G.pointwise(scale, shift, slope)
     wd, bd = G.dev(wt), G.dev(bias)
     pf = torch.zeros(lib.bp_conv_packed_floats(C.byref(cv), L.PACK_FWD), device="cuda")
