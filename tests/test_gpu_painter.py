@@ -254,3 +254,17 @@ def test_painter_train_with_graph_step(tmp_path):
     elbo = np.asarray(ts.loss_terms["ELBO"]["all"])
     assert len(elbo) >= 8 and np.isfinite(elbo).all()
     assert elbo[-4:].mean() > elbo[:4].mean(), "ELBO should improve over the first steps"
+
+
+def test_training_script_runs_end_to_end(tmp_path):
+    """scripts/CVAE_single_scale.py (the reference's training entry point, same constants and painter.train call)
+    on the synthetic fallback dataset, shortened through its environment overrides."""
+    env = dict(os.environ, BP_TILE="64", BP_N_PEPOCH="1", BP_OUTPUT_PATH=str(tmp_path / "out"), BP_DEVICE="cuda:0",
+               BP_DATA_PATH=str(tmp_path / "no_such_stacks"))
+    r = subprocess.run([sys.executable, "CVAE_single_scale.py"], cwd=os.path.join(ROOT, "scripts"), env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    runs = list((tmp_path / "out").iterdir())
+    assert len(runs) == 1
+    files = {p.name for p in runs[0].iterdir()}
+    assert {"model_state", "model_meta", "training_stats.txt", "validation_stats.txt"} <= files, files
