@@ -51,6 +51,9 @@ SIGNATURES = {
     "bp_conv_packed_floats": (C.c_int64, [_CP, C.c_int]),
     "bp_conv_kernel_id": (C.c_int, [_CP, C.c_int]),
     "bp_conv_pack": (C.c_int, [_CP, C.c_int, _P, _P, _P]),
+    "bp_conv_pack_job_bytes": (C.c_int32, []),
+    "bp_conv_pack_job": (C.c_int, [_CP, C.c_int, _P, _P, _P, C.POINTER(C.c_int64)]),
+    "bp_conv_pack_jobs": (C.c_int, [_P, _P, C.c_int32, C.c_int64, _P]),
     "bp_conv_forward": (C.c_int, [_CP, _VP, _PWP, _P, _P, _P, _VP, C.c_int, _P]),
     "bp_conv_backward_data": (C.c_int, [_CP, _VP, _P, _P, _VP, C.c_int, _P]),
     "bp_conv_backward_weight_workspace": (C.c_size_t, [_CP, _VP, _VP]),

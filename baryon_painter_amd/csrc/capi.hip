@@ -5,6 +5,11 @@
 int64_t bp_igemm_packed_floats(const ConvGeom& g);
 int bp_igemm_kernel_id(const ConvGeom& g);
 int bp_igemm_pack(const ConvGeom& g, const WeightMap& wm, const float* w_torch, float* packed, hipStream_t st);
+size_t bp_igemm_pack_job_bytes();
+int bp_igemm_pack_job(const ConvGeom& g, const WeightMap& wm, const float* w_torch, float* packed, void* job,
+                      int64_t* nblocks);
+int bp_igemm_pack_jobs(const void* jobs_dev, const int64_t* first_block_dev, int njobs, int64_t total_blocks,
+                       hipStream_t st);
 int bp_igemm_run(const ConvGeom& g, const bp_view* in, const PW& pw, const float* packed, const float* bias,
                  const bp_view* out, hipStream_t st);
 int bp_direct_gather(const ConvGeom& g, const WeightMap& wm, const bp_view* in, const PW& pw, const float* w_torch,
@@ -65,6 +70,21 @@ int bp_conv_pack(const bp_conv* cv, int dir, const float* w_torch, float* packed
   if (!conv_ok(cv) || !w_torch || !packed || (dir != BP_PACK_FWD && dir != BP_PACK_BWD)) return BP_EINVAL;
   const ConvGeom g = dir == BP_PACK_FWD ? bp_geom_forward(cv) : bp_geom_backward_data(cv);
   return bp_igemm_pack(g, bp_wmap(cv, dir), w_torch, packed, bp_stream(stream));
+}
+
+int32_t bp_conv_pack_job_bytes(void) { return (int32_t)bp_igemm_pack_job_bytes(); }
+
+int bp_conv_pack_job(const bp_conv* cv, int dir, const float* w_torch, float* packed, void* job, int64_t* nblocks) {
+  if (!conv_ok(cv) || !w_torch || !packed || !job || !nblocks || (dir != BP_PACK_FWD && dir != BP_PACK_BWD))
+    return BP_EINVAL;
+  const ConvGeom g = dir == BP_PACK_FWD ? bp_geom_forward(cv) : bp_geom_backward_data(cv);
+  return bp_igemm_pack_job(g, bp_wmap(cv, dir), w_torch, packed, job, nblocks);
+}
+
+int bp_conv_pack_jobs(const void* jobs_dev, const int64_t* first_block_dev, int32_t njobs, int64_t total_blocks,
+                      void* stream) {
+  if (!jobs_dev || !first_block_dev || njobs < 0 || total_blocks < 0) return BP_EINVAL;
+  return bp_igemm_pack_jobs(jobs_dev, first_block_dev, njobs, total_blocks, bp_stream(stream));
 }
 
 int bp_conv_forward(const bp_conv* cv, const bp_view* x, const bp_pointwise* x_pw, const float* packed_fwd,

@@ -707,8 +707,7 @@ struct PackArgs {
   int64_t total;
 };
 
-__global__ __launch_bounds__(256) void pack_kernel(PackArgs a) {
-  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void pack_element(const PackArgs& a, int64_t i) {
   if (i >= a.total) return;
   int64_t r = i;
   const int cl = r % a.CC; r /= a.CC;
@@ -736,6 +735,23 @@ __global__ __launch_bounds__(256) void pack_kernel(PackArgs a) {
   if (ci < a.cin_g && cch < a.cout_g && ky < a.k && kx >= 0 && kx < a.k)
     v = a.w[ci * a.sa + cch * a.sb + ky * a.k + kx];
   a.dst[i] = v;
+}
+
+__global__ __launch_bounds__(256) void pack_kernel(PackArgs a) {
+  pack_element(a, (int64_t)blockIdx.x * 256 + threadIdx.x);
+}
+
+// Every layer's weights in ONE launch: `jobs` is a device table of PackArgs, `first_block[j]` the first workgroup
+// of job j (first_block[njobs] = grid size).  A workgroup finds its job by bisection.
+__global__ __launch_bounds__(256) void pack_jobs_kernel(const PackArgs* jobs, const int64_t* first_block, int njobs) {
+  const int64_t b = blockIdx.x;
+  int lo = 0, hi = njobs;              // invariant: first_block[lo] <= b < first_block[hi]
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (first_block[mid] <= b) lo = mid; else hi = mid;
+  }
+  const PackArgs a = jobs[lo];
+  pack_element(a, (b - first_block[lo]) * 256 + threadIdx.x);
 }
 
 // Spatial tile of one workgroup and the halo it gathers.
@@ -976,18 +992,46 @@ int64_t bp_igemm_packed_floats(const ConvGeom& g) {
   return (int64_t)g.nphase * g.nphase * g.taps * c.tapsx * c.nchunk * c.cout_padP * c.CC;
 }
 
-int bp_igemm_pack(const ConvGeom& g, const WeightMap& wm, const float* w_torch, float* packed,
-                  hipStream_t st) {
-  if (bp_small_ok(g)) return bp_small_pack(g, wm, w_torch, packed, st);
+static bool igemm_pack_args(const ConvGeom& g, const WeightMap& wm, const float* w_torch, float* packed, PackArgs& a) {
   const IgemmConfig c = igemm_config(g);
-  if (!c.ok) return BP_EUNSUPPORTED;
-  PackArgs a{};
+  if (!c.ok) return false;
+  a = PackArgs{};
   a.w = w_torch; a.dst = packed; a.sa = wm.sa; a.sb = wm.sb;
   a.k = g.k; a.stride = g.stride; a.pad = g.pad; a.tapsy = g.taps; a.tapsx = c.tapsx; a.nphase = g.nphase;
   a.transposed = g.gather_transposed; a.cin_g = g.cin_g; a.cout_g = g.cout_g;
   a.CC = c.CC; a.nchunk = c.nchunk; a.cout_padP = c.cout_padP; a.PP = c.PP; a.COP = c.COP;
   a.total = bp_igemm_packed_floats(g);
+  return true;
+}
+
+int bp_igemm_pack(const ConvGeom& g, const WeightMap& wm, const float* w_torch, float* packed,
+                  hipStream_t st) {
+  if (bp_small_ok(g)) return bp_small_pack(g, wm, w_torch, packed, st);
+  PackArgs a;
+  if (!igemm_pack_args(g, wm, w_torch, packed, a)) return BP_EUNSUPPORTED;
   hipLaunchKernelGGL(pack_kernel, dim3((unsigned)((a.total + 255) / 256)), dim3(256), 0, st, a);
+  BP_CHECK_LAUNCH();
+  return BP_OK;
+}
+
+// Batched packing (bp_conv_pack_job / bp_conv_pack_jobs): the job record is the kernel's own argument block.
+size_t bp_igemm_pack_job_bytes() { return sizeof(PackArgs); }
+
+int bp_igemm_pack_job(const ConvGeom& g, const WeightMap& wm, const float* w_torch, float* packed, void* job,
+                      int64_t* nblocks) {
+  if (bp_small_ok(g)) return BP_EUNSUPPORTED;       // (its own tiny pack kernel: packed by bp_conv_pack)
+  PackArgs a;
+  if (!igemm_pack_args(g, wm, w_torch, packed, a)) return BP_EUNSUPPORTED;
+  *reinterpret_cast<PackArgs*>(job) = a;
+  *nblocks = (a.total + 255) / 256;
+  return BP_OK;
+}
+
+int bp_igemm_pack_jobs(const void* jobs_dev, const int64_t* first_block_dev, int njobs, int64_t total_blocks,
+                       hipStream_t st) {
+  if (njobs <= 0 || total_blocks <= 0) return BP_OK;
+  hipLaunchKernelGGL(pack_jobs_kernel, dim3((unsigned)total_blocks), dim3(256), 0, st,
+                     reinterpret_cast<const PackArgs*>(jobs_dev), first_block_dev, njobs);
   BP_CHECK_LAUNCH();
   return BP_OK;
 }

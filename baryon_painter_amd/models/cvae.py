@@ -18,7 +18,7 @@ import torch
 
 from .. import _lib as L
 from .arch import conv_block, conv_down, conv_up, res_block  # noqa: F401  (reference: ``from .utils import *``)
-from .graph import (PW, ConvUnit, Slot, build_holders, compile_sequential, probe_output, _stream)
+from .graph import (PW, ConvUnit, PackBatch, Slot, build_holders, compile_sequential, probe_output, _stream)
 
 pi = math.pi
 
@@ -159,7 +159,10 @@ class _Plan:
             self.ws2 = torch.zeros_like(self.ws)
         # q_x_in, q_y_in and the prior network are independent chains of small kernels (none fills the GPU):
         # q_y_in and the prior run on their own streams, each with its own reduction workspace
-        self.branch = None
+        all_units = self._flat([u for us in self.q_units for u in us] + list(self.p_units)
+                               + [u for us in self.g_units for u in us] + list(self.mu_units) + list(self.var_units))
+        self.pack_batch = PackBatch(self, [u for u in all_units if isinstance(u, ConvUnit)])
+        self.branch = self._branch_streams = None
         # (single device only: under data parallelism every batch-norm layer all-reduces its statistics, and
         #  collectives of one communicator must not be in flight on several streams at once)
         if os.environ.get("BP_BRANCH_STREAMS", "1") != "0" and self.q_units and self.p_units and model.sync is None:
@@ -245,7 +248,16 @@ class _Plan:
         self.seed = torch.ones(1, device=self.device)
 
     # ---- execution
+    def pack_all(self):
+        """Re-pack every layer's weights (one launch) if any parameter changed since the last pack."""
+        us = self.pack_batch.units
+        if all(u._packed_version == (u.holder.weight._version, u.holder.weight.data_ptr(),
+                                      getattr(self.model, "_param_epoch", 0)) for u in us):
+            return
+        self.pack_batch.run()
+
     def load_inputs(self, y, aux, x=None):
+        self.pack_all()
         lib, st = self.lib, _stream()
         m = self.model
         cy = m.dim_y[0]

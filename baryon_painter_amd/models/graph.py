@@ -486,6 +486,63 @@ class ConvUnit:
             plan.prof_end(t0, self, "backward_data")
 
 
+class PackBatch:
+    """All weight re-layouts of a plan in one launch (``bp_conv_pack_jobs``) instead of two per layer.
+
+    The job table holds raw pointers: it is rebuilt when the parameter storage moves.  Layers whose packing is
+    not batchable (vector-ALU kernels) keep their own ``bp_conv_pack`` call."""
+
+    def __init__(self, plan, units):
+        self.plan, self.units = plan, units
+        self._storage = None
+
+    def _build(self):
+        lib, dev = self.plan.lib, self.plan.device
+        nb = lib.bp_conv_pack_job_bytes()
+        recs, counts, self.rest = [], [], []
+        for u in self.units:
+            jobs = [(u.cv, L.PACK_FWD, u.holder.weight, u.packed_fwd)]
+            if u.packed_bwd is not None:
+                jobs.append((u.cv, L.PACK_BWD, u.holder.weight, u.packed_bwd))
+            if u._sub is not None:
+                jobs.append((u._sub["cv"], L.PACK_BWD, u._sub["w"], u._sub["packed"]))
+            for cv, d, w, packed in jobs:
+                buf = (C.c_char * nb)()
+                n = C.c_int64(0)
+                rc = lib.bp_conv_pack_job(C.byref(cv), d, L.ptr(w), L.ptr(packed), buf, C.byref(n))
+                if rc == L.BP_OK:
+                    recs.append(bytes(buf))
+                    counts.append(n.value)
+                else:
+                    self.rest.append((cv, d, w, packed))
+        first = [0]
+        for c in counts:
+            first.append(first[-1] + c)
+        self.njobs, self.total_blocks = len(recs), first[-1]
+        self.jobs = torch.frombuffer(bytearray(b"".join(recs) or b"\0"), dtype=torch.uint8).to(dev)
+        self.first = torch.tensor(first, dtype=torch.int64, device=dev)
+
+    def run(self):
+        plan, lib, st = self.plan, self.plan.lib, _stream()
+        storage = tuple(u.holder.weight.data_ptr() for u in self.units)
+        if storage != self._storage:
+            self._build()
+            self._storage = storage
+        for u in self.units:
+            if u._sub is not None:
+                c0, c1 = u.dgrad_slice
+                w = u.holder.weight
+                with torch.no_grad():
+                    u._sub["w"].copy_(w[c0:c1] if u.cv.transposed else w[:, c0:c1])
+        L.check(lib.bp_conv_pack_jobs(L.ptr(self.jobs), L.ptr(self.first), self.njobs, self.total_blocks, st),
+                "batched pack")
+        for cv, d, w, packed in self.rest:
+            L.check(lib.bp_conv_pack(C.byref(cv), d, L.ptr(w), L.ptr(packed), st), "pack")
+        for u in self.units:
+            w = u.holder.weight
+            u._packed_version = (w._version, w.data_ptr(), getattr(plan.model, "_param_epoch", 0))
+
+
 class ResidualUnit:
     """activation(res_block(x) + x)  (utils.py:22-38)."""
 

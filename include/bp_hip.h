@@ -82,6 +82,18 @@ int bp_conv_kernel_id(const bp_conv* cv, int dir);
  * whenever the weights change (once per optimiser step). */
 int bp_conv_pack(const bp_conv* cv, int dir, const float* w_torch, float* packed, void* stream);
 
+/* Batched packing: every layer's weights in ONE launch (a step re-packs ~60 small images).  bp_conv_pack_job
+ * fills a host record of bp_conv_pack_job_bytes() bytes describing bp_conv_pack(cv, dir, w_torch, packed) and
+ * returns its workgroup count (BP_EUNSUPPORTED for the few layers served by the vector-ALU kernel: pack those
+ * with bp_conv_pack).  The caller uploads the records back to back, plus first_block[njobs + 1] = exclusive
+ * prefix sums of the workgroup counts, and launches them with bp_conv_pack_jobs; the pointers inside the records
+ * must stay valid (parameters are views of one flat buffer, packed images belong to the plan). */
+int32_t bp_conv_pack_job_bytes(void);
+int bp_conv_pack_job(const bp_conv* cv, int dir, const float* w_torch, float* packed, void* job,
+                     int64_t* nblocks);
+int bp_conv_pack_jobs(const void* jobs_dev, const int64_t* first_block_dev, int32_t njobs,
+                      int64_t total_blocks, void* stream);
+
 /* y_raw = conv(act(x)) [+ bias].  `x_pw` may be NULL (identity). */
 int bp_conv_forward(const bp_conv* cv, const bp_view* x, const bp_pointwise* x_pw,
                     const float* packed_fwd, const float* w_torch, const float* bias,

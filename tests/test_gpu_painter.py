@@ -268,3 +268,23 @@ def test_training_script_runs_end_to_end(tmp_path):
     assert len(runs) == 1
     files = {p.name for p in runs[0].iterdir()}
     assert {"model_state", "model_meta", "training_stats.txt", "validation_stats.txt"} <= files, files
+
+
+def test_bench_two_ranks_rehearsal():
+    """bench.py through torch.distributed.run with two ranks (gloo collectives, both ranks on this GPU): the
+    multi-rank code path of the bench line - sharded batch, global batch-norm statistics, gradient all-reduce,
+    the serial profiling pass on every rank - runs and reports the aggregate."""
+    import json
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, BP_DIST_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--batch", "2", "--tile", "64", "--no-paint"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 4 and out["value"] > 0
+    assert out["config"]["batch_norm"].startswith("global")
+    assert out["roofline"]["achieved"] > 0
