@@ -189,6 +189,32 @@ def test_forward_is_deterministic_and_shape_checked():
         m(torch.from_numpy(x), torch.from_numpy(y), torch.from_numpy(aux[:1]))
 
 
+def test_backward_is_bitwise_reproducible_with_overlapped_streams():
+    """Weight gradients run on a second stream and the q_y_in / prior branches on their own streams: repeating the
+    same step from the same state must give the same bits every time (a workspace or buffer shared across
+    streams would show up here), and the same bits as the single-stream schedule."""
+    arch = A.fiducial_architecture(128)
+    m, _ = _model(arch)
+    x, y, aux = [torch.from_numpy(t) for t in syn.synthetic_batch(4, 128, 128, seed=5)]
+    m._eps_override = syn.synthetic_eps((1, 4, *arch["dim_z"]), seed=6)
+    state = {k: v.clone() for k, v in m.state_dict().items()}
+
+    def grads():
+        m.load_state_dict(state)
+        m._bump_param_versions()
+        m.zero_grad()
+        (-m(x, y, aux)).backward()
+        return m._flat_grads.clone()
+
+    ref = grads()
+    assert m._last.side is not None and m._last.branch is not None, "the overlapped schedule is the default"
+    for _ in range(5):
+        assert torch.equal(grads(), ref)
+    m.overlap_weight_gradients(False)
+    assert torch.equal(grads(), ref)
+    m.overlap_weight_gradients(True)
+
+
 @pytest.mark.parametrize("n,L,train", [(1, 1, True), (5, 1, True), (2, 2, True), (3, 1, False)])
 def test_batch_sizes_L_and_eval_mode_against_oracle(n, L, train):
     """Shapes the fixtures do not cover (batch 1, odd batch, L = 2 samples per datum, eval-mode
