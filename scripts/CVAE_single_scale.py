@@ -10,6 +10,8 @@ overrides so the script can be exercised without the BAHAMAS stacks:
   BP_OUTPUT_PATH  run directory (default ../output/)
   BP_DEVICE       compute device (default cuda:0)
   BP_N_PEPOCH / BP_TILE  shorten the run / shrink the tiles for smoke tests
+  BP_DIST_BACKEND  collective backend under torch.distributed.run (default nccl = RCCL; gloo to rehearse the
+                  multi-rank path with all ranks on one GPU)
 Launch under ``python -m torch.distributed.run --nproc-per-node N`` for data-parallel training
 (RCCL all-reduce of one flat gradient buffer + batch-norm statistics).
 """
@@ -41,9 +43,15 @@ if __name__ == "__main__":
     if int(os.environ.get("WORLD_SIZE", "1")) > 1:
         import torch.distributed as dist
         local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        backend = os.environ.get("BP_DIST_BACKEND", "nccl")       # "gloo" only to rehearse on a one-GPU box
+        if backend != "nccl":
+            local_rank = 0
         compute_device = f"cuda:{local_rank}"
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device(compute_device))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(compute_device))
+        else:
+            dist.init_process_group(backend)
         from baryon_painter_amd.dist import Sync
         sync = Sync()
 

@@ -288,3 +288,20 @@ def test_bench_two_ranks_rehearsal():
     assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 4 and out["value"] > 0
     assert out["config"]["batch_norm"].startswith("global")
     assert out["roofline"]["achieved"] > 0
+
+
+def test_training_script_two_ranks_rehearsal(tmp_path):
+    """The training script under torch.distributed.run with two ranks (gloo collectives, both ranks on this GPU):
+    sharded loader, global batch-norm statistics, flat gradient all-reduce, rank-0-only output files."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, BP_TILE="64", BP_N_PEPOCH="1", BP_OUTPUT_PATH=str(tmp_path / "out"),
+               BP_DATA_PATH=str(tmp_path / "no_such_stacks"), BP_DIST_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), "CVAE_single_scale.py"]
+    r = subprocess.run(cmd, cwd=os.path.join(ROOT, "scripts"), env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    runs = list((tmp_path / "out").iterdir())
+    assert len(runs) == 1
+    files = {p.name for p in runs[0].iterdir()}
+    assert {"model_state", "model_meta", "training_stats.txt"} <= files, files
