@@ -351,7 +351,22 @@ class ConvUnit:
         self._packed_version = ver
 
     # ---- forward
+    def _drive(self, steps):
+        """Run a unit's step generator on its own: every statistic it yields is all-reduced right away."""
+        try:
+            while True:
+                sums = next(steps)               # (StopIteration ends the unit; single-device units never yield)
+                self.plan.sync.all_reduce_sum(sums)
+        except StopIteration as done:
+            return done.value
+
     def forward(self, training):
+        return self._drive(self.forward_steps(training))
+
+    def forward_steps(self, training):
+        """Generator: the forward pass, yielding once - the batch-norm sums that must become global - under data
+        parallelism.  A caller that drives several independent units in lock step (cvae._Plan, the recognition and
+        prior branches) answers all their yields with ONE collective over the buffer their ``sums`` are views of."""
         plan, lib, st = self.plan, self.plan.lib, _stream()
         self.maybe_pack()
         hold = self.holder
@@ -372,7 +387,7 @@ class ConvUnit:
                                         st), f"{self.name} bn stats")
             count = float(self.out.n * self.out.h * self.out.w)
             if plan.sync is not None and plan.sync.sync_bn:
-                plan.sync.all_reduce_sum(self.sums[:2 * c])
+                yield self.sums[:2 * c]
                 count *= plan.sync.world_size
             self.count = count
             L.check(lib.bp_bn_finalize(L.ptr(self.sums), count, c, L.ptr(bn.weight), L.ptr(bn.bias),
@@ -401,17 +416,24 @@ class ConvUnit:
     def backward(self, grads):
         """``out.grad`` (+``out.grad2``) hold d/d(activated out).  Writes parameter gradients into
         ``grads[id(param)]`` and d/d(activated in) into the view claimed from the input slot."""
+        return self._drive(self.backward_steps(grads))
+
+    def backward_steps(self, grads):
+        """Generator form of ``backward`` (see ``forward_steps``)."""
         out = self.out
         if self.has_pw or out.grad2 is not None:
             pw = None if self.out_pw is None else C.byref(self.out_pw.struct)
-            self.activation_backward(out.grad, out.grad2, pw, None, None if self.bn is not None else out.grad,
-                                     out.grad, grads)
+            yield from self.activation_backward_steps(out.grad, out.grad2, pw, None,
+                                                      None if self.bn is not None else out.grad, out.grad, grads)
         self.conv_backward(grads)
 
-    def activation_backward(self, dout, dout2, pw, act_out, g_out, d_raw_out, grads):
+    def activation_backward(self, *args):
+        return self._drive(self.activation_backward_steps(*args))
+
+    def activation_backward_steps(self, dout, dout2, pw, act_out, g_out, d_raw_out, grads):
         """g = (dout+dout2)*act'(t) -> g_out;  batch-norm backward of g -> d_raw_out.
         ``g_out`` None (batch-norm layers whose g nobody else reads): g is not stored, the apply pass
-        recomputes it from dout / the activation mask."""
+        recomputes it from dout / the activation mask.  Generator: yields the sums to make global (once)."""
         plan, lib, st = self.plan, self.plan.lib, _stream()
         c = self.cv.cout
         bn = self.bn
@@ -428,7 +450,7 @@ class ConvUnit:
         if bn is not None:
             pscale = 1.0
             if plan.sync is not None and plan.sync.sync_bn:
-                plan.sync.all_reduce_sum(self.sums[:2 * c])
+                yield self.sums[:2 * c]
                 pscale = 1.0 / plan.sync.world_size       # sums are global, losses are per-rank means
             L.check(lib.bp_bn_backward_finalize(L.ptr(self.sums), self.count, c, L.ptr(bn.weight),
                                                 L.ptr(self.save_mean), L.ptr(self.save_invstd), pscale,
