@@ -1,0 +1,506 @@
+// bf16 matrix-core convolutions (v_mfma_f32_16x16x32_bf16): BASELINE.json configs[3] -- bf16 activations and
+// gradients in HBM, fp32 accumulation, fp32 master weights.  At bf16 the step is HBM-bound (ridge
+// 310 FLOP/B vs an arithmetic intensity of ~200), so these kernels are built around bytes, not MFMA issue:
+//   * activations / gradients are read as 16-byte vectors (8 bf16 channels) and written as 16-byte vectors;
+//   * the pending batch-norm affine + (leaky) ReLU of the producer is applied in fp32 registers on the way into LDS,
+//     exactly like the fp32 kernels ("lazy activation"), and rounded to bf16 once;
+//   * either side of a layer may still be fp32 (the few-channel edges of the network stay fp32: a 1-channel tensor
+//     at 512^2 is 1/16 of the bytes of its 16-channel neighbour), so input and output element types are template
+//     parameters of one kernel, not separate code paths.
+//
+// Forward / data gradient: the stride-IS correlation over output phases of conv_igemm.hip (ConvGeom), with the GEMM
+// K dimension = 32 consecutive bf16 of the LDS halo image  [row][x % IS][x / IS][CC]:
+//     CC = 32  one tap, 32 channels of a channel chunk         (cin 32, 64, 128, ...)
+//     CC = 16  two x-adjacent taps of a 16-channel tensor;  CC = 8: four;  CC = 4: eight (the 3(+1)-channel stem)
+// i.e. a lane's 16-byte fragment is ALWAYS 8 consecutive bf16 of the image, whatever the channel count, and the
+// packed weights carry zeros for the taps of a run that do not exist.  D = W-tile x X-tile, so a lane ends up with
+// 4 channels of one pixel per N tile; the packing interleaves the channels of an N-tile pair so that those are 8
+// consecutive channels = one 16-byte bf16 store.
+//
+// Weight gradient: M = 16 coarse-grid (Y) channels, N = 16 fine-grid (X) channels, K = 32 pixels of a row; both
+// fragments are K-major while the tensors are channel-major, so both come out of LDS through the transposing read
+// ds_read_b64_tr_b16 (4 pixels x 16 channels per 16 lanes) -- no transposed copy of anything is ever stored.
+#include "common.hpp"
+#include <cstdlib>
+
+namespace {
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+typedef short s4 __attribute__((ext_vector_type(4)));
+typedef unsigned short u16;
+
+__device__ __forceinline__ float bf2f(u16 v) { return __builtin_bit_cast(float, (unsigned)v << 16); }
+__device__ __forceinline__ u16 f2bf(float f) { return __builtin_bit_cast(u16, (__bf16)f); }   // RNE, NaN stays NaN
+__device__ __forceinline__ unsigned pack2(float a, float b) { return (unsigned)f2bf(a) | ((unsigned)f2bf(b) << 16); }
+
+// ---------------------------------------------------------------------------------------------- forward / dgrad
+struct BArgs {
+  const void* in; int in_h, in_w, in_cs, in_co, cin;
+  void* out; int out_h, out_w, out_cs, out_co, cout;
+  const u16* wp; const float* bias;
+  PW pw;
+  int tapsy, ISy, ISx, OS, nphase, transposed, stride, pad;
+  int nrun;                 // K-steps per tap row and channel chunk
+  int run_off[16];          // LDS pixel offset of run s inside a tap row: xm * IWq + xq
+  int tiles_x, tiles_y, TPR, BH;
+  int nchunk, cout_padP;
+  int IH, IWq;
+};
+
+__device__ __forceinline__ void b_tile_of_block(int* tile, int* by) {
+  const int gx = gridDim.x, n = gx * gridDim.y;
+  const int L = blockIdx.y * gx + blockIdx.x;
+  const int q = n >> 3, r = n & 7;
+  const int xcd = L & 7, idx = L >> 3;
+  const int Lp = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  *tile = Lp % gx;
+  *by = Lp / gx;
+}
+
+// U channels of one pixel: global (fp32 or bf16) -> fp32 registers
+template <int U, bool IN_BF16>
+__device__ __forceinline__ void load_unit(const void* base, int64_t elem_off, float (&v)[U]) {
+  if constexpr (IN_BF16) {
+    const u16* p = reinterpret_cast<const u16*>(base) + elem_off;
+    if constexpr (U == 8) {
+      const uint4 t = *reinterpret_cast<const uint4*>(p);
+      const unsigned w[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { v[2 * j] = bf2f((u16)(w[j] & 0xffffu)); v[2 * j + 1] = bf2f((u16)(w[j] >> 16)); }
+    } else {
+      const uint2 t = *reinterpret_cast<const uint2*>(p);
+      v[0] = bf2f((u16)(t.x & 0xffffu)); v[1] = bf2f((u16)(t.x >> 16));
+      v[2] = bf2f((u16)(t.y & 0xffffu)); v[3] = bf2f((u16)(t.y >> 16));
+    }
+  } else {
+    const float* p = reinterpret_cast<const float*>(base) + elem_off;
+#pragma unroll
+    for (int j = 0; j < U; j += 4) {
+      const float4 t = *reinterpret_cast<const float4*>(p + j);
+      v[j] = t.x; v[j + 1] = t.y; v[j + 2] = t.z; v[j + 3] = t.w;
+    }
+  }
+}
+
+template <int U>
+__device__ __forceinline__ void lds_store_unit(u16* dst, const float (&v)[U]) {
+  if constexpr (U == 8) {
+    *reinterpret_cast<uint4*>(dst) = make_uint4(pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7]));
+  } else {
+    *reinterpret_cast<uint2*>(dst) = make_uint2(pack2(v[0], v[1]), pack2(v[2], v[3]));
+  }
+}
+
+// 8 consecutive bf16 of LDS as an MFMA fragment (16-byte aligned unless CC == 4: two 8-byte reads)
+template <int CC>
+__device__ __forceinline__ bf8 lds_frag(const u16* p) {
+  if constexpr (CC == 4) {
+    const uint2 a = *reinterpret_cast<const uint2*>(p);
+    const uint2 b = *reinterpret_cast<const uint2*>(p + 4);
+    return __builtin_bit_cast(bf8, make_uint4(a.x, a.y, b.x, b.y));
+  } else {
+    return __builtin_bit_cast(bf8, *reinterpret_cast<const uint4*>(p));
+  }
+}
+
+template <int CC, int NT, int WN, int MT, int SLOTS, bool IN_BF16, bool OUT_BF16>
+__global__ __launch_bounds__(256, 2) void igemm_bf16_kernel(BArgs a) {
+  constexpr int U = CC < 8 ? CC : 8;            // channels per staging unit
+  constexpr int UPP = CC / U;                   // units per pixel
+  constexpr int WM = 4 / WN;
+  constexpr int COB = 16 * NT * WN;
+  extern __shared__ __attribute__((aligned(16))) u16 smem[];
+  u16* lds_in = smem;
+  const int in_elems = a.IH * a.ISx * a.IWq * CC;
+  u16* lds_w = smem + ((in_elems + 7) & ~7);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int lm = lane & 15, kq = lane >> 4;
+
+  int tile, by;
+  b_tile_of_block(&tile, &by);
+  const int tile_x = tile % a.tiles_x, tile_y = tile / a.tiles_x;
+  const int co0 = blockIdx.z * COB;
+  const int ph = by % (a.nphase * a.nphase);
+  const int n = by / (a.nphase * a.nphase);
+  const int py = ph / a.nphase, px = ph % a.nphase;
+
+  const int BW = 16 * a.TPR;
+  const int qy0 = tile_y * a.BH, qx0 = tile_x * BW;
+  const int qh = (a.out_h - py + a.OS - 1) / a.OS;
+  const int qw = (a.out_w - px + a.OS - 1) / a.OS;
+  if (qy0 >= qh || qx0 >= qw) return;  // uniform per block
+
+  int iy0, ix0;
+  if (a.transposed) {
+    iy0 = bp_t_i0(py, a.pad, a.stride, a.tapsy);
+    ix0 = bp_t_i0(px, a.pad, a.stride, a.tapsy);
+  } else {
+    iy0 = -a.pad; ix0 = -a.pad;
+  }
+  const int gy0 = a.ISy * qy0 + iy0, gx0 = a.ISx * qx0 + ix0;
+
+  int abase[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int t = wm * MT + mt;
+    const int tr = t / a.TPR, tc = t % a.TPR;
+    abase[mt] = (tr * a.ISy * a.ISx * a.IWq + tc * 16 + lm) * CC + kq * 8;
+  }
+  int bbase[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) bbase[nt] = ((wn * NT + nt) * 16 + lm) * 32 + kq * 8;
+
+  v4f acc[MT][NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = v4f{0.f, 0.f, 0.f, 0.f};
+
+  const int64_t in_img = (int64_t)n * a.in_h * a.in_w * a.in_cs + a.in_co;
+  const int E = a.IH * a.ISx * a.IWq * UPP;     // staging units of the LDS image
+
+  // this thread's units: (row, column) are the same for every channel chunk
+  const int cu = tid % UPP;                     // 256 % UPP == 0: fixed channel group per thread
+  int s_g[SLOTS];                               // element offset inside the image, -1 outside / unused slot
+#pragma unroll
+  for (int i = 0; i < SLOTS; ++i) {
+    const int e = tid + i * 256;
+    s_g[i] = -2;
+    if (e < E) {
+      const int pi = e / UPP;
+      const int xq = pi % a.IWq;
+      const int t = pi / a.IWq;
+      const int xm = t % a.ISx, r = t / a.ISx;
+      const int iy = gy0 + r, ix = gx0 + xq * a.ISx + xm;
+      s_g[i] = (iy >= 0 && iy < a.in_h && ix >= 0 && ix < a.in_w) ? (iy * a.in_w + ix) * a.in_cs + cu * U : -1;
+    }
+  }
+
+  float stage[SLOTS][U];
+  auto load_chunk = [&](int chunk) {
+#pragma unroll
+    for (int i = 0; i < SLOTS; ++i)
+      if (s_g[i] >= 0) load_unit<U, IN_BF16>(a.in, in_img + s_g[i] + chunk * CC, stage[i]);
+  };
+  auto store_chunk = [&](int chunk) {
+    const int ch = chunk * CC + cu * U;
+    float sc[U], sf[U], sl[U];
+    const bool on = a.pw.scale != nullptr;
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+      const bool ok = on && ch + j < a.cin;
+      sc[j] = ok ? a.pw.scale[ch + j] : 1.f;
+      sf[j] = ok ? a.pw.shift[ch + j] : 0.f;
+      sl[j] = ok ? a.pw.slope[ch + j] : 1.f;
+    }
+#pragma unroll
+    for (int i = 0; i < SLOTS; ++i) {
+      if (s_g[i] == -2) continue;
+      float v[U];
+#pragma unroll
+      for (int j = 0; j < U; ++j) {
+        float t = 0.f;
+        if (s_g[i] >= 0 && ch + j < a.cin) {
+          t = stage[i][j];
+          if (on) { t = fmaf(t, sc[j], sf[j]); t = t > 0.f ? t : t * sl[j]; }
+        }
+        v[j] = t;
+      }
+      lds_store_unit<U>(lds_in + (tid + i * 256) * U, v);
+    }
+  };
+
+  load_chunk(0);
+  for (int chunk = 0; chunk < a.nchunk; ++chunk) {
+    __syncthreads();                 // the previous chunk's readers are done with lds_in / lds_w
+    store_chunk(chunk);
+    if (chunk + 1 < a.nchunk) load_chunk(chunk + 1);      // in flight while this chunk is computed
+    for (int ty = 0; ty < a.tapsy; ++ty) {
+      if (ty) __syncthreads();       // readers of the previous tap row's weights are done
+      {
+        // weights of (phase, ty, all runs, chunk): nrun slabs of COB x 32 bf16
+        constexpr int slab8 = COB * 32 / 8;                // 16-byte groups per slab
+        for (int e = tid; e < a.nrun * slab8; e += 256) {
+          const int s = e / slab8, o = e % slab8;
+          const u16* src = a.wp + ((((int64_t)(ph * a.tapsy + ty) * a.nrun + s) * a.nchunk + chunk) * a.cout_padP + co0) * 32;
+          *reinterpret_cast<uint4*>(lds_w + (size_t)s * COB * 32 + o * 8) = *reinterpret_cast<const uint4*>(src + o * 8);
+        }
+      }
+      __syncthreads();
+      for (int s = 0; s < a.nrun; ++s) {
+        const int tapoff = (ty * a.ISx * a.IWq + a.run_off[s]) * CC;
+        bf8 xf[MT], wf[NT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) xf[mt] = lds_frag<CC>(lds_in + abase[mt] + tapoff);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) wf[nt] = lds_frag<32>(lds_w + s * COB * 32 + bbase[nt]);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], xf[mt], acc[mt][nt], 0, 0, 0);
+      }
+    }
+  }
+
+  // ---- epilogue: D[row = 4*kq + r][col = lm] of N tile nt = produced channel row_to_channel(nt, 4*kq + r) of pixel lm.
+  // Channel order inside a COB block (set by the packing): tile pair (2t, 2t+1), rows 4*kq..4*kq+3 of the even
+  // tile then of the odd tile = channels 32*t + 8*kq .. + 7.
+  const int64_t out_img = (int64_t)n * a.out_h * a.out_w * a.out_cs + a.out_co;
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int t = wm * MT + mt;
+    const int tr = t / a.TPR, tc = t % a.TPR;
+    const int qy = qy0 + tr, qx = qx0 + tc * 16 + lm;
+    if (qy >= qh || qx >= qw) continue;
+    const int Y = py + a.OS * qy, X = px + a.OS * qx;
+    const int64_t o = out_img + ((int64_t)Y * a.out_w + X) * a.out_cs;
+    if constexpr (NT == 1) {
+      const int j0 = co0 + wn * 16 + kq * 4;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = acc[mt][0][r] + ((a.bias && j0 + r < a.cout) ? a.bias[j0 + r] : 0.f);
+      if constexpr (OUT_BF16) {
+        u16* q = reinterpret_cast<u16*>(a.out) + o + j0;
+        if (j0 + 3 < a.cout) *reinterpret_cast<uint2*>(q) = make_uint2(pack2(v[0], v[1]), pack2(v[2], v[3]));
+        else
+#pragma unroll
+          for (int r = 0; r < 4; ++r) if (j0 + r < a.cout) q[r] = f2bf(v[r]);
+      } else {
+        float* q = reinterpret_cast<float*>(a.out) + o + j0;
+        if (j0 + 3 < a.cout && (a.out_cs & 3) == 0 && (a.out_co & 3) == 0) *reinterpret_cast<float4*>(q) = make_float4(v[0], v[1], v[2], v[3]);
+        else
+#pragma unroll
+          for (int r = 0; r < 4; ++r) if (j0 + r < a.cout) q[r] = v[r];
+      }
+    } else {
+#pragma unroll
+      for (int np = 0; np < NT / 2; ++np) {
+        const int j0 = co0 + (wn * NT / 2 + np) * 32 + kq * 8;
+        float v[8];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { v[r] = acc[mt][2 * np][r]; v[4 + r] = acc[mt][2 * np + 1][r]; }
+        if (a.bias) {
+#pragma unroll
+          for (int r = 0; r < 8; ++r) if (j0 + r < a.cout) v[r] += a.bias[j0 + r];
+        }
+        if (j0 >= a.cout) continue;
+        if constexpr (OUT_BF16) {
+          u16* q = reinterpret_cast<u16*>(a.out) + o + j0;
+          if (j0 + 7 < a.cout) *reinterpret_cast<uint4*>(q) = make_uint4(pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7]));
+          else
+#pragma unroll
+            for (int r = 0; r < 8; ++r) if (j0 + r < a.cout) q[r] = f2bf(v[r]);
+        } else {
+          float* q = reinterpret_cast<float*>(a.out) + o + j0;
+          if (j0 + 7 < a.cout && (a.out_cs & 3) == 0 && (a.out_co & 3) == 0) {
+            *reinterpret_cast<float4*>(q) = make_float4(v[0], v[1], v[2], v[3]);
+            *reinterpret_cast<float4*>(q + 4) = make_float4(v[4], v[5], v[6], v[7]);
+          } else
+#pragma unroll
+            for (int r = 0; r < 8; ++r) if (j0 + r < a.cout) q[r] = v[r];
+        }
+      }
+    }
+  }
+}
+
+// produced channel <-> (N tile, MFMA row) inside a COB block; NT == 1 blocks keep the natural order
+__host__ __device__ __forceinline__ int b_channel_of(int NT, int jb /* index inside the COB block: tile*16 + row */) {
+  if (NT == 1) return jb;
+  const int tile = jb >> 4, row = jb & 15;
+  return 32 * (tile >> 1) + 8 * (row >> 2) + 4 * (tile & 1) + (row & 3);
+}
+
+struct BConfig {
+  int CC, R, NT, WN, MT, COB, nchunk, cout_padP, nrun, run_xm[16], run_xq[16];
+  int TPR, BH, IH, IWq, slots;
+  size_t lds_bytes;
+  bool ok;
+};
+
+BConfig b_config(const ConvGeom& g) {
+  BConfig c{};
+  const int cin = g.cin_g;
+  if (cin % 32 == 0) c.CC = 32;
+  else if (cin == 16) c.CC = 16;
+  else if (cin == 8) c.CC = 8;
+  else if (cin <= 4) c.CC = 4;
+  else return c;
+  c.R = 32 / c.CC;
+  c.nchunk = c.CC == 32 ? cin / 32 : 1;
+  const int nT = bp_ceil_div(g.cout_g, 16);
+  if (nT >= 5) { c.NT = 4; c.WN = 2; }
+  else if (nT >= 3) { c.NT = 4; c.WN = 1; }
+  else if (nT == 2) { c.NT = 2; c.WN = 1; }
+  else { c.NT = 1; c.WN = 1; }
+  c.MT = 4;
+  c.COB = 16 * c.NT * c.WN;
+  c.cout_padP = bp_round_up(g.cout_g, c.COB);
+  // K-steps of one tap row: per parity plane xm (x % IS), runs of R plane-adjacent taps
+  int rmax = 0;
+  for (int xm = 0; xm < g.IS && xm < g.taps; ++xm) {
+    const int tp = bp_ceil_div(g.taps - xm, g.IS);         // taps of this plane
+    const int nr = bp_ceil_div(tp, c.R);
+    for (int r = 0; r < nr; ++r) {
+      if (c.nrun >= 16) return c;
+      c.run_xm[c.nrun] = xm; c.run_xq[c.nrun] = r * c.R; ++c.nrun;
+    }
+    if (nr * c.R > rmax) rmax = nr * c.R;
+  }
+  const int TM = (4 / c.WN) * c.MT;                        // M tiles per workgroup
+  c.TPR = 2; c.BH = TM / 2;
+  c.IH = (c.BH - 1) * g.IS + g.taps;
+  c.IWq = 16 * c.TPR + rmax - 1;
+  const int U = c.CC < 8 ? c.CC : 8;
+  const int E = c.IH * g.IS * c.IWq * (c.CC / U);
+  c.slots = bp_ceil_div(E, 256);
+  const size_t in_b = (((size_t)c.IH * g.IS * c.IWq * c.CC + 7) & ~(size_t)7) * 2;
+  c.lds_bytes = in_b + (size_t)c.nrun * c.COB * 32 * 2;
+  c.ok = c.lds_bytes <= 64 * 1024 && c.slots <= 12;
+  return c;
+}
+
+// weights: torch layout (fp32) -> [phase][ty][run][chunk][cout_padP][32] bf16, k = j*CC + cc <-> tap xm + IS*(xq + j)
+struct BPackArgs {
+  const float* w; u16* dst;
+  int64_t sa, sb;
+  int k, stride, pad, tapsy, nphase, transposed, IS;
+  int cin_g, cout_g, CC, nchunk, cout_padP, COB, NT, nrun;
+  int run_xm[16], run_xq[16];
+  int64_t total;
+};
+
+__global__ __launch_bounds__(256) void pack_bf16_kernel(BPackArgs a) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= a.total) return;
+  int64_t r = i;
+  const int kk = r % 32; r /= 32;
+  const int jb_abs = r % a.cout_padP; r /= a.cout_padP;
+  const int chunk = r % a.nchunk; r /= a.nchunk;
+  const int s = r % a.nrun; r /= a.nrun;
+  const int ty = r % a.tapsy; r /= a.tapsy;
+  const int ph = (int)r;
+  const int py = ph / a.nphase, px = ph % a.nphase;
+  const int blk = jb_abs / a.COB, jb = jb_abs % a.COB;
+  const int co = blk * a.COB + b_channel_of(a.NT, jb);
+  const int j = kk / a.CC, cc = kk % a.CC;
+  const int tx = a.run_xm[s] + a.IS * (a.run_xq[s] + j);
+  const int ci = chunk * a.CC + cc;
+  int ky, kx;
+  if (a.transposed) {
+    ky = bp_t_ky(py, a.pad, a.stride, a.tapsy, ty);
+    kx = tx < a.tapsy ? bp_t_ky(px, a.pad, a.stride, a.tapsy, tx) : -1;
+  } else {
+    ky = ty; kx = tx < a.tapsy ? tx : -1;
+  }
+  float v = 0.f;
+  if (ci < a.cin_g && co < a.cout_g && ky < a.k && kx >= 0 && kx < a.k) v = a.w[ci * a.sa + co * a.sb + ky * a.k + kx];
+  a.dst[i] = f2bf(v);
+}
+
+template <int CC, int NT, int WN, int SLOTS, bool IB, bool OB>
+int b_launch(const BArgs& a, dim3 grid, size_t lds, hipStream_t st) {
+  hipLaunchKernelGGL((igemm_bf16_kernel<CC, NT, WN, 4, SLOTS, IB, OB>), grid, dim3(256), lds, st, a);
+  BP_CHECK_LAUNCH();
+  return BP_OK;
+}
+
+template <int CC, int NT, int WN, int SLOTS>
+int b_launch_io(const BArgs& a, bool ib, bool ob, dim3 grid, size_t lds, hipStream_t st) {
+  if (ib && ob) return b_launch<CC, NT, WN, SLOTS, true, true>(a, grid, lds, st);
+  if (ib) return b_launch<CC, NT, WN, SLOTS, true, false>(a, grid, lds, st);
+  if (ob) return b_launch<CC, NT, WN, SLOTS, false, true>(a, grid, lds, st);
+  return b_launch<CC, NT, WN, SLOTS, false, false>(a, grid, lds, st);
+}
+
+template <int CC, int NT, int WN>
+int b_launch_slots(const BConfig& c, const BArgs& a, bool ib, bool ob, dim3 grid, hipStream_t st) {
+  if (c.slots <= 3) return b_launch_io<CC, NT, WN, 3>(a, ib, ob, grid, c.lds_bytes, st);
+  if (c.slots <= 6) return b_launch_io<CC, NT, WN, 6>(a, ib, ob, grid, c.lds_bytes, st);
+  return b_launch_io<CC, NT, WN, 12>(a, ib, ob, grid, c.lds_bytes, st);
+}
+
+template <int CC>
+int b_launch_cc(const BConfig& c, const BArgs& a, bool ib, bool ob, dim3 grid, hipStream_t st) {
+  if (c.NT == 4 && c.WN == 2) return b_launch_slots<CC, 4, 2>(c, a, ib, ob, grid, st);
+  if (c.NT == 4 && c.WN == 1) return b_launch_slots<CC, 4, 1>(c, a, ib, ob, grid, st);
+  if (c.NT == 2) return b_launch_slots<CC, 2, 1>(c, a, ib, ob, grid, st);
+  return b_launch_slots<CC, 1, 1>(c, a, ib, ob, grid, st);
+}
+
+}  // namespace
+
+// ---- entry points used by capi.hip
+bool bp_bf16_igemm_ok(const ConvGeom& g, const bp_view* in, const bp_view* out) {
+  const BConfig c = b_config(g);
+  if (!c.ok) return false;
+  if (in) {
+    const int U = c.CC < 8 ? c.CC : 8;
+    const int esz = in->dtype == BP_BF16 ? 2 : 4;
+    const int bytes = U * esz < 16 ? U * esz : 16;        // widest single load of a unit
+    if ((in->cstride * esz) % bytes || (in->coff * esz) % bytes || reinterpret_cast<uintptr_t>(in->ptr) % 16) return false;
+    if (in->c != g.cin_g && !(c.CC == 4 && in->coff + 4 <= in->cstride)) return false;
+  }
+  if (out && out->dtype == BP_BF16) {
+    const int need = c.NT == 1 ? 4 : 8;
+    if (out->cstride % need || out->coff % need || reinterpret_cast<uintptr_t>(out->ptr) % 16) return false;
+  }
+  return true;
+}
+
+int64_t bp_bf16_packed_elems(const ConvGeom& g) {
+  const BConfig c = b_config(g);
+  if (!c.ok) return -1;
+  return (int64_t)g.nphase * g.nphase * g.taps * c.nrun * c.nchunk * c.cout_padP * 32;
+}
+
+int bp_bf16_pack(const ConvGeom& g, const WeightMap& wm, const float* w_torch, void* packed, hipStream_t st) {
+  const BConfig c = b_config(g);
+  if (!c.ok) return BP_EUNSUPPORTED;
+  BPackArgs a{};
+  a.w = w_torch; a.dst = reinterpret_cast<u16*>(packed); a.sa = wm.sa; a.sb = wm.sb;
+  a.k = g.k; a.stride = g.stride; a.pad = g.pad; a.tapsy = g.taps; a.nphase = g.nphase;
+  a.transposed = g.gather_transposed; a.IS = g.IS; a.cin_g = g.cin_g; a.cout_g = g.cout_g;
+  a.CC = c.CC; a.nchunk = c.nchunk; a.cout_padP = c.cout_padP; a.COB = c.COB; a.NT = c.NT; a.nrun = c.nrun;
+  for (int s = 0; s < c.nrun; ++s) { a.run_xm[s] = c.run_xm[s]; a.run_xq[s] = c.run_xq[s]; }
+  a.total = bp_bf16_packed_elems(g);
+  hipLaunchKernelGGL(pack_bf16_kernel, dim3((unsigned)((a.total + 255) / 256)), dim3(256), 0, st, a);
+  BP_CHECK_LAUNCH();
+  return BP_OK;
+}
+
+int bp_bf16_igemm_run(const ConvGeom& g, const bp_view* in, const PW& pw, const void* packed, const float* bias,
+                      const bp_view* out, hipStream_t st) {
+  const BConfig c = b_config(g);
+  if (!c.ok || !bp_bf16_igemm_ok(g, in, out)) return BP_EUNSUPPORTED;
+  BArgs a{};
+  a.in = in->ptr; a.in_h = in->h; a.in_w = in->w; a.in_cs = in->cstride; a.in_co = in->coff; a.cin = g.cin_g;
+  a.out = out->ptr; a.out_h = out->h; a.out_w = out->w; a.out_cs = out->cstride; a.out_co = out->coff;
+  a.cout = g.cout_g; a.wp = reinterpret_cast<const u16*>(packed); a.bias = bias; a.pw = pw;
+  a.tapsy = g.taps; a.ISy = g.IS; a.ISx = g.IS; a.OS = g.OS; a.nphase = g.nphase;
+  a.transposed = g.gather_transposed; a.stride = g.stride; a.pad = g.pad;
+  a.nrun = c.nrun;
+  for (int s = 0; s < c.nrun; ++s) a.run_off[s] = c.run_xm[s] * c.IWq + c.run_xq[s];
+  a.TPR = c.TPR; a.BH = c.BH; a.IH = c.IH; a.IWq = c.IWq;
+  a.nchunk = c.nchunk; a.cout_padP = c.cout_padP;
+  const int qh = bp_ceil_div(out->h, g.OS), qw = bp_ceil_div(out->w, g.OS);
+  a.tiles_x = bp_ceil_div(qw, 16 * c.TPR);
+  a.tiles_y = bp_ceil_div(qh, c.BH);
+  const int64_t gz = (int64_t)in->n * g.nphase * g.nphase;
+  if (gz > 65535 || c.cout_padP / c.COB > 65535) return BP_EUNSUPPORTED;
+  dim3 grid((unsigned)(a.tiles_x * a.tiles_y), (unsigned)gz, (unsigned)(c.cout_padP / c.COB));
+  const bool ib = in->dtype == BP_BF16, ob = out->dtype == BP_BF16;
+  switch (c.CC) {
+    case 32: return b_launch_cc<32>(c, a, ib, ob, grid, st);
+    case 16: return b_launch_cc<16>(c, a, ib, ob, grid, st);
+    case 8: return b_launch_cc<8>(c, a, ib, ob, grid, st);
+    case 4: return b_launch_cc<4>(c, a, ib, ob, grid, st);
+  }
+  return BP_EUNSUPPORTED;
+}

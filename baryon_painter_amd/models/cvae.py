@@ -681,31 +681,39 @@ class CVAE(torch.nn.Module):
             return mu
 
     # ---- hipGraph-captured eval forward (BASELINE.json configs[4]: stream tiles through P)
-    def sample_P_graphed(self, y, aux_label=None):
+    def sample_P_graphed(self, y, aux_label=None, z=None):
         """``sample_P`` (prior-sampled z, mean head) replayed from a captured hipGraph: one graph
         launch instead of ~110 kernel launches per batch.  Eval mode only; the graph is captured per
-        batch size on first use and re-used while the parameters' storage is unchanged."""
+        batch size on first use and re-used while the parameters' storage is unchanged.  ``z`` (N, *dim_z), if
+        given, replaces the prior sample as in ``sample_P(..., z=z)`` (cvae.py:149-154): a second captured graph
+        without the prior network and the sampler."""
         if self.training:
             raise RuntimeError("sample_P_graphed is an eval-mode (paint) path: call model.train(False) first")
         y = torch.as_tensor(y, device=self.device, dtype=torch.float32)
         self._check_inputs(None, y)
         n = y.shape[0]
         aux = self._aux(aux_label, n)
-        g = self._graphs.get(n)
+        key = n if z is None else (n, "z")
+        g = self._graphs.get(key)
         if g is None:
-            g = self._capture_paint_graph(n)
-            self._graphs[n] = g
+            g = self._capture_paint_graph(n, given_z=z is not None)
+            self._graphs[key] = g
         for u in g["units"]:
             u.maybe_pack()                       # eager, a no-op unless the weights changed
         g["y"].copy_(y)
         if aux is not None:
             g["aux"].copy_(aux)
-        if self._eps_override is not None:
+        if z is not None:
+            zt = torch.as_tensor(z, device=self.device, dtype=torch.float32)
+            if tuple(zt.shape) != (n, *self.dim_z):
+                raise ValueError(f"z has shape {tuple(zt.shape)}, expected {(n, *self.dim_z)}")
+            g["z"].copy_(zt)
+        elif self._eps_override is not None:
             raise RuntimeError("eps override is not supported on the graphed path (noise is drawn in-graph)")
         g["graph"].replay()
         return g["out"].clone()
 
-    def _capture_paint_graph(self, n):
+    def _capture_paint_graph(self, n, given_z=False):
         """Eval-mode layers do not couple the tiles of a batch (batch-norm runs on its running statistics), so the
         batch is painted as BP_PAINT_STREAMS (default 4) sub-batches on as many streams inside one graph: kernels of different layers share
         the CUs and fill each other's stalls (the effect the training step gets from its weight-gradient
@@ -714,7 +722,8 @@ class CVAE(torch.nn.Module):
         cx = self.dim_x[0]
         st = {"y": torch.zeros((n, cy, H, W), device=self.device),
               "aux": torch.zeros((n, self.n_aux), device=self.device) if self.use_aux_label else None,
-              "out": torch.zeros((n, cx, H, W), device=self.device)}
+              "out": torch.zeros((n, cx, H, W), device=self.device),
+              "z": torch.zeros((n, *self.dim_z), device=self.device) if given_z else None}
         parts = int(os.environ.get("BP_PAINT_STREAMS", "4"))
         while parts > 1 and (n % parts != 0 or n // parts < 8):
             parts -= 1
@@ -731,8 +740,12 @@ class CVAE(torch.nn.Module):
 
         def paint(plan, lo):
             plan.load_inputs(st["y"][lo:lo + h], None if st["aux"] is None else st["aux"][lo:lo + h])
-            plan.run_prior(False)
-            plan.run_latent(torch.randn(size=(self.L, h, *self.dim_z), device=self.device), use_q=False)
+            if given_z:
+                L.check(self._lib.bp_nchw_to_view(L.ptr(st["z"][lo:lo + h]), self.dim_z[0], None, 0,
+                                                  C.byref(plan.z.view), _stream()), "z layout")
+            else:
+                plan.run_prior(False)
+                plan.run_latent(torch.randn(size=(self.L, h, *self.dim_z), device=self.device), use_q=False)
             plan.run_generator(False)
             self._head_to_nchw(plan.mu_head, plan.mu_softplus, st["out"][lo:lo + h])
 

@@ -14,7 +14,9 @@ import torch
 import torch.nn.functional as F
 
 
-def _seq(architecture, x, P, prefix, training):
+def _seq(architecture, x, P, prefix, training, tap=None):
+    """``tap`` (debug aid, tools/chain_bisect.py): dict that receives every convolution's raw output under the
+    layer's state_dict prefix, with ``retain_grad()`` so that d(loss)/d(raw) can be read after backward."""
     for i, layer in enumerate(architecture or []):
         name = layer[0].lower()
         cfg = layer[1] if len(layer) == 2 else None
@@ -22,9 +24,17 @@ def _seq(architecture, x, P, prefix, training):
         if name == "conv":
             x = F.conv2d(x, P[p + "weight"], P.get(p + "bias"), stride=cfg.get("stride", 1),
                          padding=cfg.get("padding", 0))
+            if tap is not None:
+                tap[p] = x
+                if x.requires_grad:
+                    x.retain_grad()
         elif name == "transp conv":
             x = F.conv_transpose2d(x, P[p + "weight"], P.get(p + "bias"), stride=cfg.get("stride", 1),
                                    padding=cfg.get("padding", 0), output_padding=cfg.get("output_padding", 0))
+            if tap is not None:
+                tap[p] = x
+                if x.requires_grad:
+                    x.retain_grad()
         elif name == "batchnorm":
             x = F.batch_norm(x, P[p + "running_mean"], P[p + "running_var"], P[p + "weight"], P[p + "bias"],
                              training=training, momentum=0.1, eps=1e-5)
@@ -47,7 +57,7 @@ def _seq(architecture, x, P, prefix, training):
         elif name == "flatten":
             x = x.view(x.size(0), -1)
         elif name == "residual block":
-            h = _seq(cfg[0], x, P, p + "res_block.", training) + x
+            h = _seq(cfg[0], x, P, p + "res_block.", training, tap) + x
             tail = cfg[1][0]
             if tail is None:
                 x = h
@@ -63,12 +73,14 @@ def _seq(architecture, x, P, prefix, training):
 
 
 class TorchRefCVAE:
-    def __init__(self, architecture, params, buffers=None):
-        """params: name -> array/tensor (learnables).  Buffers default to torch's initial values."""
+    def __init__(self, architecture, params, buffers=None, dtype=torch.float32, tap=None):
+        """params: name -> array/tensor (learnables).  Buffers default to torch's initial values.
+        ``dtype`` float64 gives the "true value" of every tensor; ``tap``: see ``_seq``."""
         self.a = architecture
+        self.dtype, self.tap = dtype, tap
         self.P = {}
         for k, v in params.items():
-            t = torch.as_tensor(v, dtype=torch.float32).clone()
+            t = torch.as_tensor(v, dtype=dtype).clone()
             t.requires_grad_(True)
             self.P[k] = t
         self._init_buffers(buffers or {})
@@ -88,9 +100,9 @@ class TorchRefCVAE:
                 if name == "batchnorm":
                     c = layer[1]["num_features"]
                     self.P[p + "running_mean"] = torch.as_tensor(given.get(p + "running_mean", torch.zeros(c)),
-                                                                 dtype=torch.float32).clone()
+                                                                 dtype=self.dtype).clone()
                     self.P[p + "running_var"] = torch.as_tensor(given.get(p + "running_var", torch.ones(c)),
-                                                                dtype=torch.float32).clone()
+                                                                dtype=self.dtype).clone()
                     self.P[p + "num_batches_tracked"] = torch.zeros((), dtype=torch.int64)
                 elif name == "residual block":
                     walk(layer[1][0], p + "res_block.")
@@ -114,16 +126,17 @@ class TorchRefCVAE:
 
     def forward(self, x, y, aux, eps):
         a, P, tr = self.a, self.P, self.training
-        x, y = torch.as_tensor(x, dtype=torch.float32), torch.as_tensor(y, dtype=torch.float32)
-        aux, eps = torch.as_tensor(aux, dtype=torch.float32), torch.as_tensor(eps, dtype=torch.float32)
+        dt, tap = self.dtype, self.tap
+        x, y = torch.as_tensor(x, dtype=dt), torch.as_tensor(y, dtype=dt)
+        aux, eps = torch.as_tensor(aux, dtype=dt), torch.as_tensor(eps, dtype=dt)
         y2 = self._merge(y, aux) if a["aux_label"] else y
-        h = torch.cat([_seq(a["q_x_in"], x, P, "q_x_in.", tr), _seq(a["q_y_in"], y2, P, "q_y_in.", tr)], 1)
-        h = _seq(a["q_x_y_out"], h, P, "q_out.", tr)
+        h = torch.cat([_seq(a["q_x_in"], x, P, "q_x_in.", tr, tap), _seq(a["q_y_in"], y2, P, "q_y_in.", tr, tap)], 1)
+        h = _seq(a["q_x_y_out"], h, P, "q_out.", tr, tap)
         self.z_mu, self.z_log_var = h[:, 0], h[:, 1]
         z = (self.z_mu + eps * (torch.exp(self.z_log_var / 2) + self.min_z_var)).view(-1, *self.dim_z)
         M = x.size(0)
         if "prior_z_y" in a:
-            hp = _seq(a["prior_z_y"], y2, P, "prior_network.", tr)
+            hp = _seq(a["prior_z_y"], y2, P, "prior_network.", tr, tap)
             p_mu, p_lv = hp[:, 0], hp[:, 1]
         else:
             p_mu = torch.zeros_like(self.z_mu)
@@ -147,26 +160,26 @@ class TorchRefCVAE:
         return self.ELBO
 
     def _P(self, z, y2):
-        a, P, tr = self.a, self.P, self.training
-        h_y = _seq(a["p_y_in"], y2, P, "p_y_in.", tr)
-        h_z = _seq(a["p_z_in"], z, P, "p_z_in.", tr)
-        h = _seq(a["p_y_z_in"], torch.cat([h_z, h_y.repeat(self.L, 1, 1, 1)], 1), P, "p_y_z_in.", tr)
-        x_mu = _seq(a["p_y_z_out"][0], h, P, "p_mu_out.", tr)
-        x_lv = _seq(a["p_y_z_out"][1], h, P, "p_var_out.", tr) if self.predict_var else None
+        a, P, tr, tap = self.a, self.P, self.training, self.tap
+        h_y = _seq(a["p_y_in"], y2, P, "p_y_in.", tr, tap)
+        h_z = _seq(a["p_z_in"], z, P, "p_z_in.", tr, tap)
+        h = _seq(a["p_y_z_in"], torch.cat([h_z, h_y.repeat(self.L, 1, 1, 1)], 1), P, "p_y_z_in.", tr, tap)
+        x_mu = _seq(a["p_y_z_out"][0], h, P, "p_mu_out.", tr, tap)
+        x_lv = _seq(a["p_y_z_out"][1], h, P, "p_var_out.", tr, tap) if self.predict_var else None
         return x_mu, x_lv
 
     def sample_P(self, y, aux, eps=None, z=None):
         a, P = self.a, self.P
         with torch.no_grad():
-            y = torch.as_tensor(y, dtype=torch.float32)
-            aux = torch.as_tensor(aux, dtype=torch.float32)
+            y = torch.as_tensor(y, dtype=self.dtype)
+            aux = torch.as_tensor(aux, dtype=self.dtype)
             y2 = self._merge(y, aux) if a["aux_label"] else y
             if z is None:
                 hp = _seq(a["prior_z_y"], y2, P, "prior_network.", self.training)
-                eps = torch.as_tensor(eps, dtype=torch.float32)
+                eps = torch.as_tensor(eps, dtype=self.dtype)
                 z = (hp[:, 0] + eps * (torch.exp(hp[:, 1] / 2) + self.min_z_var)).view(-1, *self.dim_z)
             else:
-                z = torch.as_tensor(z, dtype=torch.float32)
+                z = torch.as_tensor(z, dtype=self.dtype)
             return self._P(z, y2)[0]
 
     def get_stats(self):

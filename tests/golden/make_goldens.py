@@ -29,7 +29,7 @@ from baryon_painter.models import cvae as ref_cvae          # noqa: E402  (the r
 from baryon_painter.models import utils as ref_utils        # noqa: E402
 from baryon_painter_amd.models import arch as our_arch      # noqa: E402
 from baryon_painter_amd.utils import synthetic as syn       # noqa: E402
-from golden_util import summarize                           # noqa: E402
+from golden_util import distance, summarize, store_crops              # noqa: E402
 
 torch.manual_seed(0)
 torch.set_num_threads(8)
@@ -146,7 +146,37 @@ def op_goldens():
 
 
 # --------------------------------------------------------------- full-model cases
-def model_golden(tag, arch, n, size, out, seed_w=7, seed_d=1234, seed_eps=99, adam=False, alpha_var=None):
+# Equally valid executions of the SAME reference code on a CPU: thread count and the oneDNN switch change the
+# blocking / summation order inside ATen's convolutions and reductions, nothing else.  The spread of their results
+# around the float64 truth is the reference's own fp32 noise floor for each gradient.
+REF_VARIANTS = [("t1", 1, True), ("t3", 3, True), ("t8nomkl", 8, False), ("t1nomkl", 1, False)]
+
+
+def reference_variants(tag, arch, n, size, out, seed_w=7, seed_d=1234, seed_eps=99):
+    x, y, aux = syn.synthetic_batch(n, size, size, seed=seed_d)
+    eps = syn.synthetic_eps((arch.get("L", 1), n, *arch["dim_z"]), seed=seed_eps)
+    dist = []
+    for name, threads, mkldnn in REF_VARIANTS:
+        torch.set_num_threads(threads)
+        with torch.backends.mkldnn.flags(enabled=mkldnn):
+            model = ref_cvae.CVAE(arch, "cpu")
+            load_params(model, seed_w)
+            model.train(True)
+            with inject_eps(eps):
+                elbo = model(torch.from_numpy(x), torch.from_numpy(y), torch.from_numpy(aux))
+            (-elbo).backward()
+        names = [k for k, _ in model.named_parameters()]
+        dist.append([distance(f"{tag}/grad64/{k}", p.grad.numpy(), out) for k, p in model.named_parameters()])
+        print(tag, name, "ELBO", float(elbo))
+    torch.set_num_threads(8)
+    # distance of each execution's gradient from the float64 truth (tests/golden_util.distance), [variant][parameter]
+    out[f"{tag}/grad_variants"] = np.array(",".join(v[0] for v in REF_VARIANTS))
+    out[f"{tag}/grad_variant_params"] = np.array(",".join(names))
+    out[f"{tag}/grad_variant_dist"] = np.array(dist)
+
+
+def model_golden(tag, arch, n, size, out, seed_w=7, seed_d=1234, seed_eps=99, adam=False, alpha_var=None,
+                 crops=False):
     model = ref_cvae.CVAE(arch, "cpu")
     load_params(model, seed_w)
     if alpha_var is not None:
@@ -163,6 +193,8 @@ def model_golden(tag, arch, n, size, out, seed_w=7, seed_d=1234, seed_eps=99, ad
     (-elbo).backward()
     summarize(f"{tag}/stats", np.array(model.get_stats(), np.float64), out)
     summarize(f"{tag}/x_mu", model.x_mu.detach().numpy(), out)
+    if crops:
+        store_crops(f"{tag}/x_mu", model.x_mu.detach().numpy(), out)
     summarize(f"{tag}/z_mu", model.z_mu.detach().numpy(), out)
     summarize(f"{tag}/z_log_var", model.z_log_var.detach().numpy(), out)
     for k, p in model.named_parameters():
@@ -176,9 +208,13 @@ def model_golden(tag, arch, n, size, out, seed_w=7, seed_d=1234, seed_eps=99, ad
     with inject_eps(eps1):
         s = model.sample_P(yt, aux_label=at)
     summarize(f"{tag}/sample_P_eval", s.numpy(), out)
+    if crops:
+        store_crops(f"{tag}/sample_P_eval", s.numpy(), out)
     zfix = syn.synthetic_eps((n, *arch["dim_z"]), seed=seed_eps + 2)
     s = model.sample_P(yt, aux_label=at, z=zfix)
     summarize(f"{tag}/sample_P_eval_zfix", s.numpy(), out)
+    if crops:
+        store_crops(f"{tag}/sample_P_eval_zfix", s.numpy(), out)
     if len(arch["p_y_z_out"]) > 1:
         mu, var = model.sample_P(yt, aux_label=at, z=zfix, return_var=True)
         summarize(f"{tag}/sample_P_eval_var", var.numpy(), out)
@@ -226,9 +262,16 @@ def main():
     two = our_arch.fiducial_architecture(64, predict_var=True)
     # the checked-in script's two-head network (scripts/CVAE_single_scale.py:97-138)
     model_golden("twohead64_n2", two, 2, 64, out, alpha_var=0.3)
-    model_golden("fid512_n2", fid, 2, 512, out)
+    model_golden("fid512_n2", fid, 2, 512, out, crops=True)
     truth64("fid512_n2", fid, 2, 512, out)
     truth64("fid128_n2", a128, 2, 128, out)
+    reference_variants("fid512_n2", fid, 2, 512, out)
+    reference_variants("fid128_n2", a128, 2, 128, out)
+    # BASELINE.json configs[0] geometry: batch 4 of 256x256 tiles (dim_z 1x8x8)
+    a256 = syn.scaled_architecture(fid, 256)
+    model_golden("fid256_n4", a256, 4, 256, out, crops=True)
+    truth64("fid256_n4", a256, 4, 256, out)
+    reference_variants("fid256_n4", a256, 4, 256, out)
     np.savez_compressed(os.path.join(HERE, "model.npz"), **out)
     for f in ("ops.npz", "model.npz"):
         print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, "KiB")

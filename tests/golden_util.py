@@ -26,6 +26,31 @@ def summarize(prefix, arr, out):
         out[prefix + "/samples"] = flat[sample_indices(flat.size)].astype(np.float32)
 
 
+# Contiguous full-resolution crops of a large (N,C,H,W) tensor: two opposite corners (padding handling on all four
+# borders) of every sample, stored whole, so that a TRUE relative L2 distance ||a-b|| / ||b|| can be computed.
+CROP = 96
+
+
+def crop_views(arr):
+    a = np.asarray(arr)
+    return {"tl": a[..., :CROP, :CROP], "br": a[..., -CROP:, -CROP:]}
+
+
+def store_crops(prefix, arr, out):
+    for name, v in crop_views(arr).items():
+        out[f"{prefix}/crop_{name}"] = np.ascontiguousarray(v, dtype=np.float32)
+
+
+def crop_rel_l2(prefix, arr, gold):
+    """||ours - ref||_2 / ||ref||_2 over the stored crops."""
+    num = den = 0.0
+    for name, v in crop_views(arr).items():
+        g = gold[f"{prefix}/crop_{name}"].astype(np.float64)
+        num += ((np.asarray(v, np.float64) - g) ** 2).sum()
+        den += (g ** 2).sum()
+    return float(np.sqrt(num / max(den, 1e-300)))
+
+
 def check(prefix, arr, gold, rtol, atol_frac=1e-6, what=""):
     """Assert ``arr`` matches the stored summary.  ``rtol`` is relative to the
     tensor's overall scale (l2/sqrt(n) or max|.|), which is the meaningful

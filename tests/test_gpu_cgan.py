@@ -10,12 +10,15 @@ from baryon_painter_amd.utils import synthetic as syn
 pytestmark = pytest.mark.gpu
 
 
-def test_cgan_iteration_matches_torch_restatement():
+@pytest.mark.parametrize("size,n_res,n,gtol", [(64, 2, 2, 2e-3), (512, 9, 2, 5e-3)])
+def test_cgan_iteration_matches_torch_restatement(size, n_res, n, gtol):
+    """(64, 2 blocks): quick case.  (512, 9 blocks): the fiducial CGAN of BASELINE.json configs[2] at its real
+    geometry -- the k9 stem / head at 512^2, nine residual blocks at 128^2, the 256- and 512-channel PatchGAN
+    layers -- one alternating D + G iteration, every loss and gradient."""
     from baryon_painter_amd.models.cgan import CGAN
     from oracle.cgan_torch import TorchCGAN
     torch.manual_seed(0)
-    size, n = 64, 2
-    m = CGAN(tile_size=size, device="cuda:0", n_res=2)
+    m = CGAN(tile_size=size, device="cuda:0", n_res=n_res)
     m.train(True)
     ref = TorchCGAN(m.g_arch, m.d_arch, {k: v for k, v in m.state_dict().items()}, m.lambda_perceptual)
     x, y, z = syn.synthetic_batch(n, size, size, seed=5)
@@ -37,7 +40,7 @@ def test_cgan_iteration_matches_torch_restatement():
             errs.append((float((g.cpu().double() - w).abs().max() / max(float(w.abs().max()), floor)), net + k))
     errs.sort(reverse=True)
     print("worst CGAN gradient errors vs torch restatement:", errs[:4])
-    assert errs[0][0] < 2e-3, errs[:6]
+    assert errs[0][0] < gtol, errs[:6]
     # spectral-norm power-iteration state after the two discriminator forwards
     after = m.state_dict()
     for k, t in ref.P.items():

@@ -12,7 +12,7 @@ import torch
 
 from baryon_painter_amd.models import arch as A
 from baryon_painter_amd.utils import synthetic as syn
-from golden_util import check, distance, summary_distance
+from golden_util import check, crop_rel_l2, distance, summary_distance
 from oracle.cvae_oracle import CVAEOracle
 
 import gpu_util as G
@@ -20,30 +20,34 @@ import gpu_util as G
 pytestmark = pytest.mark.gpu
 
 CASES = [("fid64_n3", 64, 3, False, None), ("fid128_n2", 128, 2, False, None),
-         ("twohead64_n2", 64, 2, True, 0.3)]
+         ("twohead64_n2", 64, 2, True, 0.3), ("fid256_n4", 256, 4, False, None)]
 
 
-# Batch-norm parameters whose gradient is a catastrophically cancelling sum over all pixels of the
-# generator input's data-gradient (cancellation ~3000:1 at 512^2, measured with tools/bias_probe.py):
-# every fp32 implementation sits at its noise floor there; see DESIGN.md "Numerical parity".
-CANCELLATION_DOMINATED = ("p_z_in.7.weight", "p_z_in.7.bias")
+def reference_noise_floor(tag, k, gold):
+    """How far the REFERENCE's own fp32 gradient lies from the float64 truth: the largest distance over the
+    executions of the reference stored in the fixtures -- the golden run (8 threads, oneDNN) and the variants of
+    tests/golden/make_goldens.py REF_VARIANTS (1 / 3 threads, oneDNN off), which change nothing but the summation
+    order inside ATen.  Many of these gradients are sums with 1000:1 cancellation behind ReLU / PReLU masks that
+    flip with the last bit of the forward pass; the reference's result moves by factors of 3-10 between such
+    executions (measured: p_z_in.7.bias at 512^2 is 1.2e-3 ... 3.0e-3 from the truth in the build container and
+    8e-3 on the GPU box's host; DESIGN.md "Numerical parity").  No per-tensor exemptions."""
+    errs = [summary_distance(f"{tag}/grad/{k}", f"{tag}/grad64/{k}", gold)]
+    if f"{tag}/grad_variant_dist" in gold:
+        names = str(gold[f"{tag}/grad_variant_params"]).split(",")
+        errs += list(gold[f"{tag}/grad_variant_dist"][:, names.index(k)])
+    return float(max(errs))
 
 
-def _check_grad(tag, k, grad, gold, slack=1.0):
-    """Gradient criterion.  Where the fixtures hold the float64 true value (grad64), the HIP
-    gradient may be at most 4x as far from it as the fp32 reference itself is (floor 5e-4):
-    the recognition-net / p_z_in gradients are ill-conditioned (batch-norm cancellation of the
-    tiny latent terms) and the reference's own fp32 result is ~3e-3 off there.  Otherwise 5e-3
+def _check_grad(tag, k, grad, gold):
+    """Gradient criterion.  Where the fixtures hold the float64 true value (grad64), the HIP gradient may be at most
+    4x as far from it as the fp32 reference itself gets (``reference_noise_floor``; floor 5e-4).  Otherwise 5e-3
     against the fp32 reference."""
     if f"{tag}/grad64/{k}/shape" in gold:
-        ref_err = summary_distance(f"{tag}/grad/{k}", f"{tag}/grad64/{k}", gold)
+        ref_err = reference_noise_floor(tag, k, gold)
         ours = distance(f"{tag}/grad64/{k}", grad, gold)
-        limit = max(4 * ref_err, 5e-4) * slack
-        if k in CANCELLATION_DOMINATED:
-            limit = max(limit, 5e-2)
-        assert ours <= limit, f"grad {k}: {ours:.2e} from truth, reference {ref_err:.2e}"
+        assert ours <= max(4 * ref_err, 5e-4), f"grad {k}: {ours:.2e} from truth, reference {ref_err:.2e}"
     else:
-        check(f"{tag}/grad/{k}", grad, gold, 5e-3 * slack, what="grad ")
+        check(f"{tag}/grad/{k}", grad, gold, 5e-3, what="grad ")
 
 
 def _model(arch, impl="auto"):
@@ -60,6 +64,8 @@ def _model(arch, impl="auto"):
 @pytest.mark.parametrize("impl", ["mfma", "direct"])
 @pytest.mark.parametrize("tag,size,n,two,alpha", CASES)
 def test_model_matches_reference_goldens(tag, size, n, two, alpha, impl, golden_model):
+    if impl == "direct" and size > 128:
+        pytest.skip("the vector-ALU second-opinion kernels are exercised at 64^2 / 128^2")
     arch = A.fiducial_architecture(size, predict_var=two)
     m, P = _model(arch, impl)
     assert ",".join(m.state_dict().keys()) == str(golden_model[f"{tag}/state_keys"])
@@ -78,24 +84,24 @@ def test_model_matches_reference_goldens(tag, size, n, two, alpha, impl, golden_
     check(f"{tag}/x_mu", m.x_mu.cpu().numpy(), golden_model, 1e-4)
     check(f"{tag}/z_mu", m.z_mu.cpu().numpy(), golden_model, 1e-4)
     check(f"{tag}/z_log_var", m.z_log_var.cpu().numpy(), golden_model, 1e-4)
+    if f"{tag}/x_mu/crop_tl" in golden_model:
+        assert crop_rel_l2(f"{tag}/x_mu", m.x_mu.cpu().numpy(), golden_model) <= 1e-4
     for k, p in m.named_parameters():
         assert p.grad is not None, k
-        # the direct kernels are a debugging fallback; with them in the forward pass the
-        # cancellation-dominated gradients land ~0.5% from the true value (open question, see
-        # DESIGN.md "Numerical parity"): coarse bound only
-        _check_grad(tag, k, p.grad.cpu().numpy(), golden_model, slack=60.0 if impl == "direct" else 1.0)
+        _check_grad(tag, k, p.grad.cpu().numpy(), golden_model)
     for k, b in m.named_buffers():
         check(f"{tag}/buf/{k}", b.cpu().numpy(), golden_model, 2e-5)
-    # float64 oracle, tighter
-    ora = CVAEOracle(arch, dtype=np.float64)
-    ora.load_params(P)
-    if alpha is not None:
-        ora.alpha_var = alpha
-    ora.forward(x, y, aux, eps)
-    g = ora.backward(seed=-1.0)
-    errs = sorted(((G.rel_err(p.grad.cpu().numpy(), g[k]), k) for k, p in m.named_parameters()), reverse=True)
-    print("worst gradient errors vs float64 oracle:", errs[:5])
-    assert errs[0][0] < (5e-2 if impl == "direct" else 2e-3), errs[:5]
+    if size <= 128:
+        # float64 NumPy oracle in-process, every gradient (the fixtures hold summaries of the large ones)
+        ora = CVAEOracle(arch, dtype=np.float64)
+        ora.load_params(P)
+        if alpha is not None:
+            ora.alpha_var = alpha
+        ora.forward(x, y, aux, eps)
+        g = ora.backward(seed=-1.0)
+        errs = sorted(((G.rel_err(p.grad.cpu().numpy(), g[k]), k) for k, p in m.named_parameters()), reverse=True)
+        print("worst gradient errors vs float64 oracle:", errs[:5])
+        assert errs[0][0] < 2e-3, errs[:5]
     # paint-style sampling in eval mode (running statistics)
     m.train(False)
     m._eps_override = syn.synthetic_eps((1, n, *arch["dim_z"]), seed=100)
@@ -104,6 +110,8 @@ def test_model_matches_reference_goldens(tag, size, n, two, alpha, impl, golden_
     zfix = syn.synthetic_eps((n, *arch["dim_z"]), seed=101)
     s = m.sample_P(torch.from_numpy(y), aux_label=torch.from_numpy(aux), z=zfix)
     check(f"{tag}/sample_P_eval_zfix", s.cpu().numpy(), golden_model, 1e-4)
+    if f"{tag}/sample_P_eval_zfix/crop_tl" in golden_model:
+        assert crop_rel_l2(f"{tag}/sample_P_eval_zfix", s.cpu().numpy(), golden_model) <= 1e-4
     if two:
         _, var = m.sample_P(torch.from_numpy(y), aux_label=torch.from_numpy(aux), z=zfix, return_var=True)
         check(f"{tag}/sample_P_eval_var", var.cpu().numpy(), golden_model, 1e-4)
@@ -120,14 +128,27 @@ def test_fiducial_512_matches_reference_goldens(golden_model):
     tag = "fid512_n2"
     check(f"{tag}/stats", np.array(m.get_stats()), golden_model, 2e-5)
     check(f"{tag}/x_mu", m.x_mu.cpu().numpy(), golden_model, 1e-4)
+    # north_star: "within 1e-4 rel-L2 of reference" as a true ||a-b||/||b|| over full-resolution crops
+    assert crop_rel_l2(f"{tag}/x_mu", m.x_mu.cpu().numpy(), golden_model) <= 1e-4
     for k, p in m.named_parameters():
         _check_grad(tag, k, p.grad.cpu().numpy(), golden_model)
     for k, b in m.named_buffers():
         check(f"{tag}/buf/{k}", b.cpu().numpy(), golden_model, 2e-5)
     m.train(False)
+    yt, at = torch.from_numpy(y), torch.from_numpy(aux)
     zfix = syn.synthetic_eps((2, *arch["dim_z"]), seed=101)
-    s = m.sample_P(torch.from_numpy(y), aux_label=torch.from_numpy(aux), z=zfix)
+    s = m.sample_P(yt, aux_label=at, z=zfix)
     check(f"{tag}/sample_P_eval_zfix", s.cpu().numpy(), golden_model, 1e-4)
+    assert crop_rel_l2(f"{tag}/sample_P_eval_zfix", s.cpu().numpy(), golden_model) <= 1e-4
+    m._eps_override = syn.synthetic_eps((1, 2, *arch["dim_z"]), seed=100)
+    s = m.sample_P(yt, aux_label=at)
+    check(f"{tag}/sample_P_eval", s.cpu().numpy(), golden_model, 1e-4)
+    assert crop_rel_l2(f"{tag}/sample_P_eval", s.cpu().numpy(), golden_model) <= 1e-4
+    # the hipGraph-captured paint forward (the path bench.py's paint leg times) against the same golden
+    m._eps_override = None
+    s = m.sample_P_graphed(yt, aux_label=at, z=zfix)
+    check(f"{tag}/sample_P_eval_zfix", s.cpu().numpy(), golden_model, 1e-4)
+    assert crop_rel_l2(f"{tag}/sample_P_eval_zfix", s.cpu().numpy(), golden_model) <= 1e-4
 
 
 def test_adam_step_matches_reference(golden_model):

@@ -159,6 +159,30 @@ def test_graphed_paint_matches_eager_statistics():
         m.sample_P_graphed(yt, aux_label=at)
 
 
+def test_graphed_paint_four_streams_equals_eager_given_z():
+    """The graph that bench.py's paint leg replays paints four sub-batches on four streams; with the latent given
+    (``sample_P(..., z=z)``, cvae.py:149-154) it must reproduce the eager single-stream forward -- which the golden
+    tests pin to the reference -- bit for bit (eval-mode layers do not couple the tiles of a batch)."""
+    from baryon_painter_amd.models.cvae import CVAE
+    arch = A.fiducial_architecture(128)
+    torch.manual_seed(4)
+    m = CVAE(arch, "cuda:0")
+    with torch.no_grad():                               # non-trivial running statistics
+        x, y, aux = syn.synthetic_batch(4, 128, 128, seed=12)
+        m(torch.from_numpy(x), torch.from_numpy(y), torch.from_numpy(aux))
+    m.train(False)
+    n = 32
+    x, y, aux = syn.synthetic_batch(n, 128, 128, seed=13)
+    yt, at = torch.from_numpy(y).cuda(), torch.from_numpy(aux).cuda()
+    z = syn.synthetic_eps((n, *arch["dim_z"]), seed=14)
+    eager = m.sample_P(yt, aux_label=at, z=z)
+    graphed = m.sample_P_graphed(yt, aux_label=at, z=z)
+    assert len(m._graphs[(n, "z")]["plans"]) == 4
+    assert torch.equal(eager, graphed)
+    again = m.sample_P_graphed(yt.flip(0), aux_label=at.flip(0), z=z[::-1].copy())
+    assert torch.equal(again.flip(0), eager)
+
+
 def test_device_tile_assembler_matches_host_dataset():
     """GPU batch assembly == BAHAMASDataset[idx] (index arithmetic bit-exact; transform to 1 ulp)."""
     from baryon_painter_amd.utils import data_transforms as T

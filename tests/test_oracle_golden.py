@@ -148,9 +148,10 @@ def test_full_model_matches_reference(tag, size, n, two, alpha, golden_model):
         check(f"{tag}/sample_P_eval_var", var, golden_model, 5e-5)
 
 
-@pytest.mark.parametrize("tag,size,n,two,alpha", CASES[:1] + CASES[2:])
+@pytest.mark.parametrize("tag,size,n,two,alpha", CASES[:1] + CASES[2:] + [("fid256_n4", 256, 4, False, None)])
 def test_torch_cpu_restatement_matches_reference(tag, size, n, two, alpha, golden_model):
-    """oracle/torch_ref.py (the timed CPU baseline of bench.py) against the same fixtures."""
+    """oracle/torch_ref.py (the timed CPU baseline of bench.py) against the same fixtures; fid256_n4 is the geometry
+    of BASELINE.json configs[0] (batch 4 of 256x256 tiles, dim_z 1x8x8)."""
     import torch
     from oracle.torch_ref import TorchRefCVAE
     arch = A.fiducial_architecture(size, predict_var=two)
@@ -165,7 +166,14 @@ def test_torch_cpu_restatement_matches_reference(tag, size, n, two, alpha, golde
     check(f"{tag}/stats", np.array(m.get_stats()), golden_model, 1e-6)
     check(f"{tag}/x_mu", m.x_mu.detach().numpy(), golden_model, 1e-6)
     for k in shapes:
-        check(f"{tag}/grad/{k}", m.P[k].grad.numpy(), golden_model, 1e-5, what="grad ")
+        # (at 256^2 the latent-path gradients move by 1e-3..1e-2 with the thread count of the host: fixtures'
+        #  grad_variant_dist; the same arithmetic on another core count is not bit-equal)
+        check(f"{tag}/grad/{k}", m.P[k].grad.numpy(), golden_model, 1e-5 if size <= 128 else 5e-2, what="grad ")
     m.training = False
     zfix = syn.synthetic_eps((n, *arch["dim_z"]), seed=101)
-    check(f"{tag}/sample_P_eval_zfix", m.sample_P(y, aux, z=zfix).numpy(), golden_model, 1e-6)
+    s = m.sample_P(y, aux, z=zfix).numpy()
+    check(f"{tag}/sample_P_eval_zfix", s, golden_model, 1e-6)
+    if f"{tag}/x_mu/crop_tl" in golden_model:
+        from golden_util import crop_rel_l2
+        assert crop_rel_l2(f"{tag}/x_mu", m.x_mu.detach().numpy(), golden_model) <= 1e-6
+        assert crop_rel_l2(f"{tag}/sample_P_eval_zfix", s, golden_model) <= 1e-6
