@@ -10,13 +10,14 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libbp_hip.so")
 
 BP_OK = 0
-IMPL_AUTO, IMPL_DIRECT, IMPL_MFMA = 0, 1, 2
+IMPL_AUTO, IMPL_DIRECT, IMPL_MFMA, IMPL_BF16 = 0, 1, 2, 3
 PACK_FWD, PACK_BWD = 0, 1
+F32, BF16 = 0, 1
 
 
 class View(C.Structure):
     _fields_ = [("ptr", C.c_void_p), ("n", C.c_int32), ("h", C.c_int32), ("w", C.c_int32),
-                ("c", C.c_int32), ("cstride", C.c_int32), ("coff", C.c_int32)]
+                ("c", C.c_int32), ("cstride", C.c_int32), ("coff", C.c_int32), ("dtype", C.c_int32)]
 
 
 class Pointwise(C.Structure):
@@ -54,6 +55,9 @@ SIGNATURES = {
     "bp_conv_pack_job_bytes": (C.c_int32, []),
     "bp_conv_pack_job": (C.c_int, [_CP, C.c_int, _P, _P, _P, C.POINTER(C.c_int64)]),
     "bp_conv_pack_jobs": (C.c_int, [_P, _P, C.c_int32, C.c_int64, _P]),
+    "bp_conv_bf16_packed_elems": (C.c_int64, [_CP, C.c_int]),
+    "bp_conv_bf16_pack": (C.c_int, [_CP, C.c_int, _P, _P, _P]),
+    "bp_conv_bf16_supported": (C.c_int, [_CP, C.c_int, _VP, _VP]),
     "bp_conv_forward": (C.c_int, [_CP, _VP, _PWP, _P, _P, _P, _VP, C.c_int, _P]),
     "bp_conv_backward_data": (C.c_int, [_CP, _VP, _P, _P, _VP, C.c_int, _P]),
     "bp_conv_backward_weight_workspace": (C.c_size_t, [_CP, _VP, _VP]),

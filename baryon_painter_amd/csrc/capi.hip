@@ -20,6 +20,15 @@ size_t bp_wgrad_mfma_workspace(const bp_conv* cv, const bp_view* X, const bp_vie
 int bp_wgrad_mfma(const bp_conv* cv, const bp_view* X, const PW& pwx, const bp_view* Y, const PW& pwy, float* dst,
                   void* workspace, size_t workspace_bytes, hipStream_t st);
 extern "C" int bp_sums_to_float(const double* sums, int32_t c, float* dst, void* stream);
+// conv_bf16.hip
+bool bp_bf16_igemm_ok(const ConvGeom& g, const bp_view* in, const bp_view* out);
+int64_t bp_bf16_packed_elems(const ConvGeom& g);
+int bp_bf16_pack(const ConvGeom& g, const WeightMap& wm, const float* w_torch, void* packed, hipStream_t st);
+int bp_bf16_igemm_run(const ConvGeom& g, const bp_view* in, const PW& pw, const void* packed, const float* bias,
+                      const bp_view* out, hipStream_t st);
+size_t bp_wgrad_bf16_workspace(const bp_conv* cv, const bp_view* X, const bp_view* Y);
+int bp_wgrad_bf16_run(const bp_conv* cv, const bp_view* X, const PW& pwx, const bp_view* Y, const PW& pwy, float* dst,
+                      void* workspace, size_t workspace_bytes, hipStream_t st);
 
 namespace {
 
@@ -29,9 +38,9 @@ bool conv_ok(const bp_conv* cv) {
          cv->out_pad < cv->stride + (cv->stride == 1);
 }
 
-// x: module input, y: module output
-bool shapes_ok(const bp_conv* cv, const bp_view* x, const bp_view* y) {
-  if (!bp_view_ok(x) || !bp_view_ok(y)) return false;
+// x: module input, y: module output (fp32 views unless `any`)
+bool shapes_ok(const bp_conv* cv, const bp_view* x, const bp_view* y, bool any = false) {
+  if (any ? (!bp_view_ok_any(x) || !bp_view_ok_any(y)) : (!bp_view_ok(x) || !bp_view_ok(y))) return false;
   if (x->n != y->n || x->c != cv->cin || y->c != cv->cout) return false;
   return y->h == bp_conv_out_extent(cv, x->h) && y->w == bp_conv_out_extent(cv, x->w) && y->h > 0 && y->w > 0;
 }
@@ -87,10 +96,31 @@ int bp_conv_pack_jobs(const void* jobs_dev, const int64_t* first_block_dev, int3
   return bp_igemm_pack_jobs(jobs_dev, first_block_dev, njobs, total_blocks, bp_stream(stream));
 }
 
+int64_t bp_conv_bf16_packed_elems(const bp_conv* cv, int dir) {
+  if (!conv_ok(cv) || (dir != BP_PACK_FWD && dir != BP_PACK_BWD)) return -1;
+  return bp_bf16_packed_elems(dir == BP_PACK_FWD ? bp_geom_forward(cv) : bp_geom_backward_data(cv));
+}
+
+int bp_conv_bf16_pack(const bp_conv* cv, int dir, const float* w_torch, void* packed, void* stream) {
+  if (!conv_ok(cv) || !w_torch || !packed || (dir != BP_PACK_FWD && dir != BP_PACK_BWD)) return BP_EINVAL;
+  const ConvGeom g = dir == BP_PACK_FWD ? bp_geom_forward(cv) : bp_geom_backward_data(cv);
+  return bp_bf16_pack(g, bp_wmap(cv, dir), w_torch, packed, bp_stream(stream));
+}
+
+int bp_conv_bf16_supported(const bp_conv* cv, int dir, const bp_view* in, const bp_view* out) {
+  if (!conv_ok(cv) || (dir != BP_PACK_FWD && dir != BP_PACK_BWD)) return 0;
+  if ((in && !bp_view_ok_any(in)) || (out && !bp_view_ok_any(out))) return 0;
+  return bp_bf16_igemm_ok(dir == BP_PACK_FWD ? bp_geom_forward(cv) : bp_geom_backward_data(cv), in, out) ? 1 : 0;
+}
+
 int bp_conv_forward(const bp_conv* cv, const bp_view* x, const bp_pointwise* x_pw, const float* packed_fwd,
                     const float* w_torch, const float* bias, const bp_view* y, int impl, void* stream) {
-  if (!conv_ok(cv) || !shapes_ok(cv, x, y)) return BP_EINVAL;
+  if (!conv_ok(cv) || !shapes_ok(cv, x, y, impl == BP_IMPL_BF16)) return BP_EINVAL;
   const ConvGeom g = bp_geom_forward(cv);
+  if (impl == BP_IMPL_BF16) {
+    if (!packed_fwd) return BP_EINVAL;
+    return bp_bf16_igemm_run(g, x, bp_pw(x_pw), packed_fwd, bias, y, bp_stream(stream));
+  }
   if (impl == BP_IMPL_AUTO) impl = packed_fwd ? BP_IMPL_MFMA : BP_IMPL_DIRECT;
   if (impl == BP_IMPL_MFMA) {
     if (!packed_fwd) return BP_EINVAL;
@@ -102,8 +132,12 @@ int bp_conv_forward(const bp_conv* cv, const bp_view* x, const bp_pointwise* x_p
 
 int bp_conv_backward_data(const bp_conv* cv, const bp_view* dy, const float* packed_bwd, const float* w_torch,
                           const bp_view* dx, int impl, void* stream) {
-  if (!conv_ok(cv) || !shapes_ok(cv, dx, dy)) return BP_EINVAL;
+  if (!conv_ok(cv) || !shapes_ok(cv, dx, dy, impl == BP_IMPL_BF16)) return BP_EINVAL;
   const ConvGeom g = bp_geom_backward_data(cv);
+  if (impl == BP_IMPL_BF16) {
+    if (!packed_bwd) return BP_EINVAL;
+    return bp_bf16_igemm_run(g, dy, PW{nullptr, nullptr, nullptr}, packed_bwd, nullptr, dx, bp_stream(stream));
+  }
   if (impl == BP_IMPL_AUTO) impl = packed_bwd ? BP_IMPL_MFMA : BP_IMPL_DIRECT;
   if (impl == BP_IMPL_MFMA) {
     if (!packed_bwd) return BP_EINVAL;
@@ -115,23 +149,33 @@ int bp_conv_backward_data(const bp_conv* cv, const bp_view* dy, const float* pac
 }
 
 size_t bp_conv_backward_weight_workspace(const bp_conv* cv, const bp_view* x, const bp_view* dy) {
-  if (!conv_ok(cv) || !shapes_ok(cv, x, dy)) return 0;
+  if (!conv_ok(cv) || !shapes_ok(cv, x, dy, true)) return 0;
   const bp_view* X = cv->transposed ? dy : x;
   const bp_view* Y = cv->transposed ? x : dy;
-  return align256(bp_wgrad_mfma_workspace(cv, X, Y)) + align256(bp_channel_sums_workspace(dy)) +
-         align256((size_t)2 * dy->c * sizeof(double));
+  // (the larger of the fp32 and the bf16 kernel's needs: the caller sizes one workspace per layer)
+  size_t main = (x->dtype == BP_F32 && dy->dtype == BP_F32) ? bp_wgrad_mfma_workspace(cv, X, Y) : 0;
+  const size_t mb = bp_wgrad_bf16_workspace(cv, X, Y);
+  if (mb > main) main = mb;
+  return align256(main) + align256(bp_channel_sums_workspace(dy)) + align256((size_t)2 * dy->c * sizeof(double));
 }
 
 int bp_conv_backward_weight(const bp_conv* cv, const bp_view* x, const bp_pointwise* x_pw, const bp_view* dy,
                             float* dw_torch, float* dbias, void* workspace, size_t workspace_bytes, int impl,
                             void* stream) {
-  if (!conv_ok(cv) || !shapes_ok(cv, x, dy) || !dw_torch) return BP_EINVAL;
+  if (!conv_ok(cv) || !shapes_ok(cv, x, dy, impl == BP_IMPL_BF16) || !dw_torch) return BP_EINVAL;
   const bp_view* X = cv->transposed ? dy : x;
   const bp_view* Y = cv->transposed ? x : dy;
   const PW none{nullptr, nullptr, nullptr};
   const PW pwx = cv->transposed ? none : bp_pw(x_pw);
   const PW pwy = cv->transposed ? bp_pw(x_pw) : none;
   hipStream_t st = bp_stream(stream);
+  if (impl == BP_IMPL_BF16) {
+    if (dbias) return BP_EUNSUPPORTED;       // (bias gradients: the fp32 path; the CVAE's convolutions have none)
+    const size_t need = bp_wgrad_bf16_workspace(cv, X, Y);
+    if (!need) return BP_EUNSUPPORTED;
+    if (!workspace || workspace_bytes < need) return BP_EWORKSPACE;
+    return bp_wgrad_bf16_run(cv, X, pwx, Y, pwy, dw_torch, workspace, workspace_bytes, st);
+  }
   const size_t ws_main = align256(bp_wgrad_mfma_workspace(cv, X, Y));
   if (impl == BP_IMPL_AUTO) impl = ws_main ? BP_IMPL_MFMA : BP_IMPL_DIRECT;
   if (impl == BP_IMPL_MFMA || dbias) {

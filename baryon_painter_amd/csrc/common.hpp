@@ -11,10 +11,13 @@
 
 static inline hipStream_t bp_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
-static inline bool bp_view_ok(const bp_view* v) {
+// geometry of a view, any element type
+static inline bool bp_view_ok_any(const bp_view* v) {
   return v && v->ptr && v->n > 0 && v->h > 0 && v->w > 0 && v->c > 0 && v->cstride >= v->c &&
-         v->coff >= 0 && v->coff + v->c <= v->cstride;
+         v->coff >= 0 && v->coff + v->c <= v->cstride && (v->dtype == BP_F32 || v->dtype == BP_BF16);
 }
+// ... of an fp32 view: what every entry point without a bf16 form checks
+static inline bool bp_view_ok(const bp_view* v) { return bp_view_ok_any(v) && v->dtype == BP_F32; }
 
 // every pixel's channel slice starts on a 16-byte boundary
 static inline bool bp_view_vec4(const bp_view* v) {

@@ -271,6 +271,27 @@ static int wgrad_chunked(const bp_conv* cv, const bp_view* X, const PW& pwx, con
   return BP_OK;
 }
 
+// bf16 matrix-core weight gradient (conv_bf16.hip) + the same fixed-order reduction; operands may be fp32 or bf16
+int bp_wgrad_bf16(const bp_conv* cv, const bp_view* X, const PW& pwx, const bp_view* Y, const PW& pwy, float* ws,
+                  size_t ws_bytes, size_t* need, int* nsplit, int* cxp, int* cyp, hipStream_t st, bool dry);
+
+size_t bp_wgrad_bf16_workspace(const bp_conv* cv, const bp_view* X, const bp_view* Y) {
+  size_t need = 0;
+  int ns, cxp, cyp;
+  const PW none{nullptr, nullptr, nullptr};
+  return bp_wgrad_bf16(cv, X, none, Y, none, nullptr, 0, &need, &ns, &cxp, &cyp, nullptr, true) == BP_OK ? need : 0;
+}
+
+int bp_wgrad_bf16_run(const bp_conv* cv, const bp_view* X, const PW& pwx, const bp_view* Y, const PW& pwy, float* dst,
+                      void* workspace, size_t workspace_bytes, hipStream_t st) {
+  size_t need = 0;
+  int ns, cxp, cyp;
+  const int rc = bp_wgrad_bf16(cv, X, pwx, Y, pwy, reinterpret_cast<float*>(workspace), workspace_bytes, &need, &ns,
+                               &cxp, &cyp, st, false);
+  if (rc != BP_OK) return rc;
+  return wgrad_reduce(reinterpret_cast<const float*>(workspace), dst, cv->k, X->c, Y->c, cxp, cyp, ns, st);
+}
+
 size_t bp_wgrad_mfma_workspace(const bp_conv* cv, const bp_view* X, const bp_view* Y) {
   size_t need = 0;
   int ns, cxp, cyp;

@@ -823,9 +823,43 @@ __global__ __launch_bounds__(RB) void adam_dev_kernel(float* p, const float* g, 
 
 }  // namespace
 
+// out[i] = sum over blocks of partial[b][i], fixed order (shared with pointwise_bf16.hip)
+int bp_sum_partials(const double* partial, int nblk, int n, double* out, hipStream_t st) {
+  hipLaunchKernelGGL(sum_partials_wave_kernel, dim3(n), dim3(64), 0, st, partial, nblk, n, out);
+  BP_CHECK_LAUNCH();
+  return BP_OK;
+}
+
+// pointwise_bf16.hip: the same passes over dense bf16 views
+bool bp_bf16_dense_ok(const bp_view* v);
+size_t bp_bf16_reduce_workspace(const bp_view* x, int nsums);
+int bp_bf16_channel_sums(const bp_view* x, double* sums, void* workspace, hipStream_t st);
+int bp_bf16_act_backward(const bp_view* dout, const bp_view* dout2, const bp_view* raw, const PW& pw,
+                         const bp_view* act_out, const bp_view* g, double* sums, void* workspace, hipStream_t st);
+int bp_bf16_bn_backward_apply(const bp_view* dout, const bp_view* dout2, const bp_view* raw, const PW& pw,
+                              const bp_view* act_out, const double* abc, const bp_view* out, bool recompute_g,
+                              hipStream_t st);
+int bp_bf16_residual_forward(const bp_view* raw, const PW& pw, const bp_view* skip, const PW& spw, float slope,
+                             const bp_view* out, hipStream_t st);
+
+// A call whose views are bf16: every view must be a dense bf16 view of the same grid (the layouts the launch
+// plan produces for the generator trunk); anything else has no bf16 form.
+static bool is_bf16(const bp_view* v) { return v && v->dtype == BP_BF16; }
+static bool bf16_set_ok(const bp_view* ref, const bp_view* const* vs, int n) {
+  if (!bp_view_ok_any(ref) || !bp_bf16_dense_ok(ref)) return false;
+  for (int i = 0; i < n; ++i) {
+    const bp_view* v = vs[i];
+    if (!v) continue;
+    if (!bp_view_ok_any(v) || !bp_bf16_dense_ok(v) || v->n != ref->n || v->h != ref->h || v->w != ref->w || v->c != ref->c)
+      return false;
+  }
+  return true;
+}
+
 extern "C" {
 
 size_t bp_channel_sums_workspace(const bp_view* x) {
+  if (is_bf16(x)) return bp_view_ok_any(x) && bp_bf16_dense_ok(x) ? bp_bf16_reduce_workspace(x, 2) : 0;
   if (!bp_view_ok(x)) return 0;
   const RedPlan r = red_plan(x->c, bp_view_pixels(x));
   const FastPlan f = fast_plan(bp_view_pixels(x) * x->c);
@@ -834,6 +868,12 @@ size_t bp_channel_sums_workspace(const bp_view* x) {
 }
 
 int bp_channel_sums(const bp_view* x, double* sums, void* workspace, size_t workspace_bytes, void* stream) {
+  if (is_bf16(x)) {
+    if (!sums) return BP_EINVAL;
+    if (!bf16_set_ok(x, nullptr, 0)) return BP_EUNSUPPORTED;
+    if (!workspace || workspace_bytes < bp_bf16_reduce_workspace(x, 2)) return BP_EWORKSPACE;
+    return bp_bf16_channel_sums(x, sums, workspace, bp_stream(stream));
+  }
   if (!bp_view_ok(x) || !sums) return BP_EINVAL;
   if (!workspace || workspace_bytes < bp_channel_sums_workspace(x)) return BP_EWORKSPACE;
   const RedPlan r = red_plan(x->c, bp_view_pixels(x));
@@ -878,6 +918,7 @@ int bp_bn_eval_pointwise(int32_t c, const float* gamma, const float* beta, const
 }
 
 size_t bp_act_backward_workspace(const bp_view* raw) {
+  if (is_bf16(raw)) return bp_view_ok_any(raw) && bp_bf16_dense_ok(raw) ? bp_bf16_reduce_workspace(raw, 3) : 0;
   if (!bp_view_ok(raw)) return 0;
   const RedPlan r = red_plan(raw->c, bp_view_pixels(raw));
   const FastPlan f = fast_plan(bp_view_pixels(raw) * raw->c);
@@ -892,6 +933,13 @@ static bool same_grid(const bp_view* a, const bp_view* b) {
 int bp_act_backward(const bp_view* dout, const bp_view* dout2, const bp_view* raw, const bp_pointwise* pw,
                     const bp_view* act_out, const bp_view* g, double* sums, void* workspace,
                     size_t workspace_bytes, void* stream) {
+  if (is_bf16(raw) || is_bf16(dout) || is_bf16(dout2) || is_bf16(act_out) || is_bf16(g)) {
+    if (!sums || !dout) return BP_EINVAL;
+    const bp_view* vs[4] = {dout, dout2, act_out, g};
+    if (!bf16_set_ok(raw, vs, 4)) return BP_EUNSUPPORTED;
+    if (!workspace || workspace_bytes < bp_bf16_reduce_workspace(raw, 3)) return BP_EWORKSPACE;
+    return bp_bf16_act_backward(dout, dout2, raw, bp_pw(pw), act_out, g, sums, workspace, bp_stream(stream));
+  }
   if (!bp_view_ok(dout) || !bp_view_ok(raw) || (g && !bp_view_ok(g)) || !sums) return BP_EINVAL;
   if (!same_grid(dout, raw) || (g && !same_grid(g, raw))) return BP_EINVAL;
   if (dout2 && (!bp_view_ok(dout2) || !same_grid(dout2, raw))) return BP_EINVAL;
@@ -940,6 +988,13 @@ int bp_bn_backward_finalize(const double* sums, double count, int32_t c, const f
 
 int bp_bn_backward_apply(const bp_view* g, const bp_view* raw, const double* coef_abc, const bp_view* out,
                          void* stream) {
+  if (is_bf16(g) || is_bf16(raw) || is_bf16(out)) {
+    if (!coef_abc || !g || !out) return BP_EINVAL;
+    const bp_view* vs[2] = {g, out};
+    if (!bf16_set_ok(raw, vs, 2)) return BP_EUNSUPPORTED;
+    return bp_bf16_bn_backward_apply(g, nullptr, raw, PW{nullptr, nullptr, nullptr}, nullptr, coef_abc, out, false,
+                                     bp_stream(stream));
+  }
   if (!bp_view_ok(g) || !bp_view_ok(raw) || !bp_view_ok(out) || !same_grid(g, raw) || !same_grid(g, out) ||
       !coef_abc)
     return BP_EINVAL;
@@ -962,6 +1017,12 @@ int bp_bn_backward_apply(const bp_view* g, const bp_view* raw, const double* coe
 
 int bp_act_bn_backward_apply(const bp_view* dout, const bp_view* dout2, const bp_view* raw, const bp_pointwise* pw,
                              const bp_view* act_out, const double* coef_abc, const bp_view* out, void* stream) {
+  if (is_bf16(raw) || is_bf16(dout) || is_bf16(dout2) || is_bf16(act_out) || is_bf16(out)) {
+    if (!coef_abc || !dout || !out) return BP_EINVAL;
+    const bp_view* vs[4] = {dout, dout2, act_out, out};
+    if (!bf16_set_ok(raw, vs, 4)) return BP_EUNSUPPORTED;
+    return bp_bf16_bn_backward_apply(dout, dout2, raw, bp_pw(pw), act_out, coef_abc, out, true, bp_stream(stream));
+  }
   if (!bp_view_ok(dout) || !bp_view_ok(raw) || !bp_view_ok(out) || !coef_abc) return BP_EINVAL;
   if (!same_grid(dout, raw) || !same_grid(out, raw)) return BP_EINVAL;
   if (dout2 && (!bp_view_ok(dout2) || !same_grid(dout2, raw))) return BP_EINVAL;
@@ -1003,6 +1064,12 @@ int bp_sums_to_float(const double* sums, int32_t c, float* dst, void* stream) {
 
 int bp_residual_forward(const bp_view* raw, const bp_pointwise* pw, const bp_view* skip,
                         const bp_pointwise* skip_pw, float slope, const bp_view* out, void* stream) {
+  if (is_bf16(raw) || is_bf16(skip) || is_bf16(out)) {
+    if (!skip || !out) return BP_EINVAL;
+    const bp_view* vs[2] = {skip, out};
+    if (!bf16_set_ok(raw, vs, 2)) return BP_EUNSUPPORTED;
+    return bp_bf16_residual_forward(raw, bp_pw(pw), skip, bp_pw(skip_pw), slope, out, bp_stream(stream));
+  }
   if (!bp_view_ok(raw) || !bp_view_ok(skip) || !bp_view_ok(out)) return BP_EINVAL;
   if (!same_grid(raw, skip) || !same_grid(raw, out)) return BP_EINVAL;
   const int64_t total = bp_view_pixels(raw) * raw->c;

@@ -32,13 +32,20 @@ extern "C" {
 #define BP_ELAUNCH (-3)      /* hipGetLastError() != hipSuccess after the launch */
 #define BP_EWORKSPACE (-4)   /* workspace too small */
 
-/* NHWC view: element (n,y,x,ch) lives at ptr[((n*h + y)*w + x)*cstride + coff + ch]. */
+/* Element type of a view.  fp32 is the reference's arithmetic (parity mode, BASELINE.json configs[1]); bf16
+ * storage with fp32 accumulation is the throughput mode of configs[3] and is accepted by the entry points that say
+ * so (convolutions, batch-norm statistics, activation / batch-norm backward, residual tail); every other entry
+ * point returns BP_EUNSUPPORTED for a bf16 view. */
+enum { BP_F32 = 0, BP_BF16 = 1 };
+
+/* NHWC view: element (n,y,x,ch) lives at ptr[((n*h + y)*w + x)*cstride + coff + ch] (in elements of `dtype`). */
 typedef struct bp_view {
-  float* ptr;
+  float* ptr;      /* device pointer (to 2-byte elements when dtype == BP_BF16) */
   int32_t n, h, w;
   int32_t c;       /* channels in this view            */
   int32_t cstride; /* channels of the underlying buffer */
   int32_t coff;    /* first channel of the view         */
+  int32_t dtype;   /* BP_F32 (0) or BP_BF16             */
 } bp_view;
 
 /* Per-channel t = x*scale[ch] + shift[ch];  y = t > 0 ? t : t*slope[ch].
@@ -57,7 +64,7 @@ typedef struct bp_conv {
   int32_t k, stride, pad, out_pad;
 } bp_conv;
 
-enum { BP_IMPL_AUTO = 0, BP_IMPL_DIRECT = 1, BP_IMPL_MFMA = 2 };
+enum { BP_IMPL_AUTO = 0, BP_IMPL_DIRECT = 1, BP_IMPL_MFMA = 2, BP_IMPL_BF16 = 3 };
 enum { BP_PACK_FWD = 0, BP_PACK_BWD = 1 };
 
 /* ---- library ------------------------------------------------------------------------------ */
@@ -93,6 +100,14 @@ int bp_conv_pack_job(const bp_conv* cv, int dir, const float* w_torch, float* pa
                      int64_t* nblocks);
 int bp_conv_pack_jobs(const void* jobs_dev, const int64_t* first_block_dev, int32_t njobs,
                       int64_t total_blocks, void* stream);
+
+/* bf16 matrix-core path (configs[3]): impl == BP_IMPL_BF16 in the three calls below takes a bf16 packed image
+ * (bp_conv_bf16_pack, bp_conv_bf16_packed_elems 2-byte elements) and views of either element type on both sides;
+ * products are bf16 x bf16, accumulation and the weight gradient are fp32.  bp_conv_bf16_supported says whether
+ * the kernels take a layer / direction with the given views (NULL: any). */
+int64_t bp_conv_bf16_packed_elems(const bp_conv* cv, int dir);
+int bp_conv_bf16_pack(const bp_conv* cv, int dir, const float* w_torch, void* packed, void* stream);
+int bp_conv_bf16_supported(const bp_conv* cv, int dir, const bp_view* in, const bp_view* out);
 
 /* y_raw = conv(act(x)) [+ bias].  `x_pw` may be NULL (identity). */
 int bp_conv_forward(const bp_conv* cv, const bp_view* x, const bp_pointwise* x_pw,

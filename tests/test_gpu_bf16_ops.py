@@ -1,0 +1,132 @@
+"""GPU: the bf16 matrix-core convolutions (csrc/conv_bf16.hip, impl BP_IMPL_BF16) through the C ABI.
+
+The kernels multiply bf16 x bf16 exactly and accumulate in fp32, so against a float64 convolution of the SAME
+bf16-rounded operands (activation applied in fp32, then rounded, as the kernel does) the only differences are the
+fp32 accumulation order and, for bf16 outputs, one final rounding:
+    fp32 output  <= 2e-5 of the tensor's scale        bf16 output  <= 2^-8 (4e-3) of the tensor's scale.
+Every trunk layer class of the fiducial CVAE generator, forward, data gradient and weight
+gradient, with each side fp32 or bf16, at sizes that leave ragged tiles."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from baryon_painter_amd import _lib as L
+from oracle import ops
+
+import gpu_util as G
+
+pytestmark = pytest.mark.gpu
+
+
+def bf16_round(a):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(torch.bfloat16).to(torch.float32).numpy()
+
+
+def to_view(x_nchw, bf16, cstride=None, coff=0):
+    n, c, h, w = x_nchw.shape
+    cs = c if cstride is None else cstride
+    buf = torch.full((n, h, w, cs), 7.5, dtype=torch.float32, device="cuda")
+    buf[..., coff:coff + c] = torch.from_numpy(np.ascontiguousarray(x_nchw.transpose(0, 2, 3, 1))).cuda()
+    if bf16:
+        buf = buf.to(torch.bfloat16)
+    return buf, L.View(buf.data_ptr(), n, h, w, c, cs, coff, L.BF16 if bf16 else L.F32)
+
+
+def empty_view(n, h, w, c, bf16, cstride=None, coff=0):
+    cs = c if cstride is None else cstride
+    buf = torch.full((n, h, w, cs), float("nan"), dtype=torch.bfloat16 if bf16 else torch.float32, device="cuda")
+    return buf, L.View(buf.data_ptr(), n, h, w, c, cs, coff, L.BF16 if bf16 else L.F32)
+
+
+def from_view(buf, c, coff=0):
+    return buf[..., coff:coff + c].to(torch.float32).permute(0, 3, 1, 2).contiguous().cpu().numpy()
+
+
+# (transposed, cin, cout, k, stride, pad, (n, h, w), in_cstride): the generator trunk + heads
+CASES = [
+    (0, 3, 16, 5, 1, 2, (2, 21, 37), 4),            # p_y_z_in.0 (the 3(+1)-channel stem; CC = 4, 8 taps per MFMA)
+    (0, 16, 32, 4, 2, 1, (2, 22, 38), None),        # p_y_z_in.3  (CC = 16, tap pairs in the stride planes)
+    (0, 32, 64, 4, 2, 1, (2, 14, 22), None),
+    (0, 64, 128, 4, 2, 1, (2, 10, 38), None),
+    (0, 128, 128, 3, 1, 1, (2, 13, 35), None),      # residual trunk
+    (1, 128, 64, 4, 2, 1, (2, 7, 18), None),        # decoder
+    (1, 64, 32, 4, 2, 1, (3, 5, 9), None),
+    (1, 32, 16, 4, 2, 1, (2, 9, 21), None),
+    (0, 16, 8, 7, 1, 3, (2, 19, 35), None),         # p_mu_out.0 (data gradient gathers 8 channels: CC = 8)
+]
+
+
+@pytest.mark.parametrize("io", [(True, True), (False, True), (True, False), (False, False)],
+                         ids=["bf16-bf16", "f32-bf16", "bf16-f32", "f32-f32"])
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "%s%d_%d_k%ds%d" % ("T" if c[0] else "C", *c[1:5]))
+def test_bf16_convolution_forward_dgrad_wgrad(case, io):
+    lib = L.load()
+    tr, ci, co, k, s, p, (n, h, w), in_cs = case
+    in_bf, out_bf = io
+    rng = np.random.default_rng(ci * 11 + co + k + 2 * in_bf + out_bf)
+    x = rng.standard_normal((n, ci, h, w)).astype(np.float32)
+    wt = (rng.standard_normal(((ci, co) if tr else (co, ci)) + (k, k)) * 0.1).astype(np.float32)
+    scale = rng.uniform(0.5, 1.5, ci).astype(np.float32)
+    shift = rng.uniform(0.2, 0.6, ci).astype(np.float32)          # act(0) != 0: padding must stay 0
+    slope = rng.uniform(0.0, 0.3, ci).astype(np.float32)
+    xin = bf16_round(x) if in_bf else x
+    # the kernel evaluates fmaf(x, scale, shift) in fp32: product exact in float64, one rounding
+    t = (xin.astype(np.float64) * scale[None, :, None, None].astype(np.float64)
+         + shift[None, :, None, None].astype(np.float64)).astype(np.float32)
+    xa = bf16_round(np.where(t > 0, t, t * slope[None, :, None, None]).astype(np.float32)).astype(np.float64)
+    w64 = bf16_round(wt).astype(np.float64)
+    y_ref = ops.convT2d_fwd(xa, w64, s, p, 0) if tr else ops.conv2d_fwd(xa, w64, s, p)
+    _, _, ho, wo = y_ref.shape
+    cv = L.Conv(tr, ci, co, k, s, p, 0)
+    st = G.stream()
+    xb, xv = to_view(xin, in_bf, cstride=in_cs)
+    yb, yv = empty_view(n, ho, wo, co, out_bf, cstride=co + 8, coff=8)
+    assert lib.bp_conv_bf16_supported(C.byref(cv), L.PACK_FWD, C.byref(xv), C.byref(yv)) == 1
+    keep, pw = G.pointwise(scale, shift, slope)
+    wd = G.dev(wt)
+    pf = torch.zeros(lib.bp_conv_bf16_packed_elems(C.byref(cv), L.PACK_FWD), device="cuda", dtype=torch.bfloat16)
+    pb = torch.zeros(lib.bp_conv_bf16_packed_elems(C.byref(cv), L.PACK_BWD), device="cuda", dtype=torch.bfloat16)
+    L.check(lib.bp_conv_bf16_pack(C.byref(cv), L.PACK_FWD, L.ptr(wd), L.ptr(pf), st))
+    L.check(lib.bp_conv_bf16_pack(C.byref(cv), L.PACK_BWD, L.ptr(wd), L.ptr(pb), st))
+    L.check(lib.bp_conv_forward(C.byref(cv), C.byref(xv), C.byref(pw), L.ptr(pf), L.ptr(wd), None, C.byref(yv),
+                                L.IMPL_BF16, st), "forward")
+    tol = 4e-3 if out_bf else 2e-5
+    got = from_view(yb, co, coff=8)
+    assert G.rel_err(got, y_ref) < tol, "forward"
+    raw = yb.to(torch.float32)
+    assert torch.isnan(raw[..., :8]).all(), "stores outside the view"
+
+    # ---- data gradient (no pending activation on dy)
+    dy = rng.standard_normal(y_ref.shape).astype(np.float32)
+    dyin = bf16_round(dy) if in_bf else dy
+    dy64 = bf16_round(dyin).astype(np.float64)
+    dyb, dyv = to_view(dyin, in_bf)
+    dxb, dxv = empty_view(n, h, w, ci, out_bf and ci % 8 == 0, cstride=None if ci != 3 else 4)
+    L.check(lib.bp_conv_backward_data(C.byref(cv), C.byref(dyv), L.ptr(pb), L.ptr(wd), C.byref(dxv), L.IMPL_BF16, st),
+            "backward_data")
+    dx_ref = ops.convT2d_bwd_data(dy64, w64, s, p) if tr else ops.conv2d_bwd_data(dy64, w64, s, p, h, w)
+    assert G.rel_err(from_view(dxb, ci), dx_ref) < (4e-3 if dxv.dtype == L.BF16 else 2e-5), "backward_data"
+
+    # ---- weight gradient: fp32 result from bf16 products
+    ws_bytes = lib.bp_conv_backward_weight_workspace(C.byref(cv), C.byref(xv), C.byref(dyv))
+    assert ws_bytes > 0
+    ws = torch.zeros(ws_bytes // 8 + 8, dtype=torch.float64, device="cuda")
+    dw = torch.full(wt.shape, float("nan"), device="cuda")
+    L.check(lib.bp_conv_backward_weight(C.byref(cv), C.byref(xv), C.byref(pw), C.byref(dyv), L.ptr(dw), None,
+                                        L.ptr(ws), ws.numel() * 8, L.IMPL_BF16, st), "backward_weight")
+    dw_ref = ops.convT2d_bwd_weight(xa, dy64, s, p, k, k) if tr else ops.conv2d_bwd_weight(xa, dy64, s, p, k, k)
+    assert G.rel_err(dw.cpu().numpy(), dw_ref) < 1e-4, "backward_weight"
+
+
+def test_fp32_entry_points_refuse_bf16_views():
+    lib = L.load()
+    buf, v = empty_view(1, 4, 4, 8, True)
+    sums = torch.zeros(16, dtype=torch.float64, device="cuda")
+    ws = torch.zeros(4096, dtype=torch.float64, device="cuda")
+    cv = L.Conv(0, 8, 8, 3, 1, 1, 0)
+    out, ov = empty_view(1, 4, 4, 8, False)
+    pf = torch.zeros(lib.bp_conv_packed_floats(C.byref(cv), L.PACK_FWD), device="cuda")
+    assert lib.bp_conv_forward(C.byref(cv), C.byref(v), None, L.ptr(pf), None, None, C.byref(ov), L.IMPL_MFMA,
+                               G.stream()) == -1            # BP_EINVAL: the fp32 kernels take fp32 views only
