@@ -324,7 +324,7 @@ struct BConfig {
   bool ok;
 };
 
-BConfig b_config(const ConvGeom& g) {
+static BConfig b_config_for(const ConvGeom& g, int NT, int WN) {
   BConfig c{};
   const int cin = g.cin_g;
   if (cin % 32 == 0) c.CC = 32;
@@ -334,11 +334,7 @@ BConfig b_config(const ConvGeom& g) {
   else return c;
   c.R = 32 / c.CC;
   c.nchunk = c.CC == 32 ? cin / 32 : 1;
-  const int nT = bp_ceil_div(g.cout_g, 16);
-  if (nT >= 5) { c.NT = 4; c.WN = 2; }
-  else if (nT >= 3) { c.NT = 4; c.WN = 1; }
-  else if (nT == 2) { c.NT = 2; c.WN = 1; }
-  else { c.NT = 1; c.WN = 1; }
+  c.NT = NT; c.WN = WN;
   c.MT = 4;
   c.COB = 16 * c.NT * c.WN;
   c.cout_padP = bp_round_up(g.cout_g, c.COB);
@@ -364,6 +360,22 @@ BConfig b_config(const ConvGeom& g) {
   c.lds_bytes = in_b + (size_t)c.nrun * c.COB * 32 * 2;
   c.ok = c.lds_bytes <= 80 * 1024 && c.slots <= 12;       // two workgroups per CU
   return c;
+}
+
+// Waves split the pixels of a 256-pixel tile (WN = 1) unless the produced-channel block is 128 wide or the halo
+// of such a tile does not fit (strided gathers of 32-channel chunks): then two waves share each half tile.
+BConfig b_config(const ConvGeom& g) {
+  const int nT = bp_ceil_div(g.cout_g, 16);
+  if (nT >= 5) return b_config_for(g, 4, 2);
+  if (nT >= 3) {
+    const BConfig c = b_config_for(g, 4, 1);
+    return c.ok ? c : b_config_for(g, 2, 2);
+  }
+  if (nT == 2) {
+    const BConfig c = b_config_for(g, 2, 1);
+    return c.ok ? c : b_config_for(g, 1, 2);
+  }
+  return b_config_for(g, 1, 1);
 }
 
 // weights: torch layout (fp32) -> [phase][ty][run][chunk][cout_padP][32] bf16, k = j*CC + cc <-> tap xm + IS*(xq + j)
@@ -434,7 +446,9 @@ template <int CC>
 int b_launch_cc(const BConfig& c, const BArgs& a, bool ib, bool ob, dim3 grid, hipStream_t st) {
   if (c.NT == 4 && c.WN == 2) return b_launch_slots<CC, 4, 2>(c, a, ib, ob, grid, st);
   if (c.NT == 4 && c.WN == 1) return b_launch_slots<CC, 4, 1>(c, a, ib, ob, grid, st);
+  if (c.NT == 2 && c.WN == 2) return b_launch_slots<CC, 2, 2>(c, a, ib, ob, grid, st);
   if (c.NT == 2) return b_launch_slots<CC, 2, 1>(c, a, ib, ob, grid, st);
+  if (c.NT == 1 && c.WN == 2) return b_launch_slots<CC, 1, 2>(c, a, ib, ob, grid, st);
   return b_launch_slots<CC, 1, 1>(c, a, ib, ob, grid, st);
 }
 

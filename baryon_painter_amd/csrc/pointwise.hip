@@ -773,7 +773,8 @@ __global__ __launch_bounds__(RB) void gather_tiles_kernel(const TileDesc* d100, 
   const float vb = b.base[(int64_t)(b.r0 + b.rr * r + b.rc * c) * b.pitch + (b.c0 + b.cr * r + b.cc * c)];
   const float s = va + vb;                                   // float32 add, like the host path
   const SampleXform x = xf[n];
-  double v = x.scale == 1.0 ? (double)s : (double)(float)(x.scale * (double)s);
+  // (python float * float32 array = a float32 multiply with the scalar rounded to float32, datasets.py:399)
+  double v = x.scale == 1.0 ? (double)s : (double)((float)x.scale * s);
   if (x.mode == 1) v = log(v * x.inv_sigma + 1.0) * x.inv_k;
   out[i] = (float)v;
 }

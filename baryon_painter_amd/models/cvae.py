@@ -31,6 +31,7 @@ class _Plan:
         self.lib = model._lib
         self.device = model.device
         self.impl = model.impl
+        self.bf16 = model.dtype == "bf16"
         self.sync = model.sync
         self.n = n
         self.with_grad = with_grad
@@ -178,6 +179,18 @@ class _Plan:
                 u.ws_name = "ws_b"
             for u in self._flat(self.p_units):
                 u.ws_name = "ws_c"
+
+    # ---- bf16 policy (dtype="bf16", BASELINE.json configs[3]).  The generator trunk p_y_z_in and the first layer of
+    # each head run on the bf16 matrix-core kernels and every p_y_z_in activation / gradient is stored as bf16: that
+    # is 92 % of the activation bytes of a step (SURVEY.md 8a totals).  The recognition / prior networks, p_z_in and
+    # the 8-, 1-channel tails of the heads stay fp32: together 8 % of the bytes, and their few-channel layers have
+    # no 16-byte bf16 vectors to move.  Parameters, gradients of parameters, batch-norm statistics and every loss
+    # reduction are fp32 / fp64 in both modes.
+    def bf16_unit(self, name):
+        return self.bf16 and (name.startswith("p_y_z_in.") or name in ("p_mu_out.0", "p_var_out.0"))
+
+    def bf16_out(self, name):
+        return self.bf16 and name.startswith("p_y_z_in.")
 
     # ---- helpers
     @staticmethod
@@ -478,8 +491,14 @@ class _ELBOFunction(torch.autograd.Function):
 class CVAE(torch.nn.Module):
     """Drop-in for ``baryon_painter.models.cvae.CVAE`` (cvae.py:8-61)."""
 
-    def __init__(self, architecture, device="cuda:0", impl="auto", sync=None):
+    def __init__(self, architecture, device="cuda:0", impl="auto", sync=None, dtype="f32"):
+        """``dtype``: "f32" = the reference's arithmetic (parity mode); "bf16" = bf16 activations / gradients with
+        fp32 accumulation, fp32 master weights and fp32/fp64 statistics in the generator trunk (throughput mode,
+        BASELINE.json configs[3]; see ``_Plan.bf16_unit``)."""
         super().__init__()
+        if dtype not in ("f32", "bf16"):
+            raise ValueError("dtype must be 'f32' or 'bf16'")
+        self.dtype = dtype
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError("baryon_painter_amd.CVAE runs on an AMD GPU only (device='cuda:N'); "

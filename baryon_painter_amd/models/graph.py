@@ -171,22 +171,24 @@ class PW:
 
 class Slot:
     def __init__(self, buf, n, h, w, c, coff=0, pw=None, parent=None):
-        self.buf = buf                       # torch tensor (n,h,w,cstride)
+        self.buf = buf                       # torch tensor (n,h,w,cstride), float32 or bfloat16
         self.n, self.h, self.w, self.c = n, h, w, c
         self.cstride = buf.shape[-1]
         self.coff = coff
         self.pw = pw                          # None = identity
         self.parent = parent
-        self.view = L.View(buf.data_ptr(), n, h, w, c, self.cstride, coff)
+        self.dt = L.BF16 if buf.dtype == torch.bfloat16 else L.F32     # element type of the slot AND its gradients
+        self.view = L.View(buf.data_ptr(), n, h, w, c, self.cstride, coff, self.dt)
         self.grad_buf = None
         self.grad = None                      # L.View
         self.grad2 = None                     # L.View (second contribution) or None
         self.n_consumers = 0
 
     @staticmethod
-    def new(n, h, w, c, device, cstride=None, pw=None):
+    def new(n, h, w, c, device, cstride=None, pw=None, bf16=False):
         cs = c if cstride is None else cstride
-        return Slot(torch.zeros((n, h, w, cs), device=device, dtype=torch.float32), n, h, w, c, 0, pw)
+        return Slot(torch.zeros((n, h, w, cs), device=device, dtype=torch.bfloat16 if bf16 else torch.float32),
+                    n, h, w, c, 0, pw)
 
     def sub(self, c0, c1, pw=None):
         """Channel slice sharing storage (and gradient storage)."""
@@ -206,7 +208,8 @@ class Slot:
                 self.grad_buf = self.parent.grad_buf
             else:
                 self.grad_buf = torch.zeros_like(self.buf)
-            self.grad = L.View(self.grad_buf.data_ptr(), self.n, self.h, self.w, self.c, self.cstride, self.coff)
+            self.grad = L.View(self.grad_buf.data_ptr(), self.n, self.h, self.w, self.c, self.cstride, self.coff,
+                               self.dt)
         return self.grad
 
     def claim_grad(self):
@@ -215,8 +218,8 @@ class Slot:
         if self.n_consumers == 1:
             return self.ensure_grad()
         if self.n_consumers == 2 and self.grad2 is None:
-            self._grad2_buf = torch.zeros((self.n, self.h, self.w, self.c), device=self.buf.device)
-            self.grad2 = L.View(self._grad2_buf.data_ptr(), self.n, self.h, self.w, self.c, self.c, 0)
+            self._grad2_buf = torch.zeros((self.n, self.h, self.w, self.c), device=self.buf.device, dtype=self.buf.dtype)
+            self.grad2 = L.View(self._grad2_buf.data_ptr(), self.n, self.h, self.w, self.c, self.c, 0, self.dt)
             return self.grad2
         raise NotImplementedError("more than two consumers of one activation")
 
@@ -269,8 +272,14 @@ class ConvUnit:
             else:
                 out_pw.slope.fill_(1.0)      # none; prelu is refreshed every forward
         self.out_pw = out_pw
+        # bf16 matrix-core kernels for this layer (plan policy: the generator trunk under dtype="bf16"), and bf16
+        # storage of its output when the plan says every consumer reads bf16
+        self.bf16 = bool(getattr(plan, "bf16_unit", lambda n_: False)(name)) and holder.bias is None \
+            and plan.lib.bp_conv_bf16_supported(C.byref(cv), L.PACK_FWD, None, None) == 1 \
+            and plan.lib.bp_conv_bf16_supported(C.byref(cv), L.PACK_BWD, None, None) == 1
+        out_bf16 = self.bf16 and out_slot is None and bool(plan.bf16_out(name)) and c >= 8 and (c & (c - 1)) == 0
         if out_slot is None:
-            self.out = Slot.new(inp.n, ho, wo, c, dev, pw=out_pw)
+            self.out = Slot.new(inp.n, ho, wo, c, dev, pw=out_pw, bf16=out_bf16)
         else:
             if out_slot.shape() != (inp.n, ho, wo, c):
                 raise ValueError(f"{name}: concat slot shape {out_slot.shape()} != {(inp.n, ho, wo, c)}")
@@ -283,12 +292,20 @@ class ConvUnit:
             self.abc = torch.zeros(4 * c, device=dev, dtype=torch.float64)
             self.count = 1.0
         lib = plan.lib
-        n_fwd = lib.bp_conv_packed_floats(C.byref(cv), L.PACK_FWD)
-        n_bwd = lib.bp_conv_packed_floats(C.byref(cv), L.PACK_BWD)
+        if self.bf16:
+            n_fwd = lib.bp_conv_bf16_packed_elems(C.byref(cv), L.PACK_FWD)
+            n_bwd = lib.bp_conv_bf16_packed_elems(C.byref(cv), L.PACK_BWD)
+            pdt = torch.bfloat16
+        else:
+            if inp.dt != L.F32:
+                raise NotImplementedError(f"{name}: an fp32 layer cannot read a bf16 activation")
+            n_fwd = lib.bp_conv_packed_floats(C.byref(cv), L.PACK_FWD)
+            n_bwd = lib.bp_conv_packed_floats(C.byref(cv), L.PACK_BWD)
+            pdt = torch.float32
         if n_fwd <= 0 or n_bwd <= 0:
             raise NotImplementedError(f"{name}: shape not supported by the gfx950 kernels")
-        self.packed_fwd = torch.zeros(n_fwd, device=dev)
-        self.packed_bwd = torch.zeros(n_bwd, device=dev) if need_dgrad else None
+        self.packed_fwd = torch.zeros(n_fwd, device=dev, dtype=pdt)
+        self.packed_bwd = torch.zeros(n_bwd, device=dev, dtype=pdt) if need_dgrad else None
         self._packed_version = None
         self.dx = None
         self.dgrad_slice = None        # (c0, c1): only these input channels need a gradient
@@ -305,14 +322,17 @@ class ConvUnit:
             return
         lib, dev = self.plan.lib, self.plan.device
         sub = L.Conv(cv.transposed, c1 - c0, cv.cout, cv.k, cv.stride, cv.pad, cv.out_pad)
-        n_bwd = lib.bp_conv_packed_floats(C.byref(sub), L.PACK_BWD)
+        if self.bf16:
+            n_bwd = lib.bp_conv_bf16_packed_elems(C.byref(sub), L.PACK_BWD)
+        else:
+            n_bwd = lib.bp_conv_packed_floats(C.byref(sub), L.PACK_BWD)
         if n_bwd <= 0:
             return                      # no kernel for the narrower layer: keep the full data gradient
         w = self.holder.weight
         shape = (c1 - c0, cv.cout, cv.k, cv.k) if cv.transposed else (cv.cout, c1 - c0, cv.k, cv.k)
         self.dgrad_slice = (c0, c1)
         self._sub = {"cv": sub, "w": torch.zeros(shape, device=dev, dtype=w.dtype),
-                     "packed": torch.zeros(n_bwd, device=dev)}
+                     "packed": torch.zeros(n_bwd, device=dev, dtype=torch.bfloat16 if self.bf16 else torch.float32)}
         self.packed_bwd = None
 
     ws_name = "ws"      # which of the plan's workspaces this unit's reductions use (branches that run on
@@ -320,6 +340,9 @@ class ConvUnit:
 
     def _ws(self):
         return getattr(self.plan, self.ws_name)
+
+    def _impl(self, kind):
+        return L.IMPL_BF16 if self.bf16 else self.plan.impl_of(kind, self.name)
 
     def macs(self, kind="forward"):
         """Multiply-accumulates of one forward (= of each of the two gradients; fewer for a data gradient
@@ -338,16 +361,16 @@ class ConvUnit:
         if ver == self._packed_version:
             return
         lib, st = self.plan.lib, _stream()
-        L.check(lib.bp_conv_pack(C.byref(self.cv), L.PACK_FWD, L.ptr(w), L.ptr(self.packed_fwd), st), "pack")
+        pack = lib.bp_conv_bf16_pack if self.bf16 else lib.bp_conv_pack
+        L.check(pack(C.byref(self.cv), L.PACK_FWD, L.ptr(w), L.ptr(self.packed_fwd), st), "pack")
         if self.packed_bwd is not None:
-            L.check(lib.bp_conv_pack(C.byref(self.cv), L.PACK_BWD, L.ptr(w), L.ptr(self.packed_bwd), st), "pack")
+            L.check(pack(C.byref(self.cv), L.PACK_BWD, L.ptr(w), L.ptr(self.packed_bwd), st), "pack")
         if self._sub is not None:
             c0, c1 = self.dgrad_slice
             sub = self._sub
             with torch.no_grad():
                 sub["w"].copy_(w[c0:c1] if self.cv.transposed else w[:, c0:c1])
-            L.check(lib.bp_conv_pack(C.byref(sub["cv"]), L.PACK_BWD, L.ptr(sub["w"]), L.ptr(sub["packed"]), st),
-                    "pack")
+            L.check(pack(C.byref(sub["cv"]), L.PACK_BWD, L.ptr(sub["w"]), L.ptr(sub["packed"]), st), "pack")
         self._packed_version = ver
 
     # ---- forward
@@ -373,7 +396,7 @@ class ConvUnit:
         t0 = plan.prof_begin()
         L.check(lib.bp_conv_forward(C.byref(self.cv), C.byref(self.inp.view), self.inp.pw_struct(),
                                     L.ptr(self.packed_fwd), L.ptr(hold.weight), L.ptr(hold.bias),
-                                    C.byref(self.out.view), plan.impl_of("fwd", self.name), st),
+                                    C.byref(self.out.view), self._impl("fwd"), st),
                 f"{self.name} forward")
         plan.prof_end(t0, self, "forward")
         c = self.cv.cout
@@ -411,7 +434,8 @@ class ConvUnit:
         if self.dx is not None and self._sub is not None:
             c0, c1 = self.dgrad_slice
             full = self.dx
-            self._sub["dx"] = L.View(full.ptr, full.n, full.h, full.w, c1 - c0, full.cstride, full.coff + c0)
+            self._sub["dx"] = L.View(full.ptr, full.n, full.h, full.w, c1 - c0, full.cstride, full.coff + c0,
+                                     full.dtype)
 
     def backward(self, grads):
         """``out.grad`` (+``out.grad2``) hold d/d(activated out).  Writes parameter gradients into
@@ -482,7 +506,7 @@ class ConvUnit:
             t0 = plan.prof_begin()
             L.check(lib.bp_conv_backward_weight(C.byref(self.cv), C.byref(self.inp.view), self.inp.pw_struct(),
                                                 C.byref(g), L.ptr(grads[id(hold.weight)]), L.ptr(dbias),
-                                                L.ptr(ws), plan.ws_bytes, plan.impl_of("wgrad"), _stream()),
+                                                L.ptr(ws), plan.ws_bytes, self._impl("wgrad"), _stream()),
                     f"{self.name} backward_weight")
             plan.prof_end(t0, self, "backward_weight")
 
@@ -499,11 +523,11 @@ class ConvUnit:
             if self._sub is not None:
                 sub = self._sub
                 L.check(lib.bp_conv_backward_data(C.byref(sub["cv"]), C.byref(g), L.ptr(sub["packed"]),
-                                                  L.ptr(sub["w"]), C.byref(sub["dx"]), plan.impl_of("dgrad"), st),
+                                                  L.ptr(sub["w"]), C.byref(sub["dx"]), self._impl("dgrad"), st),
                         f"{self.name} backward_data (channels {self.dgrad_slice})")
             else:
                 L.check(lib.bp_conv_backward_data(C.byref(self.cv), C.byref(g), L.ptr(self.packed_bwd),
-                                                  L.ptr(hold.weight), C.byref(self.dx), plan.impl_of("dgrad"), st),
+                                                  L.ptr(hold.weight), C.byref(self.dx), self._impl("dgrad"), st),
                         f"{self.name} backward_data")
             plan.prof_end(t0, self, "backward_data")
 
@@ -522,7 +546,10 @@ class PackBatch:
         lib, dev = self.plan.lib, self.plan.device
         nb = lib.bp_conv_pack_job_bytes()
         recs, counts, self.rest = [], [], []
+        self.own = [u for u in self.units if u.bf16]            # (bf16 images: the layer's own pack launches)
         for u in self.units:
+            if u.bf16:
+                continue
             jobs = [(u.cv, L.PACK_FWD, u.holder.weight, u.packed_fwd)]
             if u.packed_bwd is not None:
                 jobs.append((u.cv, L.PACK_BWD, u.holder.weight, u.packed_bwd))
@@ -550,8 +577,11 @@ class PackBatch:
         if storage != self._storage:
             self._build()
             self._storage = storage
+        for u in self.own:
+            u._packed_version = None
+            u.maybe_pack()
         for u in self.units:
-            if u._sub is not None:
+            if u._sub is not None and not u.bf16:
                 c0, c1 = u.dgrad_slice
                 w = u.holder.weight
                 with torch.no_grad():
@@ -576,7 +606,9 @@ class ResidualUnit:
         last = body_units[-1].out
         if last.shape() != inp.shape():
             raise ValueError(f"{name}: residual branch changes the shape")
-        self.out = Slot.new(inp.n, inp.h, inp.w, inp.c, plan.device, pw=None)
+        if last.dt != inp.dt:
+            raise NotImplementedError(f"{name}: residual branch and skip differ in element type")
+        self.out = Slot.new(inp.n, inp.h, inp.w, inp.c, plan.device, pw=None, bf16=inp.dt == L.BF16)
         lp = last.pw if last.pw is not None else PW.identity(inp.c, plan.device)
         # mask pointwise of the tail: the branch's affine, the tail's slope
         self.tail_pw = PW(lp.scale, lp.shift, torch.full((inp.c,), float(self.slope), device=plan.device))

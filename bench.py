@@ -139,6 +139,9 @@ def main():
     ap.add_argument("--layers", action="store_true", help="also print a per-layer table to stderr")
     ap.add_argument("--no-paint", action="store_true", help="skip the paint() throughput leg")
     ap.add_argument("--torch-adam", action="store_true", help="torch.optim.Adam instead of the fused FlatAdam")
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
+                    help="f32: the reference's arithmetic (configs[1], the headline); bf16: bf16 activations / gradients "
+                         "in the generator trunk, fp32 accumulation, master weights and statistics (configs[3])")
     ap.add_argument("--workload", choices=["cvae", "cgan"], default="cvae",
                     help="cvae: BASELINE.json configs[1] (the headline); cgan: configs[2] (alternating D/G step)")
     args = ap.parse_args()
@@ -177,7 +180,7 @@ def main():
     torch.manual_seed(1234)                      # same initial weights on every rank
     import contextlib
     with contextlib.redirect_stdout(sys.stderr):     # the model announces itself like the reference does
-        model = CVAE(arch, dev, sync=sync)
+        model = CVAE(arch, dev, sync=sync, dtype=args.dtype)
     from baryon_painter_amd.optim import FlatAdam
     opt = FlatAdam(model, lr=1e-3) if not args.torch_adam else torch.optim.Adam(model.parameters(), lr=1e-3)
     n = args.batch

@@ -10,7 +10,9 @@ from baryon_painter_amd.utils import synthetic as syn
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("size,n_res,n,gtol", [(64, 2, 2, 2e-3), (512, 9, 2, 5e-3)])
+# gtol at 512^2: two fp32 executions of one graph differ by up to ~1e-2 in single gradients at this size (LeakyReLU /
+# batch-norm cancellation; measured for the CVAE against its float64 truth, tests/golden grad_variant_dist)
+@pytest.mark.parametrize("size,n_res,n,gtol", [(64, 2, 2, 2e-3), (512, 9, 2, 2e-2)])
 def test_cgan_iteration_matches_torch_restatement(size, n_res, n, gtol):
     """(64, 2 blocks): quick case.  (512, 9 blocks): the fiducial CGAN of BASELINE.json configs[2] at its real
     geometry -- the k9 stem / head at 512^2, nine residual blocks at 128^2, the 256- and 512-channel PatchGAN
