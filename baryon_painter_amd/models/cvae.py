@@ -222,12 +222,12 @@ class _Plan:
         e.record()
         return e
 
-    def prof_end(self, e0, unit, kind):
+    def prof_end(self, e0, unit, kind, nstreams=1):
         if e0 is None:
             return
         e1 = torch.cuda.Event(enable_timing=True)
         e1.record()
-        self.prof.append((e0, e1, unit, kind))
+        self.prof.append((e0, e1, unit, kind, nstreams))
 
     @staticmethod
     def _no_trailing(tr, where):

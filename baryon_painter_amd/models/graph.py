@@ -354,6 +354,20 @@ class ConvUnit:
             cin = self.dgrad_slice[1] - self.dgrad_slice[0]
         return dense.n * dense.h * dense.w * cv.k * cv.k * cin * cv.cout
 
+    def algorithmic_bytes(self, kind, nstreams=1):
+        """HBM bytes one launch of this layer's kernel has to move (SURVEY.md 8d convention: every tensor it reads
+        or writes exactly once; weights are negligible)."""
+        def nbytes(slot, c=None):
+            return slot.n * slot.h * slot.w * (slot.c if c is None else c) * (2 if slot.dt == L.BF16 else 4)
+        if kind == "forward":
+            return nbytes(self.inp) + nbytes(self.out)
+        if kind == "backward_weight":
+            return nbytes(self.inp) + nbytes(self.out)
+        if kind == "backward_data":
+            c = None if self.dgrad_slice is None else self.dgrad_slice[1] - self.dgrad_slice[0]
+            return nbytes(self.out) + nbytes(self.inp, c)
+        return nstreams * nbytes(self.out)          # streaming passes over tensors of the output's shape
+
     # ---- weights
     def maybe_pack(self):
         w = self.holder.weight
@@ -406,8 +420,10 @@ class ConvUnit:
         if bn is None:
             return
         if training:
+            t0 = plan.prof_begin()
             L.check(lib.bp_channel_sums(C.byref(self.out.view), L.ptr(self.sums), L.ptr(self._ws()), plan.ws_bytes,
                                         st), f"{self.name} bn stats")
+            plan.prof_end(t0, self, "bn_stats")
             count = float(self.out.n * self.out.h * self.out.w)
             if plan.sync is not None and plan.sync.sync_bn:
                 yield self.sums[:2 * c]
@@ -465,9 +481,12 @@ class ConvUnit:
             raise ValueError("without batch-norm g IS the result: it must be stored")
         aout = None if act_out is None else C.byref(act_out)
         d2 = None if dout2 is None else C.byref(dout2)
+        nstreams = 2 + (dout2 is not None) + (act_out is not None)       # tensors this pass and the apply pass read
+        t0 = plan.prof_begin()
         L.check(lib.bp_act_backward(C.byref(dout), d2, C.byref(self.out.view), pw, aout,
                                     None if g_out is None else C.byref(g_out), L.ptr(self.sums), L.ptr(self._ws()),
                                     plan.ws_bytes, st), f"{self.name} act backward")
+        plan.prof_end(t0, self, "act_backward", nstreams + (g_out is not None))
         if self.act == "prelu":
             L.check(lib.bp_prelu_slope_grad(L.ptr(self.sums), c, L.ptr(grads[id(self.act_holder.weight)]), st),
                     f"{self.name} prelu grad")
@@ -480,13 +499,16 @@ class ConvUnit:
                                                 L.ptr(self.save_mean), L.ptr(self.save_invstd), pscale,
                                                 L.ptr(grads[id(bn.weight)]), L.ptr(grads[id(bn.bias)]),
                                                 L.ptr(self.abc), st), f"{self.name} bn backward")
+            t0 = plan.prof_begin()
             if g_out is None:
                 L.check(lib.bp_act_bn_backward_apply(C.byref(dout), d2, C.byref(self.out.view), pw, aout,
                                                      L.ptr(self.abc), C.byref(d_raw_out), st),
                         f"{self.name} act+bn backward apply")
+                plan.prof_end(t0, self, "bn_apply", nstreams + 1)
             else:
                 L.check(lib.bp_bn_backward_apply(C.byref(g_out), C.byref(self.out.view), L.ptr(self.abc),
                                                  C.byref(d_raw_out), st), f"{self.name} bn backward apply")
+                plan.prof_end(t0, self, "bn_apply", 3)
             return True
         return False
 
@@ -617,9 +639,11 @@ class ResidualUnit:
         for u in self.body:
             u.forward(training)
         last = self.body[-1].out
+        t0 = self.plan.prof_begin()
         L.check(self.plan.lib.bp_residual_forward(C.byref(last.view), last.pw_struct(), C.byref(self.inp.view),
                                                   self.inp.pw_struct(), float(self.slope),
                                                   C.byref(self.out.view), _stream()), f"{self.name} tail")
+        self.plan.prof_end(t0, self.body[-1], "residual", 3)
 
     def prepare_backward(self):
         self.out.ensure_grad()

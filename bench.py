@@ -26,13 +26,35 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_* dense peak
+PEAK_HBM_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E peak (spec); ~6.3 TB/s is what a streaming copy reaches
 TILE = 512
 BATCH_PER_GPU = 64
+
+
+def source_hash():
+    """Hash of the kernel sources: stamps profiles/pmc_traffic.json (tools/pmc_to_json.py) so that counter-derived
+    traffic figures are only quoted for the kernels they were measured on (the GPU box has no .git to ask)."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "baryon_painter_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".hpp")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def kernel_name(kind, unit, lib):
     import ctypes as C
     from baryon_painter_amd import _lib as L
+    if kind in ("bn_stats", "act_backward", "bn_apply", "residual"):
+        return {"bn_stats": "channel_sums", "act_backward": "act_backward", "bn_apply": "bn_backward_apply",
+                "residual": "residual_forward"}[kind] + ("_bf16_kernel" if unit.out.dt == L.BF16 else "_fast_kernel")
+    if getattr(unit, "bf16", False):
+        cv = unit.cv
+        tag = "%s%d->%d k%ds%d" % ("T" if cv.transposed else "C", cv.cin, cv.cout, cv.k, cv.stride)
+        return ("wgrad_bf16_kernel[%s]" if kind == "backward_weight" else
+                "igemm_bf16_kernel[%s fwd]" if kind == "forward" else "igemm_bf16_kernel[%s dgrad]") % tag
     if kind == "backward_weight":
         cv = unit.cv
         cx, cy = (cv.cout, cv.cin) if cv.transposed else (cv.cin, cv.cout)
@@ -62,33 +84,56 @@ def host_cores():
     return n
 
 
-def cpu_baseline(arch, seconds_budget=20.0):
-    """Reference arithmetic on the host: torch.nn.functional graph + autograd + torch Adam."""
+def cpu_baseline(seconds_budget=30.0):
+    """Reference arithmetic on the host cores (oracle/torch_ref.py: the reference's torch.nn.functional graph +
+    autograd + torch Adam).  SURVEY.md 8d: BASELINE.json configs[0] exactly -- batch 4 of 256x256 tiles, 10 warm-up
+    + 50 timed train steps, median -- plus, as secondary figures on what is left of the time budget, batch 4 at
+    512x512 and paint (sample_P) of one 512x512 tile."""
+    from baryon_painter_amd.models import arch as A
     from baryon_painter_amd.utils import synthetic as syn
     from oracle.cvae_oracle import CVAEOracle
     from oracle.torch_ref import TorchRefCVAE
-    n = 4
     torch.set_num_threads(host_cores())
-    shapes = CVAEOracle(arch).param_shapes()
-    m = TorchRefCVAE(arch, syn.fill_params(shapes, 7))
-    opt = torch.optim.Adam(m.parameters(), lr=1e-3)
-    x, y, aux = syn.synthetic_batch(n, TILE, TILE, seed=5)
-    eps = syn.synthetic_eps((1, n, *arch["dim_z"]), seed=6)
-    times = []
-    t_start = time.time()
-    for it in range(12):
-        t0 = time.time()
-        elbo = m.forward(x, y, aux, eps)
-        opt.zero_grad()
-        (-elbo).backward()
-        opt.step()
-        times.append(time.time() - t0)
-        if it >= 3 and time.time() - t_start > seconds_budget:
-            break
-    med = float(np.median(times[1:]))
-    return {"value": n / med, "unit": "tiles/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{len(times) - 1} timed train steps (fwd+bwd+Adam) of batch {n} x {TILE}x{TILE}, fp32, "
-                      f"oracle/torch_ref.py (torch.nn.functional on CPU), median {med:.3f} s/step"}
+    t_begin = time.time()
+
+    def train_steps(tile, n, warm, timed, budget):
+        arch = A.fiducial_architecture(tile)
+        m = TorchRefCVAE(arch, syn.fill_params(CVAEOracle(arch).param_shapes(), 7))
+        opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+        x, y, aux = syn.synthetic_batch(n, tile, tile, seed=5)
+        eps = syn.synthetic_eps((1, n, *arch["dim_z"]), seed=6)
+        times, t0 = [], time.time()
+        for it in range(warm + timed):
+            t1 = time.time()
+            elbo = m.forward(x, y, aux, eps)
+            opt.zero_grad()
+            (-elbo).backward()
+            opt.step()
+            if it >= warm:
+                times.append(time.time() - t1)
+            if len(times) >= 3 and time.time() - t0 > budget:
+                break
+        return m, arch, float(np.median(times)), len(times)
+
+    _, _, med256, k256 = train_steps(256, 4, 10, 50, seconds_budget * 0.6)
+    left = max(4.0, seconds_budget - (time.time() - t_begin))
+    m, arch, med512, k512 = train_steps(512, 4, 1, 6, left * 0.8)
+    m.training = False
+    x, y, aux = syn.synthetic_batch(1, 512, 512, seed=7)
+    z = syn.synthetic_eps((1, *arch["dim_z"]), seed=8)
+    tp = []
+    for _ in range(6):
+        t1 = time.time()
+        m.sample_P(y, aux, z=z)
+        tp.append(time.time() - t1)
+    medp = float(np.median(tp[1:]))
+    return {"value": 4 / med256, "unit": "tiles/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"BASELINE.json configs[0]: {k256} timed train steps (fwd+bwd+Adam, after 10 warm-up) of batch 4 x "
+                      f"256x256, fp32, oracle/torch_ref.py (torch.nn.functional on CPU), median {med256:.3f} s/step",
+            "train_512_tiles_per_sec": 4 / med512,
+            "train_512_sample": f"{k512} timed steps of batch 4 x 512x512, median {med512:.3f} s/step",
+            "paint_512_tiles_per_sec": 1 / medp,
+            "paint_512_sample": f"5 timed sample_P of one 512x512 tile (eval mode), median {medp * 1e3:.1f} ms"}
 
 
 def bench_cgan(args, dev, world, rank):
@@ -260,47 +305,75 @@ def main():
     if rank == 0:
         # ---- roofline of the dominant kernel
         per = {}
-        for e0, e1, unit, kind in prof_events:
+        for e0, e1, unit, kind, nstreams in prof_events:
             name = kernel_name(kind, unit, model._lib)
-            d = per.setdefault(name, {"ms": 0.0, "launches": 0, "flop": 0.0})
+            d = per.setdefault(name, {"ms": 0.0, "launches": 0, "flop": 0.0, "bytes": 0.0})
             d["ms"] += e0.elapsed_time(e1)
             d["launches"] += 1
-            d["flop"] += 2.0 * unit.macs(kind)
+            if kind in ("forward", "backward_data", "backward_weight"):
+                d["flop"] += 2.0 * unit.macs(kind)
+            d["bytes"] += unit.algorithmic_bytes(kind, nstreams)
         if args.layers:
             lay = {}
-            for e0, e1, unit, kind in prof_events:
-                d = lay.setdefault((unit.name, kind), [0.0, 2.0 * unit.macs(kind), kernel_name(kind, unit, model._lib)])
+            for e0, e1, unit, kind, nstreams in prof_events:
+                fl = 2.0 * unit.macs(kind) if kind in ("forward", "backward_data", "backward_weight") else 0.0
+                d = lay.setdefault((unit.name, kind), [0.0, fl, unit.algorithmic_bytes(kind, nstreams),
+                                                       kernel_name(kind, unit, model._lib)])
                 d[0] += e0.elapsed_time(e1) / PROF_STEPS
-            for (name, kind), (ms, fl, kn) in sorted(lay.items(), key=lambda kv: -kv[1][0]):
-                print(f"{name:28s} {kind:16s} {ms:8.3f} ms  {fl / ms / 1e9:7.2f} TF/s  {kn}", file=sys.stderr)
-        dom = max(per, key=lambda k: per[k]["ms"])
+            for (name, kind), (ms, fl, by, kn) in sorted(lay.items(), key=lambda kv: -kv[1][0]):
+                print(f"{name:28s} {kind:16s} {ms:8.3f} ms  {fl / ms / 1e9:7.2f} TF/s  {by / ms / 1e6:8.1f} GB/s  {kn}",
+                      file=sys.stderr)
+        conv = {k: v for k, v in per.items() if v["flop"] > 0}
+        # fp32: the step is matrix-core bound (AI ~100 FLOP/B vs a ridge of 20): dominant = the convolution kernel with
+        # the most time, priced in TFLOP/s.  bf16: HBM-bound (ridge 310 FLOP/B): dominant = whichever kernel takes the
+        # most time, priced in algorithmic bytes per second.
+        hbm = args.dtype == "bf16"
+        pool = per if hbm else conv
+        dom = max(pool, key=lambda k: pool[k]["ms"])
         d = per[dom]
-        achieved = d["flop"] / (d["ms"] * 1e-3) / 1e12
-        conv_ms = sum(v["ms"] for v in per.values()) / PROF_STEPS
+        conv_ms = sum(v["ms"] for v in conv.values()) / PROF_STEPS
         traffic = None
-        try:       # HBM bytes per launch from the PMC passes (rocprofv3 cannot run inside bench.py)
-            traffic = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["hbm_bytes_per_launch"].get(dom)
+        try:       # HBM bytes per launch from the PMC passes (rocprofv3 cannot run inside bench.py); only quoted when
+            #        the stamp says the counters were collected on these very kernel sources
+            pj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+            if pj.get("source_hash") == source_hash():
+                traffic = pj["hbm_bytes_per_launch"].get(dom)
         except Exception:
             pass
-        roofline = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
-                    "avg_launch_ms": round(d["ms"] / d["launches"], 4),
-                    "flop_per_launch": d["flop"] / d["launches"], "launches_per_step": d["launches"] // PROF_STEPS,
-                    "share_of_step": round(d["ms"] / PROF_STEPS / (dt / args.steps * 1e3), 3),
-                    "measured_on": f"{PROF_STEPS} steps of the serial schedule (BP_SIDE_WGRAD=0 equivalent) run right after "
-                                   "the timed region; in the timed region weight gradients overlap the rest of the "
-                                   "backward pass on a second stream, so per-launch times there are not kernel times",
-                    "all_conv_kernels_ms_per_step": round(conv_ms, 2),
-                    "per_kernel": {k: {"ms_per_step": round(v["ms"] / PROF_STEPS, 3),
-                                       "tflops": round(v["flop"] / (v["ms"] * 1e-3) / 1e12, 2)}
-                                   for k, v in sorted(per.items(), key=lambda kv: -kv[1]["ms"])}}
+        if hbm:
+            achieved = d["bytes"] / (d["ms"] * 1e-3) / 1e9
+            roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                        "frac": round(achieved / PEAK_HBM_GBS, 4), "traffic": traffic,
+                        "algorithmic_bytes_per_launch": d["bytes"] / d["launches"]}
+        else:
+            achieved = d["flop"] / (d["ms"] * 1e-3) / 1e12
+            roofline = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
+                        "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
+                        "flop_per_launch": d["flop"] / d["launches"]}
+        all_bytes = sum(v["bytes"] for v in per.values()) / PROF_STEPS
+        roofline.update({
+            "avg_launch_ms": round(d["ms"] / d["launches"], 4), "launches_per_step": d["launches"] // PROF_STEPS,
+            "share_of_step": round(d["ms"] / PROF_STEPS / (dt / args.steps * 1e3), 3),
+            "measured_on": f"{PROF_STEPS} steps of the serial schedule (BP_SIDE_WGRAD=0 equivalent) run right after "
+                           "the timed region; in the timed region weight gradients overlap the rest of the "
+                           "backward pass on a second stream, so per-launch times there are not kernel times",
+            "all_conv_kernels_ms_per_step": round(conv_ms, 2),
+            "whole_step": {"tflops": round(n * 61.4e9 * (args.tile / 512) ** 2 / (dt / args.steps) / 1e12, 1),
+                           "algorithmic_GBs_timed_kernels": round(all_bytes / (dt / args.steps) / 1e9, 1)},
+            "per_kernel": {k: {"ms_per_step": round(v["ms"] / PROF_STEPS, 3),
+                               "tflops": round(v["flop"] / (v["ms"] * 1e-3) / 1e12, 2),
+                               "GBs": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1)}
+                           for k, v in sorted(per.items(), key=lambda kv: -kv[1]["ms"])}})
         out = {
             "metric": "cvae_train_tiles_per_sec", "value": round(world * n * args.steps / dt, 2), "unit": "tiles/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"CVAE fiducial train step (fwd+bwd+Adam), batch {n}/GPU of "
-                                   f"{args.tile}x{args.tile} tiles, fp32 (BASELINE.json configs[1])",
+                                   f"{args.tile}x{args.tile} tiles, " + (
+                                       "fp32 (BASELINE.json configs[1])" if args.dtype == "f32" else
+                                       "bf16 activations/gradients in the generator trunk, fp32 accumulation, master "
+                                       "weights and statistics (BASELINE.json configs[3] per GPU)"),
                        "tile": args.tile, "batch_per_gpu": n, "global_batch": n * world,
                        "parallelism": f"dp{world}", "batch_norm": "local" if args.local_bn or world == 1 and False
                        else ("global (all-reduced statistics)" if world > 1 else "single device"),
@@ -312,7 +385,7 @@ def main():
         }
         out["paint"] = paint_leg
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(arch)
+            out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()
