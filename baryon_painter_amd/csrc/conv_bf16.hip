@@ -104,6 +104,71 @@ __device__ __forceinline__ bf8 lds_frag(const u16* p) {
   }
 }
 
+// Epilogue of one workgroup tile: D[row = 4*kq + r][col = lm] of N tile nt = produced channel (see b_channel_of) of
+// pixel lm.  Channel order inside a COB block (set by the packing): tile pair (2t, 2t+1), rows 4*kq..4*kq+3 of the
+// even tile then of the odd tile = channels 32*t + 8*kq .. + 7, i.e. one 16-byte bf16 store per lane and pair.
+template <int NT, int MT, bool OUT_BF16>
+__device__ __forceinline__ void b_store_tile(const BArgs& a, const v4f (&acc)[MT][NT], int n, int py, int px, int qy0,
+                                             int qx0, int qh, int qw, int co0, int wm, int wn, int lm, int kq) {
+  const int64_t out_img = (int64_t)n * a.out_h * a.out_w * a.out_cs + a.out_co;
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int t = wm * MT + mt;
+    const int tr = t / a.TPR, tc = t % a.TPR;
+    const int qy = qy0 + tr, qx = qx0 + tc * 16 + lm;
+    if (qy >= qh || qx >= qw) continue;
+    const int Y = py + a.OS * qy, X = px + a.OS * qx;
+    const int64_t o = out_img + ((int64_t)Y * a.out_w + X) * a.out_cs;
+    if constexpr (NT == 1) {
+      const int j0 = co0 + wn * 16 + kq * 4;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = acc[mt][0][r] + ((a.bias && j0 + r < a.cout) ? a.bias[j0 + r] : 0.f);
+      if constexpr (OUT_BF16) {
+        u16* q = reinterpret_cast<u16*>(a.out) + o + j0;
+        if (j0 + 3 < a.cout) *reinterpret_cast<uint2*>(q) = make_uint2(pack2(v[0], v[1]), pack2(v[2], v[3]));
+        else
+#pragma unroll
+          for (int r = 0; r < 4; ++r) if (j0 + r < a.cout) q[r] = f2bf(v[r]);
+      } else {
+        float* q = reinterpret_cast<float*>(a.out) + o + j0;
+        if (j0 + 3 < a.cout && (a.out_cs & 3) == 0 && (a.out_co & 3) == 0) *reinterpret_cast<float4*>(q) = make_float4(v[0], v[1], v[2], v[3]);
+        else
+#pragma unroll
+          for (int r = 0; r < 4; ++r) if (j0 + r < a.cout) q[r] = v[r];
+      }
+    } else {
+#pragma unroll
+      for (int np = 0; np < NT / 2; ++np) {
+        const int j0 = co0 + (wn * NT / 2 + np) * 32 + kq * 8;
+        float v[8];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { v[r] = acc[mt][2 * np][r]; v[4 + r] = acc[mt][2 * np + 1][r]; }
+        if (a.bias) {
+#pragma unroll
+          for (int r = 0; r < 8; ++r) if (j0 + r < a.cout) v[r] += a.bias[j0 + r];
+        }
+        if (j0 >= a.cout) continue;
+        if constexpr (OUT_BF16) {
+          u16* q = reinterpret_cast<u16*>(a.out) + o + j0;
+          if (j0 + 7 < a.cout) *reinterpret_cast<uint4*>(q) = make_uint4(pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7]));
+          else
+#pragma unroll
+            for (int r = 0; r < 8; ++r) if (j0 + r < a.cout) q[r] = f2bf(v[r]);
+        } else {
+          float* q = reinterpret_cast<float*>(a.out) + o + j0;
+          if (j0 + 7 < a.cout && (a.out_cs & 3) == 0 && (a.out_co & 3) == 0) {
+            *reinterpret_cast<float4*>(q) = make_float4(v[0], v[1], v[2], v[3]);
+            *reinterpret_cast<float4*>(q + 4) = make_float4(v[4], v[5], v[6], v[7]);
+          } else
+#pragma unroll
+            for (int r = 0; r < 8; ++r) if (j0 + r < a.cout) q[r] = v[r];
+        }
+      }
+    }
+  }
+}
+
 template <int CC, int NT, int WN, int MT, int SLOTS, bool IN_BF16, bool OUT_BF16>
 __global__ __launch_bounds__(256, 2) void igemm_bf16_kernel(BArgs a) {
   constexpr int U = CC < 8 ? CC : 8;            // channels per staging unit
@@ -248,65 +313,182 @@ __global__ __launch_bounds__(256, 2) void igemm_bf16_kernel(BArgs a) {
     }
   }
 
-  // ---- epilogue: D[row = 4*kq + r][col = lm] of N tile nt = produced channel row_to_channel(nt, 4*kq + r) of pixel lm.
-  // Channel order inside a COB block (set by the packing): tile pair (2t, 2t+1), rows 4*kq..4*kq+3 of the even
-  // tile then of the odd tile = channels 32*t + 8*kq .. + 7.
-  const int64_t out_img = (int64_t)n * a.out_h * a.out_w * a.out_cs + a.out_co;
+  b_store_tile<NT, MT, OUT_BF16>(a, acc, n, py, px, qy0, qx0, qh, qw, co0, wm, wn, lm, kq);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Persistent form for layers with ONE channel chunk (cin <= 32) whose whole weight image fits in LDS -- the
+// full-resolution few-channel layers, where a 256-pixel tile is only a few hundred MFMA cycles of work and the
+// per-tap-row weight staging (two barriers per row) of the kernel above is most of the time:
+//   * the weights of all tap rows are staged ONCE per workgroup (per phase and channel block);
+//   * a workgroup walks a contiguous range of (image, tile) pairs (neighbouring tiles share halo rows / columns:
+//     they meet in one XCD's L2) with the NEXT tile's halo in flight in registers while the current one is
+//     multiplied: two barriers per tile, no exposed global latency.
+struct BPArgs {
+  BArgs b;
+  int ntiles_total;     // images x tiles
+  int per_block;        // tiles per workgroup (contiguous)
+};
+
+template <int CC, int NT, int WN, int MT, int SLOTS, bool IN_BF16, bool OUT_BF16>
+__global__ __launch_bounds__(256, 2) void igemm_bf16_p_kernel(BPArgs pa) {
+  const BArgs& a = pa.b;
+  constexpr int U = CC < 8 ? CC : 8;
+  constexpr int UPP = CC / U;
+  constexpr int WM = 4 / WN;
+  constexpr int COB = 16 * NT * WN;
+  extern __shared__ __attribute__((aligned(16))) u16 smem[];
+  u16* lds_in = smem;
+  const int in_elems = a.IH * a.ISx * a.IWq * CC;
+  u16* lds_w = smem + ((in_elems + 7) & ~7);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int lm = lane & 15, kq = lane >> 4;
+  (void)WM;
+
+  const int ph = blockIdx.y;
+  const int py = ph / a.nphase, px = ph % a.nphase;
+  const int co0 = blockIdx.z * COB;
+  const int t_begin = blockIdx.x * pa.per_block;
+  int t_end = t_begin + pa.per_block;
+  if (t_end > pa.ntiles_total) t_end = pa.ntiles_total;
+  if (t_begin >= t_end) return;          // uniform per block
+  const int tiles_per_img = a.tiles_x * a.tiles_y;
+  const int qh = (a.out_h - py + a.OS - 1) / a.OS;
+  const int qw = (a.out_w - px + a.OS - 1) / a.OS;
+
+  int iy0, ix0;
+  if (a.transposed) {
+    iy0 = bp_t_i0(py, a.pad, a.stride, a.tapsy);
+    ix0 = bp_t_i0(px, a.pad, a.stride, a.tapsy);
+  } else {
+    iy0 = -a.pad; ix0 = -a.pad;
+  }
+
+  int abase[MT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     const int t = wm * MT + mt;
     const int tr = t / a.TPR, tc = t % a.TPR;
-    const int qy = qy0 + tr, qx = qx0 + tc * 16 + lm;
-    if (qy >= qh || qx >= qw) continue;
-    const int Y = py + a.OS * qy, X = px + a.OS * qx;
-    const int64_t o = out_img + ((int64_t)Y * a.out_w + X) * a.out_cs;
-    if constexpr (NT == 1) {
-      const int j0 = co0 + wn * 16 + kq * 4;
-      float v[4];
+    abase[mt] = (tr * a.ISy * a.ISx * a.IWq + tc * 16 + lm) * CC + kq * 8;
+  }
+  int bbase[NT];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] = acc[mt][0][r] + ((a.bias && j0 + r < a.cout) ? a.bias[j0 + r] : 0.f);
-      if constexpr (OUT_BF16) {
-        u16* q = reinterpret_cast<u16*>(a.out) + o + j0;
-        if (j0 + 3 < a.cout) *reinterpret_cast<uint2*>(q) = make_uint2(pack2(v[0], v[1]), pack2(v[2], v[3]));
-        else
+  for (int nt = 0; nt < NT; ++nt) bbase[nt] = ((wn * NT + nt) * 16 + lm) * 32 + kq * 8;
+
+  // this thread's staging units: (row, column) inside the halo image are the same for every tile
+  const int E = a.IH * a.ISx * a.IWq * UPP;
+  const int cu = tid % UPP;
+  int s_r[SLOTS], s_c[SLOTS];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) if (j0 + r < a.cout) q[r] = f2bf(v[r]);
-      } else {
-        float* q = reinterpret_cast<float*>(a.out) + o + j0;
-        if (j0 + 3 < a.cout && (a.out_cs & 3) == 0 && (a.out_co & 3) == 0) *reinterpret_cast<float4*>(q) = make_float4(v[0], v[1], v[2], v[3]);
-        else
+  for (int i = 0; i < SLOTS; ++i) {
+    const int e = tid + i * 256;
+    s_r[i] = -1; s_c[i] = 0;
+    if (e < E) {
+      const int pi = e / UPP;
+      const int xq = pi % a.IWq;
+      const int t = pi / a.IWq;
+      s_r[i] = t / a.ISx;
+      s_c[i] = xq * a.ISx + t % a.ISx;
+    }
+  }
+  // pending activation of this thread's channel group
+  float sc[U], sf[U], sl[U];
+  const bool on = a.pw.scale != nullptr;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) if (j0 + r < a.cout) q[r] = v[r];
-      }
-    } else {
+  for (int j = 0; j < U; ++j) {
+    const bool ok = on && cu * U + j < a.cin;
+    sc[j] = ok ? a.pw.scale[cu * U + j] : 1.f;
+    sf[j] = ok ? a.pw.shift[cu * U + j] : 0.f;
+    sl[j] = ok ? a.pw.slope[cu * U + j] : 1.f;
+  }
+
+  float stage[SLOTS][U];
+  unsigned inside = 0;
+  auto tile_coords = [&](int t, int* n, int* qy0, int* qx0) {
+    *n = t / tiles_per_img;
+    const int r = t - *n * tiles_per_img;
+    *qy0 = (r / a.tiles_x) * a.BH;
+    *qx0 = (r % a.tiles_x) * 16 * a.TPR;
+  };
+  auto load_tile = [&](int t) {
+    int n, qy0, qx0;
+    tile_coords(t, &n, &qy0, &qx0);
+    const int gy0 = a.ISy * qy0 + iy0, gx0 = a.ISx * qx0 + ix0;
+    const int64_t img = (int64_t)n * a.in_h * a.in_w * a.in_cs + a.in_co + cu * U;
+    inside = 0;
 #pragma unroll
-      for (int np = 0; np < NT / 2; ++np) {
-        const int j0 = co0 + (wn * NT / 2 + np) * 32 + kq * 8;
-        float v[8];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { v[r] = acc[mt][2 * np][r]; v[4 + r] = acc[mt][2 * np + 1][r]; }
-        if (a.bias) {
-#pragma unroll
-          for (int r = 0; r < 8; ++r) if (j0 + r < a.cout) v[r] += a.bias[j0 + r];
-        }
-        if (j0 >= a.cout) continue;
-        if constexpr (OUT_BF16) {
-          u16* q = reinterpret_cast<u16*>(a.out) + o + j0;
-          if (j0 + 7 < a.cout) *reinterpret_cast<uint4*>(q) = make_uint4(pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7]));
-          else
-#pragma unroll
-            for (int r = 0; r < 8; ++r) if (j0 + r < a.cout) q[r] = f2bf(v[r]);
-        } else {
-          float* q = reinterpret_cast<float*>(a.out) + o + j0;
-          if (j0 + 7 < a.cout && (a.out_cs & 3) == 0 && (a.out_co & 3) == 0) {
-            *reinterpret_cast<float4*>(q) = make_float4(v[0], v[1], v[2], v[3]);
-            *reinterpret_cast<float4*>(q + 4) = make_float4(v[4], v[5], v[6], v[7]);
-          } else
-#pragma unroll
-            for (int r = 0; r < 8; ++r) if (j0 + r < a.cout) q[r] = v[r];
-        }
+    for (int i = 0; i < SLOTS; ++i) {
+      const int iy = gy0 + s_r[i], ix = gx0 + s_c[i];
+      if (s_r[i] >= 0 && iy >= 0 && iy < a.in_h && ix >= 0 && ix < a.in_w) {
+        inside |= 1u << i;
+        load_unit<U, IN_BF16>(a.in, img + ((int64_t)iy * a.in_w + ix) * a.in_cs, stage[i]);
       }
     }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int i = 0; i < SLOTS; ++i) {
+      if (s_r[i] < 0) continue;
+      float v[U];
+#pragma unroll
+      for (int j = 0; j < U; ++j) {
+        float t = 0.f;
+        if (((inside >> i) & 1u) && cu * U + j < a.cin) {
+          t = stage[i][j];
+          if (on) { t = fmaf(t, sc[j], sf[j]); t = t > 0.f ? t : t * sl[j]; }
+        }
+        v[j] = t;
+      }
+      lds_store_unit<U>(lds_in + (tid + i * 256) * U, v);
+    }
+  };
+
+  // weights of every tap row of this phase and channel block: [ty][run][COB][32]
+  {
+    constexpr int slab8 = COB * 32 / 8;
+    const int total = a.tapsy * a.nrun * slab8;
+    for (int e = tid; e < total; e += 256) {
+      const int sl_ = e / slab8, o = e % slab8;          // sl_ = ty * nrun + s
+      const u16* src = a.wp + (((int64_t)ph * a.tapsy * a.nrun + sl_) * a.cout_padP + co0) * 32;
+      *reinterpret_cast<uint4*>(lds_w + (size_t)sl_ * COB * 32 + o * 8) = *reinterpret_cast<const uint4*>(src + o * 8);
+    }
+  }
+
+  load_tile(t_begin);
+  for (int t = t_begin; t < t_end; ++t) {
+    __syncthreads();                 // the previous tile's readers are done with lds_in
+    store_tile();
+    __syncthreads();
+    if (t + 1 < t_end) load_tile(t + 1);      // in flight while this tile is multiplied
+
+    v4f acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = v4f{0.f, 0.f, 0.f, 0.f};
+    for (int ty = 0; ty < a.tapsy; ++ty) {
+      for (int s = 0; s < a.nrun; ++s) {
+        const int tapoff = (ty * a.ISx * a.IWq + a.run_off[s]) * CC;
+        const u16* lw = lds_w + (ty * a.nrun + s) * COB * 32;
+        bf8 xf[MT], wf[NT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) xf[mt] = lds_frag<CC>(lds_in + abase[mt] + tapoff);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) wf[nt] = lds_frag<32>(lw + bbase[nt]);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], xf[mt], acc[mt][nt], 0, 0, 0);
+      }
+    }
+    int n, qy0, qx0;
+    tile_coords(t, &n, &qy0, &qx0);
+    b_store_tile<NT, MT, OUT_BF16>(a, acc, n, py, px, qy0, qx0, qh, qw, co0, wm, wn, lm, kq);
   }
 }
 
@@ -322,6 +504,8 @@ struct BConfig {
   int TPR, BH, IH, IWq, slots;
   size_t lds_bytes;
   bool ok;
+  bool persistent;          // igemm_bf16_p_kernel: one chunk, all tap rows' weights resident
+  size_t lds_p;
 };
 
 static BConfig b_config_for(const ConvGeom& g, int NT, int WN) {
@@ -359,6 +543,12 @@ static BConfig b_config_for(const ConvGeom& g, int NT, int WN) {
   const size_t in_b = (((size_t)c.IH * g.IS * c.IWq * c.CC + 7) & ~(size_t)7) * 2;
   c.lds_bytes = in_b + (size_t)c.nrun * c.COB * 32 * 2;
   c.ok = c.lds_bytes <= 80 * 1024 && c.slots <= 12;       // two workgroups per CU
+  c.lds_p = in_b + (size_t)g.taps * c.nrun * c.COB * 32 * 2;
+  static const bool no_p = getenv("BP_BF16_NOPERSIST") != nullptr;
+  // (measured on the fiducial layers: the persistent form wins for the strided gathers -- 16->32 k4s2 forward
+  //  0.61 -> 0.46 ms, 32->16 transposed data gradient 0.54 -> 0.41 ms -- whose halo tiles are four times the
+  //  output tile, and loses 10-20 % on the unit-stride forms, which are bound by LDS fragment reads, not by staging)
+  c.persistent = c.ok && !no_p && c.nchunk == 1 && c.lds_p <= 64 * 1024 && g.IS == 2;
   return c;
 }
 
@@ -427,6 +617,21 @@ int b_launch(const BArgs& a, dim3 grid, size_t lds, hipStream_t st) {
   return BP_OK;
 }
 
+template <int CC, int NT, int WN, int SLOTS, bool IB, bool OB>
+int b_launch_p(const BPArgs& a, dim3 grid, size_t lds, hipStream_t st) {
+  hipLaunchKernelGGL((igemm_bf16_p_kernel<CC, NT, WN, 4, SLOTS, IB, OB>), grid, dim3(256), lds, st, a);
+  BP_CHECK_LAUNCH();
+  return BP_OK;
+}
+
+template <int CC, int NT, int WN, int SLOTS>
+int b_launch_p_io(const BPArgs& a, bool ib, bool ob, dim3 grid, size_t lds, hipStream_t st) {
+  if (ib && ob) return b_launch_p<CC, NT, WN, SLOTS, true, true>(a, grid, lds, st);
+  if (ib) return b_launch_p<CC, NT, WN, SLOTS, true, false>(a, grid, lds, st);
+  if (ob) return b_launch_p<CC, NT, WN, SLOTS, false, true>(a, grid, lds, st);
+  return b_launch_p<CC, NT, WN, SLOTS, false, false>(a, grid, lds, st);
+}
+
 template <int CC, int NT, int WN, int SLOTS>
 int b_launch_io(const BArgs& a, bool ib, bool ob, dim3 grid, size_t lds, hipStream_t st) {
   if (ib && ob) return b_launch<CC, NT, WN, SLOTS, true, true>(a, grid, lds, st);
@@ -437,6 +642,24 @@ int b_launch_io(const BArgs& a, bool ib, bool ob, dim3 grid, size_t lds, hipStre
 
 template <int CC, int NT, int WN>
 int b_launch_slots(const BConfig& c, const BArgs& a, bool ib, bool ob, dim3 grid, hipStream_t st) {
+  if constexpr (NT <= 2) {          // (persistent form: the layers with <= 32 produced channels per block)
+    if (c.persistent) {
+      BPArgs pa{};
+      pa.b = a;
+      const int nimg = (int)grid.y / (a.nphase * a.nphase);
+      pa.ntiles_total = nimg * a.tiles_x * a.tiles_y;
+      // ~2 resident workgroups per CU and phase/channel block, each with a contiguous run of >= 4 tiles
+      int nb = 512 / ((int)grid.z * a.nphase * a.nphase);
+      if (nb < 64) nb = 64;
+      int per = bp_ceil_div(pa.ntiles_total, nb);
+      if (per < 4) per = 4;
+      pa.per_block = per;
+      dim3 pg((unsigned)bp_ceil_div(pa.ntiles_total, per), (unsigned)(a.nphase * a.nphase), grid.z);
+      if (c.slots <= 3) return b_launch_p_io<CC, NT, WN, 3>(pa, ib, ob, pg, c.lds_p, st);
+      if (c.slots <= 6) return b_launch_p_io<CC, NT, WN, 6>(pa, ib, ob, pg, c.lds_p, st);
+      return b_launch_p_io<CC, NT, WN, 12>(pa, ib, ob, pg, c.lds_p, st);
+    }
+  }
   if (c.slots <= 3) return b_launch_io<CC, NT, WN, 3>(a, ib, ob, grid, c.lds_bytes, st);
   if (c.slots <= 6) return b_launch_io<CC, NT, WN, 6>(a, ib, ob, grid, c.lds_bytes, st);
   return b_launch_io<CC, NT, WN, 12>(a, ib, ob, grid, c.lds_bytes, st);

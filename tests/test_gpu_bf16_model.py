@@ -46,10 +46,14 @@ def test_bf16_step_against_reference_fixtures(tag, size, n, golden_model):
     if f"{tag}/x_mu/crop_tl" in golden_model:
         assert crop_rel_l2(f"{tag}/x_mu", m.x_mu.cpu().numpy(), golden_model) <= 1e-2
     # gradients vs the float64 truth
-    bulk = [k for k, p in m.named_parameters() if k.startswith("p_y_z_in.") and p.dim() == 4]
-    for k in bulk:
-        d = distance(f"{tag}/grad64/{k}", m.get_parameter(k).grad.cpu().numpy(), golden_model)
-        assert d <= 5e-2, (k, d)
+    # (p_y_z_in.0 is left out: one of its three input planes is the constant redshift map and another the upsampled
+    #  latent, so two thirds of its weight gradient are sums of a batch-norm backward output over all pixels -- zero up
+    #  to border effects, i.e. pure cancellation)
+    bulk = [k for k, p in m.named_parameters() if k.startswith("p_y_z_in.") and p.dim() == 4 and k != "p_y_z_in.0.weight"]
+    errs = sorted(((distance(f"{tag}/grad64/{k}", m.get_parameter(k).grad.cpu().numpy(), golden_model), k) for k in bulk),
+                  reverse=True)
+    print(tag, "worst trunk weight gradients vs float64:", errs[:4])
+    assert errs[0][0] <= 5e-2, errs[:4]
     for k, b in m.named_buffers():
         check(f"{tag}/buf/{k}", b.cpu().numpy(), golden_model, 5e-3)
     m.train(False)
