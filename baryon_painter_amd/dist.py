@@ -16,37 +16,58 @@ class Sync:
     """Collectives the launch plan needs.  ``sync_bn=False`` keeps batch-norm statistics local
     (throughput mode: different arithmetic from the single-device reference)."""
 
-    def __init__(self, group=None, sync_bn=True):
+    def __init__(self, group=None, sync_bn=True, grad_group="new"):
+        """``group``: communicator of the batch-norm statistics (latency-bound, on the critical path, main stream).
+        ``grad_group``: communicator of the gradient buffers -- a SECOND one ("new": created here, collectively, by
+        every rank), so that a gradient all-reduce may be in flight on the weight-gradient stream while statistics
+        are reduced on the main stream: collectives of ONE communicator must be issued in the same order on every
+        rank and therefore cannot be spread over streams; two communicators can.  None: share ``group``."""
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed is not initialised")
         self.group = group
         self.world_size = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         self.sync_bn = sync_bn
-        self.n_small = 0
+        self.grad_group = dist.new_group() if (grad_group == "new" and self.world_size > 1) else \
+            (group if grad_group in ("new", None) else grad_group)
+        self.overlap = self.grad_group is not group and self.world_size > 1
+        self.n_small = self.n_grad = 0
+        self.bytes_grad = 0
+        self.timing = None           # bench.py: list of (start event, end event, kind) while enabled
+
+    def _timed(self, kind):
+        import contextlib
+        import torch.cuda as tc
+        if self.timing is None or not tc.is_available():
+            return contextlib.nullcontext()
+        sync = self
+
+        class _T:
+            def __enter__(self):
+                self.e0 = tc.Event(enable_timing=True)
+                self.e0.record()
+
+            def __exit__(self, *a):
+                e1 = tc.Event(enable_timing=True)
+                e1.record()
+                sync.timing.append((self.e0, e1, kind))
+        return _T()
 
     def all_reduce_sum(self, t):
-        """Batch-norm statistics (float64 vector of 2*C entries)."""
+        """Batch-norm statistics (float64 vector of 2*C entries per layer of a level)."""
         if self.sync_bn and self.world_size > 1:
-            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+            with self._timed("bn"):
+                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
             self.n_small += 1
 
     def all_reduce_mean(self, flat):
-        """The flat gradient buffer."""
+        """A gradient buffer (or a contiguous slice of one), on the CURRENT stream."""
         if self.world_size > 1:
-            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
-            flat.mul_(1.0 / self.world_size)
-
-
-class LocalBNSync(Sync):
-    """Gradient averaging only."""
-
-    def __init__(self, group=None):
-        super().__init__(group, sync_bn=False)
-
-    @property
-    def bn_world(self):
-        return 1
+            with self._timed("grad"):
+                dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.grad_group)
+                flat.mul_(1.0 / self.world_size)
+            self.n_grad += 1
+            self.bytes_grad += flat.numel() * flat.element_size()
 
 
 def shard_indices(permutation, rank, world_size, batch_size):

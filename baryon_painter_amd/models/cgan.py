@@ -26,7 +26,7 @@ from .graph import SNConv2d, Slot, build_holders, compile_sequential, _stream
 
 class _GanPlan:
     def __init__(self, model, n):
-        self.model, self.lib, self.device, self.impl, self.sync = model, model._lib, model.device, L.IMPL_AUTO, None
+        self.model, self.lib, self.device, self.impl, self.sync = model, model._lib, model.device, L.IMPL_AUTO, model.sync
         self.n, self.ws_bytes, self.ws, self.prof = n, 0, None, None
         H, W = model.tile_size, model.tile_size
         dev = self.device
@@ -142,8 +142,14 @@ class _GanPlan:
 class CGAN(torch.nn.Module):
     """Generator + discriminator with their alternating training step."""
 
-    def __init__(self, tile_size=512, device="cuda:0", n_res=9, lambda_perceptual=2.5, g_arch=None, d_arch=None):
+    def __init__(self, tile_size=512, device="cuda:0", n_res=9, lambda_perceptual=2.5, g_arch=None, d_arch=None,
+                 sync=None):
+        """``sync`` (baryon_painter_amd.dist.Sync): data parallel, one process per GPU -- the generator's batch-norm
+        statistics become those of the global batch, the discriminator's and the generator's gradients are averaged
+        over ranks as ONE flat buffer each, right after their backward pass (the spectral-norm power iteration is
+        parameter-side arithmetic and identical on every rank)."""
         super().__init__()
+        self.sync = sync
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError("baryon_painter_amd.CGAN runs on an AMD GPU only; there is no CPU implementation.")
@@ -159,8 +165,15 @@ class CGAN(torch.nn.Module):
         self.sn_layers = [m for m in self.discriminator if isinstance(m, SNConv2d)]
         self._plans = {}
         self._grads = {}
-        for p in self.parameters():
-            p.grad = torch.zeros_like(p)
+        self._flat = {}
+        for name, net in (("d", self.discriminator), ("g", self.generator)):
+            ps = list(net.parameters())
+            flat = torch.zeros(sum(p.numel() for p in ps), device=self.device)
+            off = 0
+            for p in ps:
+                p.grad = flat[off:off + p.numel()].view_as(p)
+                off += p.numel()
+            self._flat[name] = flat
         for h in self.sn_layers:
             self._grads[id(h.weight)] = h.weight_grad
         for p in self.parameters():
@@ -234,6 +247,8 @@ class CGAN(torch.nn.Module):
             for h in self.sn_layers:
                 h.finish_backward()
             loss_d = 0.5 * (plan.sums[0] + plan.sums[1]) / plan.cnt_d
+            if self.sync is not None:
+                self.sync.all_reduce_mean(self._flat["d"])
             if capture is not None:        # tests: gradients of the discriminator step
                 capture["d"] = {k: p.grad.clone() for k, p in self.discriminator.named_parameters()}
             opt_d.step()
@@ -251,6 +266,8 @@ class CGAN(torch.nn.Module):
             plan.backward_g(self._grads, self.lambda_perceptual / plan.cnt_px)
             loss_g_adv = 0.5 * plan.sums[2] / plan.cnt_d
             loss_g_perc = plan.sums[3] / plan.cnt_px
+            if self.sync is not None:
+                self.sync.all_reduce_mean(self._flat["g"])
             if capture is not None:
                 capture["g"] = {k: p.grad.clone() for k, p in self.generator.named_parameters()}
             opt_g.step()

@@ -415,9 +415,11 @@ class _Plan:
         for us in (self.var_units, self.mu_units):
             for u in reversed(us):
                 u.backward(grads)
-        for us in reversed(self.g_units):
-            for u in reversed(us):
-                u.backward(grads)
+        for u in reversed(self.g_units[1]):              # generator trunk p_y_z_in
+            u.backward(grads)
+        early = self._reduce_trunk_gradients()
+        for u in reversed(self.g_units[0]):              # p_z_in
+            u.backward(grads)
         L.check(lib.bp_latent_backward(C.byref(self.lat), C.byref(self.z.grad), L.ptr(self.stats4),
                                        L.ptr(self.eps), L.ptr(self.seed), float(self.model.beta_KL),
                                        C.byref(self.q_head.grad),
@@ -450,6 +452,30 @@ class _Plan:
             main.wait_stream(sy); main.wait_stream(sp)
         if self.side is not None:
             torch.cuda.current_stream(self.device).wait_stream(self.side)    # join: every weight gradient is written
+        sync, flat = self.model.sync, self.model._flat_grads
+        if sync is not None:
+            if early is None:
+                sync.all_reduce_mean(flat)
+            else:                                        # what the early all-reduce did not cover: 3 % of the buffer
+                for a, b in ((0, early[0]), (early[1], flat.numel())):
+                    if b > a:
+                        sync.all_reduce_mean(flat[a:b])
+
+    def _reduce_trunk_gradients(self):
+        """Data parallel: average the gradients of the generator trunk and heads over ranks NOW, on the weight-
+        gradient stream (right behind the trunk's last weight gradient), while the main stream still runs the
+        backward pass of p_z_in, the latent heads, the prior and the recognition networks.  Uses the gradient
+        communicator of ``dist.Sync`` (the batch-norm statistics keep flowing on the main stream's own).
+        Returns the slice it covered, or None."""
+        sync, sl = self.model.sync, self.model._early_slice
+        if sync is None or sync.world_size == 1 or not sync.overlap or sl is None or self.side is None \
+                or os.environ.get("BP_EARLY_ALLREDUCE", "1") == "0":
+            return None
+        main = torch.cuda.current_stream(self.device)
+        self.side.wait_stream(main)          # batch-norm / PReLU parameter gradients are written on the main stream
+        with torch.cuda.stream(self.side):
+            sync.all_reduce_mean(self.model._flat_grads[sl[0]:sl[1]])
+        return sl
 
 
 class _ELBOFunction(torch.autograd.Function):
@@ -470,10 +496,7 @@ class _ELBOFunction(torch.autograd.Function):
         if not ctx.was_training:
             raise RuntimeError("backward through an eval-mode forward (batch-norm on running statistics) is not "
                                "implemented; the reference never does it (painter.py:85,372)")
-        flat = model._flat_grads
-        plan.backward(grad_out.detach().to(torch.float32), model._grad_views_by_id)
-        if model.sync is not None:
-            model.sync.all_reduce_mean(flat)
+        plan.backward(grad_out.detach().to(torch.float32), model._grad_views_by_id)     # (reduces over ranks too)
         # Parameter gradients live in ONE flat buffer; after optimizer.zero_grad() (grad = None) the
         # views are attached directly instead of letting autograd clone 92 tensors per step.
         out = []
@@ -563,6 +586,14 @@ class CVAE(torch.nn.Module):
         self._flat_grads = torch.zeros(n, device=self.device)
         off = 0
         self._grad_views, self._grad_views_by_id = [], {}
+        # slice of the flat buffers that holds the generator trunk and its heads (97 % of the parameters): their
+        # gradients are complete long before the backward pass ends (dist.Sync: early all-reduce on the side stream)
+        names = {id(p): n for n, p in self.named_parameters()}
+        early = [i for i, p in enumerate(params) if names[id(p)].startswith(("p_y_z_in.", "p_mu_out.", "p_var_out."))]
+        self._early_slice = None
+        if early and early == list(range(early[0], early[-1] + 1)):
+            e0 = sum(p.numel() for p in params[:early[0]])
+            self._early_slice = (e0, e0 + sum(params[i].numel() for i in early))
         for p in params:
             k = p.numel()
             self._flat_params[off:off + k].copy_(p.detach().reshape(-1))

@@ -85,7 +85,11 @@ class SNConv2d(_NoForward, torch.nn.Conv2d):
         g = self.weight_grad
         inner = (g * self.weight).sum()
         uv = torch.outer(self.weight_u, self.weight_v).view_as(g)
-        self.weight_orig.grad = (g - inner * uv) / self.sigma
+        r = (g - inner * uv) / self.sigma
+        if self.weight_orig.grad is None:
+            self.weight_orig.grad = r
+        else:
+            self.weight_orig.grad.copy_(r)          # in place: the gradient may be a view of a flat buffer
 
 
 class Marker(_NoForward, torch.nn.Module):

@@ -136,19 +136,17 @@ def cpu_baseline(seconds_budget=30.0):
             "paint_512_sample": f"5 timed sample_P of one 512x512 tile (eval mode), median {medp * 1e3:.1f} ms"}
 
 
-def bench_cgan(args, dev, world, rank):
+def bench_cgan(args, dev, world, rank, sync=None):
     """BASELINE.json configs[2]: CGAN fiducial, alternating discriminator / generator iteration."""
     import contextlib
     from baryon_painter_amd.models.cgan import CGAN
     from baryon_painter_amd.utils import synthetic as syn
-    if world > 1:
-        raise SystemExit("the CGAN leg is single-GPU in this round")
     torch.manual_seed(1234)
     with contextlib.redirect_stdout(sys.stderr):
-        model = CGAN(tile_size=args.tile, device=dev)
+        model = CGAN(tile_size=args.tile, device=dev, sync=sync)
     n = args.batch
     nb = min(n, 8)
-    x, y, z = syn.synthetic_batch(nb, args.tile, args.tile, seed=1234)
+    x, y, z = syn.synthetic_batch(nb, args.tile, args.tile, seed=1234 + rank)
     reps = (n + nb - 1) // nb
     x = torch.from_numpy(np.tanh(3 * np.tile(x, (reps, 1, 1, 1))[:n] - 0.5).astype(np.float32)).to(dev)
     y = torch.from_numpy(np.tile(y, (reps, 1, 1, 1))[:n]).to(dev)
@@ -157,18 +155,30 @@ def bench_cgan(args, dev, world, rank):
     opt_d = torch.optim.Adam(model.d_parameters(), lr=5e-5, betas=(0.5, 0.999))
     for _ in range(args.warmup):
         model.train_step(x, y, z, opt_g, opt_d)
+    if world > 1:
+        torch.distributed.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         losses = model.train_step(x, y, z, opt_g, opt_d)
     torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
     dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+        torch.distributed.destroy_process_group()
+    if rank != 0:
+        return
     print(json.dumps({
-        "metric": "cgan_train_tiles_per_sec", "value": round(n * args.steps / dt, 2), "unit": "tiles/s", "n_gpus": 1,
+        "metric": "cgan_train_tiles_per_sec", "value": round(world * n * args.steps / dt, 2), "unit": "tiles/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"CGAN fiducial alternating D+G iteration, batch {n} of {args.tile}x{args.tile} tiles, fp32 "
                                "(BASELINE.json configs[2]); parity vs own restatement only (no reference code)",
+                   "parallelism": f"dp{world}", "global_batch": n * world,
                    "losses": {k: float(v) for k, v in losses.items()}}}), flush=True)
 
 
@@ -219,7 +229,7 @@ def main():
     from baryon_painter_amd.utils import synthetic as syn
 
     if args.workload == "cgan":
-        return bench_cgan(args, dev, world, rank)
+        return bench_cgan(args, dev, world, rank, sync)
 
     arch = A.fiducial_architecture(args.tile)
     torch.manual_seed(1234)                      # same initial weights on every rank
@@ -262,6 +272,27 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
     final_elbo = float(elbo.detach())
+
+    # ---- collectives (N > 1): two further steps of the timed schedule with HIP events around every all-reduce
+    coll = None
+    if sync is not None:
+        n0, g0, b0 = sync.n_small, sync.n_grad, sync.bytes_grad
+        sync.timing = []
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        ev, sync.timing = sync.timing, None
+        ms = {}
+        for e0, e1, kind in ev:
+            ms[kind] = ms.get(kind, 0.0) + e0.elapsed_time(e1) / 2
+        coll = {"collectives_per_step": {"batch_norm_statistics": (sync.n_small - n0) // 2,
+                                         "gradient_buffers": (sync.n_grad - g0) // 2},
+                "gradient_bytes_per_step": (sync.bytes_grad - b0) // 2,
+                "ms_per_step_inside_collectives": {k: round(v, 3) for k, v in ms.items()},
+                "gradient_all_reduce": "generator trunk + heads (97 % of the bytes) on the weight-gradient stream right "
+                                       "behind the trunk's last weight gradient, own communicator; the rest after the "
+                                       "backward pass" if sync.overlap else "one flat buffer after the backward pass",
+                "backend": torch.distributed.get_backend()}
 
     # ---- kernel times for the roofline: PROF_STEPS further steps of the SERIAL schedule (not timed above).
     # In the timed region the weight gradients run on a second stream and share the CUs with the data gradients
@@ -384,6 +415,8 @@ def main():
             "roofline": roofline,
         }
         out["paint"] = paint_leg
+        if coll is not None:
+            out["config"].update(coll)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

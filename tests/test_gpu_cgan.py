@@ -53,6 +53,72 @@ def test_cgan_iteration_matches_torch_restatement(size, n_res, n, gtol):
     assert g.shape == (n, 1, size, size) and torch.isfinite(g).all() and float(g.abs().max()) <= 1.0
 
 
+_CGAN_DP_WORKER = r"""
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np, torch, torch.distributed as dist
+from baryon_painter_amd.dist import Sync
+from baryon_painter_amd.models.cgan import CGAN
+from baryon_painter_amd.utils import synthetic as syn
+dist.init_process_group("gloo")            # 2 ranks share the one GPU of the box; RCCL needs distinct devices
+r, w = dist.get_rank(), dist.get_world_size()
+size, n = 64, 4
+x, y, z = syn.synthetic_batch(n, size, size, seed=5)
+x = np.tanh(3 * x - 0.5).astype(np.float32)
+def run(sync, sl):
+    torch.manual_seed(0)
+    m = CGAN(tile_size=size, device="cuda:0", n_res=2, sync=sync)
+    m.train(True)
+    og = torch.optim.Adam(m.g_parameters(), lr=5e-5, betas=(0.5, 0.999))
+    od = torch.optim.Adam(m.d_parameters(), lr=5e-5, betas=(0.5, 0.999))
+    cap = {}
+    losses = m.train_step(torch.from_numpy(x[sl]), torch.from_numpy(y[sl]), torch.from_numpy(z[sl]), og, od, capture=cap)
+    return m, cap, {k: float(v) for k, v in losses.items()}
+h = n // w
+dp, cap_dp, l_dp = run(Sync(), slice(r * h, (r + 1) * h))
+t = torch.tensor([l_dp["D"], l_dp["G_adv"], l_dp["G_perceptual"]], dtype=torch.float64); dist.all_reduce(t); t /= w
+if r == 0:
+    ref, cap_ref, l_ref = run(None, slice(0, n))
+    for v, k in zip(t.tolist(), ("D", "G_adv", "G_perceptual")):
+        assert abs(v - l_ref[k]) <= 2e-5 * max(1.0, abs(l_ref[k])), (k, v, l_ref[k])
+    errs = []
+    for net in ("d", "g"):
+        floor = 1e-4 * max(float(v.abs().max()) for v in cap_ref[net].values() if v.numel() > 1)
+        for k, g in cap_dp[net].items():
+            b = cap_ref[net][k].double()
+            errs.append((float((g.double() - b).abs().max() / max(float(b.abs().max()), floor)), net + "." + k))
+    errs.sort(reverse=True)
+    print("worst:", errs[:5])
+    assert errs[0][0] < 5e-4, errs[:5]
+    for (k, a), (_, b) in zip(dp.state_dict().items(), ref.state_dict().items()):
+        assert torch.allclose(a.double(), b.double(), rtol=2e-4, atol=1e-6), k      # parameters after the Adam steps
+    open(os.path.join(sys.argv[2], "dp.ok"), "w").write(str(errs[0][0]))
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+def test_cgan_two_rank_data_parallel_equals_single_device(tmp_path):
+    """Sharded batch, generator batch-norm on global statistics, averaged D and G gradient buffers == one device on
+    the whole batch (losses, every gradient, parameters after the alternating step)."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "cgan_dp_worker.py"
+    script.write_text(_CGAN_DP_WORKER)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), str(script), root, str(tmp_path)],
+                         capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    assert (tmp_path / "dp.ok").exists()
+
+
 def test_cgan_painter_api(tmp_path):
     from baryon_painter_amd.painter import CGANPainter
     from baryon_painter_amd.utils import datasets as D

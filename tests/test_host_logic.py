@@ -160,6 +160,12 @@ assert sums.tolist() == [3.0, 30.0], sums
 flat = torch.full((1000,), float(r + 1))
 s.all_reduce_mean(flat)
 assert torch.allclose(flat, torch.full((1000,), 1.5))
+# gradients travel on their own communicator (may overlap the statistics' one on another stream), slice-wise
+assert s.overlap and s.grad_group is not s.group
+part = torch.arange(10.0) * (r + 1)
+s.all_reduce_mean(part[2:5])
+assert part[:2].tolist() == [0.0, 1.0 * (r + 1)] and torch.allclose(part[2:5], torch.tensor([3.0, 4.5, 6.0]))
+assert s.n_grad == 2 and s.bytes_grad == 4000 + 12 and s.n_small == 1
 local = Sync(sync_bn=False)
 t = torch.tensor([float(r)], dtype=torch.float64)
 local.all_reduce_sum(t)
