@@ -53,10 +53,13 @@ def make_weight_map(tile_shape, falloff=0.05, sigma=1):
 
 
 def paint_plane(painter, delta, tile_relative_size, n_pixel_tile, z, min_tile_overlap=0.5, falloff=0.05,
-                sigma=0.5, regularise_std=None, batch_size=64):
+                sigma=0.5, regularise_std=None, batch_size=64, seed=0, first_tile_id=0):
     """Paint a periodic mass plane tile by tile and blend (the inner loop of ``process_SLICS``,
     process_SLICS.py:198-220): tiles are cut with wrap-around, resampled to the network's tile size
-    if necessary, painted in batches, weighted by ``make_weight_map`` and accumulated."""
+    if necessary, painted in batches, weighted by ``make_weight_map`` and accumulated.
+
+    Painters with a ``paint_stream`` (CVAEPainter) paint all tiles of the plane through the pipelined device path;
+    tile (j, k) of the plane draws its prior noise under the id ``first_tile_id + j * n_side + k`` and ``seed``."""
     n_plane = int(n_pixel_tile / tile_relative_size)
     origins, slices = generate_tiling(n_plane, n_pixel_tile, min_tile_overlap)
     tiles = []
@@ -67,7 +70,11 @@ def paint_plane(painter, delta, tile_relative_size, n_pixel_tile, z, min_tile_ov
                 import scipy.ndimage
                 t = scipy.ndimage.zoom(t, zoom=n_pixel_tile / t.shape[0], mode="reflect")
             tiles.append(np.asarray(t, dtype=np.float32))
-    painted = painter.paint_batch(np.stack(tiles), z, batch_size=batch_size)
+    if hasattr(painter, "paint_stream"):
+        ids = first_tile_id + np.arange(len(tiles), dtype=np.int64)
+        painted = painter.paint_stream(np.stack(tiles), z, batch_size=min(batch_size, len(tiles)), tile_ids=ids, seed=seed)
+    else:
+        painted = painter.paint_batch(np.stack(tiles), z, batch_size=batch_size)
     plane = np.zeros((n_plane, n_plane))
     weight = np.zeros((n_plane, n_plane))
     it = iter(painted)
@@ -79,4 +86,5 @@ def paint_plane(painter, delta, tile_relative_size, n_pixel_tile, z, min_tile_ov
                 w[np.abs(p - p.mean()) > p.std() * regularise_std] = 0
             plane[slices[j][k]] += w * p
             weight[slices[j][k]] += w
-    return plane / weight
+    with np.errstate(invalid="ignore"):          # 0 / 0 where no tile reaches, as in the reference
+        return plane / weight

@@ -763,7 +763,23 @@ class CVAE(torch.nn.Module):
         g["graph"].replay()
         return g["out"].clone()
 
-    def _capture_paint_graph(self, n, given_z=False):
+    def paint_graph(self, n):
+        """The captured paint pipeline for batches of ``n`` RAW tiles (configs[4]): buffers to fill -- ``raw`` (n, cy, H,
+        W) untransformed input tiles, ``aux`` (n, 1) redshifts, ``xf_in`` / ``xf_out`` (n, 2) float64 {sigma, k} /
+        {k, sigma} of the shift-log transform and its inverse, ``tile_ids`` (n,) int64 global tile numbers, ``seed``
+        -- and ``graph.replay()``, which leaves the painted physical tiles in ``out`` (n, cx, H, W)."""
+        if self.training:
+            raise RuntimeError("paint_graph is an eval-mode (paint) path: call model.train(False) first")
+        key = (n, "pipeline", int(getattr(self, "paint_seed", 0)))
+        g = self._graphs.get(key)
+        if g is None:
+            g = self._capture_paint_graph(n, pipeline=True)
+            self._graphs[key] = g
+        for u in g["units"]:
+            u.maybe_pack()
+        return g
+
+    def _capture_paint_graph(self, n, given_z=False, pipeline=False):
         """Eval-mode layers do not couple the tiles of a batch (batch-norm runs on its running statistics), so the
         batch is painted as BP_PAINT_STREAMS (default 4) sub-batches on as many streams inside one graph: kernels of different layers share
         the CUs and fill each other's stalls (the effect the training step gets from its weight-gradient
@@ -774,6 +790,16 @@ class CVAE(torch.nn.Module):
               "aux": torch.zeros((n, self.n_aux), device=self.device) if self.use_aux_label else None,
               "out": torch.zeros((n, cx, H, W), device=self.device),
               "z": torch.zeros((n, *self.dim_z), device=self.device) if given_z else None}
+        if pipeline:
+            if self.L != 1 or self.prior_network is None:
+                raise NotImplementedError("the paint pipeline needs L = 1 and a prior network")
+            per_tile = self.dim_z[0] * self.dim_z[1] * self.dim_z[2]
+            st.update({"raw": torch.zeros((n, cy, H, W), device=self.device),
+                       "xf_in": torch.ones((n, 2), device=self.device, dtype=torch.float64),
+                       "xf_out": torch.ones((n, 2), device=self.device, dtype=torch.float64),
+                       "tile_ids": torch.zeros(n, device=self.device, dtype=torch.int64),
+                       "eps": torch.zeros((1, n, per_tile), device=self.device),
+                       "seed": int(getattr(self, "paint_seed", 0))})      # (a launch argument: part of the graph)
         parts = int(os.environ.get("BP_PAINT_STREAMS", "4"))
         while parts > 1 and (n % parts != 0 or n // parts < 8):
             parts -= 1
@@ -788,7 +814,25 @@ class CVAE(torch.nn.Module):
         st["units"] = units
         others = [torch.cuda.Stream(device=self.device) for _ in range(parts - 1)]
 
+        def paint_pipeline(plan, lo):
+            lib, sm = self._lib, _stream()
+            plan.pack_all()
+            auxp = L.ptr(st["aux"][lo:lo + h]) if st["aux"] is not None else None
+            for view in (plan.y2.view, plan.hy_slot.view):
+                L.check(lib.bp_paint_load(L.ptr(st["raw"][lo:lo + h]), cy, L.ptr(st["xf_in"][lo:lo + h]), auxp,
+                                          plan.caux, C.byref(view), sm), "paint load")
+            plan.run_prior(False)
+            eps = st["eps"][:, lo:lo + h]
+            L.check(lib.bp_philox_normal(int(st["seed"]), L.ptr(st["tile_ids"][lo:lo + h]), h, 1, eps.shape[-1],
+                                         L.ptr(eps), sm), "philox")
+            plan.run_latent(eps.reshape(1, h, *self.dim_z), use_q=False)
+            plan.run_generator(False)
+            L.check(lib.bp_paint_store(C.byref(plan.mu_head.view), None, 1 if plan.mu_softplus else 0,
+                                       L.ptr(st["xf_out"][lo:lo + h]), L.ptr(st["out"][lo:lo + h]), sm), "paint store")
+
         def paint(plan, lo):
+            if pipeline:
+                return paint_pipeline(plan, lo)
             plan.load_inputs(st["y"][lo:lo + h], None if st["aux"] is None else st["aux"][lo:lo + h])
             if given_z:
                 L.check(self._lib.bp_nchw_to_view(L.ptr(st["z"][lo:lo + h]), self.dim_z[0], None, 0,

@@ -313,6 +313,129 @@ class CVAEPainter(Painter):
                 out.append(pred)
         return np.concatenate(out, axis=0)
 
+    # ---- throughput pipeline (BASELINE.json configs[4]) ---------------------------------------------------------
+    def _shift_log_parameters(self, zs):
+        """(sigma_in, k_in, k_out, sigma_out) per tile for the device-side transforms, read out of the compiled host
+        transforms (the reference's "shift-log" range compression, data_transforms.py:72-97); anything else has no
+        device form."""
+        from .utils import data_transforms as T
+
+        def find(compiled, direction, field):
+            steps = getattr(getattr(compiled, "func", None), "steps", None) or [getattr(compiled, "func", None)]
+            for st in steps:
+                if isinstance(st, T._RangeCompress) and st.direction == direction:
+                    if st.modes[field].lower() != "shift-log":
+                        raise NotImplementedError("device-side transforms implement the 'shift-log' mode only")
+                    return float(st.k_values[field]), compiled.stats[field]
+            raise NotImplementedError("paint_stream(transform=True) needs the painter's shift-log range compression")
+        if len(self.label_fields) != 1:
+            raise NotImplementedError("Painting with more than one output field is not supported yet.")
+        k_in, st_in = find(self.transform, 0, self.input_field)
+        k_out, st_out = find(self.inverse_transform, 1, self.label_fields[0])
+        s_in = np.array([np.sqrt(T.interpolate_z(st_in, float(z))["var"]) for z in zs])
+        s_out = np.array([np.sqrt(T.interpolate_z(st_out, float(z))["var"]) for z in zs])
+        return s_in, k_in, k_out, s_out
+
+    def paint_stream(self, inputs, z, batch_size=64, tile_ids=None, seed=0, rank=0, world_size=1, out=None):
+        """Paint MANY raw tiles: ``inputs`` (N, H, W) float32 host array (NumPy, memory map, or a pinned torch tensor),
+        redshifts ``z`` (scalar or (N,)) -> (N, H, W) float32 physical tiles.  The production form of ``paint``
+        (process_SLICS.py:201-218 calls it tile by tile):
+
+          * the transform and its inverse run on the device, fused into the layout kernels on either side of the
+            network (``bp_paint_load`` / ``bp_paint_store``), bit-compatible with the host transforms;
+          * batches of ``batch_size`` tiles replay ONE captured hipGraph (prior + sampler + generator on four streams);
+          * host->device and device->host copies go through pinned double buffers on their own streams, so that
+            batch b+1 is uploaded and batch b-1 downloaded while batch b is painted;
+          * the prior noise of tile i comes from a counter-based generator keyed on (``seed``, ``tile_ids[i]``
+            [default: i]), so the result does not depend on ``batch_size`` or on how tiles are dealt to ranks;
+          * ``rank`` / ``world_size``: this process paints the contiguous block of tiles that is its share (one
+            process per GPU, no collective: tiles are independent) and returns (block, (lo, hi))."""
+        model = self.model
+        model.train(False)
+        dev = model.device
+        cy, H, W = model.dim_y
+        if cy != 1:
+            raise NotImplementedError("paint_stream paints single-channel input tiles")
+        N = len(inputs)
+        if tuple(inputs.shape[1:]) != (H, W):
+            raise ValueError(f"Shape mismatch between input and model: {tuple(inputs.shape)} vs {model.dim_y}")
+        zs = np.broadcast_to(np.asarray(z, dtype=np.float64), (N,))
+        ids = np.arange(N, dtype=np.int64) if tile_ids is None else np.asarray(tile_ids, dtype=np.int64)
+        per = (N + world_size - 1) // world_size
+        lo, hi = min(rank * per, N), min((rank + 1) * per, N)
+        B = int(batch_size)
+        model.paint_seed = int(seed)
+        g = model.paint_graph(B)
+        s_in, k_in, k_out, s_out = self._shift_log_parameters(zs[lo:hi])
+        torch_in = isinstance(inputs, torch.Tensor)
+        result = out if out is not None else np.empty((hi - lo, H, W), np.float32)
+        torch_out = isinstance(result, torch.Tensor)
+        main = torch.cuda.current_stream(dev)
+        up, down = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+        slots = []
+        for _ in range(2):
+            slots.append({"h_in": None if torch_in else torch.empty((B, 1, H, W), dtype=torch.float32).pin_memory(),
+                          "h_out": None if torch_out else torch.empty((B, 1, H, W), dtype=torch.float32).pin_memory(),
+                          "h_par": torch.empty((B, 6), dtype=torch.float64).pin_memory(),
+                          "d_in": torch.empty((B, 1, H, W), device=dev), "d_out": torch.empty((B, 1, H, W), device=dev),
+                          "d_par": torch.empty((B, 6), device=dev, dtype=torch.float64),
+                          "ev_up": torch.cuda.Event(), "ev_done": torch.cuda.Event(), "ev_down": torch.cuda.Event(),
+                          "pending": None})
+
+        def harvest(sl):
+            if sl["pending"] is None:
+                return
+            a, b = sl["pending"]
+            sl["ev_down"].synchronize()
+            if not torch_out:
+                result[a - lo:b - lo] = sl["h_out"][:b - a, 0].numpy()
+            sl["pending"] = None
+
+        with torch.no_grad():
+            for bi, a in enumerate(range(lo, hi, B)):
+                b = min(a + B, hi)
+                m = b - a
+                sl = slots[bi % 2]
+                harvest(sl)                                   # this slot's previous batch has left the device
+                par = sl["h_par"].numpy()
+                par[:m, 0], par[:m, 1] = s_in[a - lo:b - lo], k_in
+                par[:m, 2], par[:m, 3] = k_out, s_out[a - lo:b - lo]
+                par[:m, 4], par[:m, 5] = zs[a:b], ids[a:b].astype(np.float64)   # (ids < 2^53)
+                if m < B:
+                    par[m:] = par[m - 1]
+                if torch_in:
+                    src = inputs[a:b].reshape(m, 1, H, W)
+                else:
+                    sl["h_in"][:m, 0].numpy()[...] = np.asarray(inputs[a:b], dtype=np.float32)
+                    src = sl["h_in"][:m]
+                up.wait_event(sl["ev_done"])                  # the device input of two batches ago has been consumed
+                with torch.cuda.stream(up):
+                    sl["d_in"][:m].copy_(src, non_blocking=True)
+                    sl["d_par"].copy_(sl["h_par"], non_blocking=True)
+                    sl["ev_up"].record(up)
+                main.wait_event(sl["ev_up"])
+                main.wait_event(sl["ev_down"])                # ... and its device output has been downloaded
+                dp = sl["d_par"]
+                g["raw"].copy_(sl["d_in"])
+                g["xf_in"].copy_(dp[:, 0:2])
+                g["xf_out"].copy_(dp[:, 2:4])
+                if g["aux"] is not None:
+                    g["aux"].copy_(dp[:, 4:5])
+                g["tile_ids"].copy_(dp[:, 5])
+                g["graph"].replay()
+                sl["d_out"].copy_(g["out"])
+                sl["ev_done"].record(main)
+                down.wait_event(sl["ev_done"])
+                with torch.cuda.stream(down):
+                    dst = result[a - lo:b - lo].reshape(m, 1, H, W) if torch_out else sl["h_out"][:m]
+                    dst.copy_(sl["d_out"][:m], non_blocking=True)
+                    sl["ev_down"].record(down)
+                sl["pending"] = (a, b)
+            for sl in slots:
+                harvest(sl)
+            torch.cuda.synchronize(dev)
+        return (result, (lo, hi)) if world_size > 1 else result
+
     # ------------------------------------------------------------------------------ checkpoints
     def save_state_to_file(self, filename, mode="model_state_dict+metadata"):
         """(state_path, meta_path): ``torch.save(state_dict)`` + pickled metadata with the

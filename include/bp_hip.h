@@ -203,6 +203,24 @@ int bp_view_to_nchw(const bp_view* src, const bp_pointwise* pw, int32_t softplus
                     void* stream);
 int bp_fill(float* dst, int64_t n, float value, void* stream);
 
+/* ---- paint() pipeline (painter.py:371-392 around cvae.py:149-162; utils/data_transforms.py:72-97) ----------------
+ * The raw tile goes in, the physical tile comes out: the reference's "shift-log" range compression and its inverse
+ * are fused into the layout kernels on either side of the network, with the float32 / float64 promotion of the
+ * reference's NumPy expressions, so device and host transforms agree bit for bit up to libm's exp (<= 1 ulp).
+ *   bp_paint_load : out[n,:,:,ch<c] = (float) (log((double) raw / sigma_k[n][0] + 1) / sigma_k[n][1]), and the aux
+ *                   label(s) as constant planes in the next caux channels (= transform + bp_nchw_to_view)
+ *   bp_paint_store: dst = (float) ((double) (expf32(act(src) * (float) k_sigma[n][0]) - 1.f) * k_sigma[n][1]),
+ *                   NCHW (= bp_view_to_nchw + inverse transform; softplus as in bp_view_to_nchw) */
+int bp_paint_load(const float* raw_nchw, int32_t c, const double* sigma_k, const float* aux, int32_t caux,
+                  const bp_view* out, void* stream);
+int bp_paint_store(const bp_view* src, const bp_pointwise* pw, int32_t softplus, const double* k_sigma,
+                   float* dst_nchw, void* stream);
+/* eps (L, n, per_tile) standard normal for the sampler of cvae.py:64-65 from Philox4x32-10 keyed on `seed`, counter
+ * (element group, l, tile id): a tile's noise depends on (seed, its GLOBAL id) only, not on batch, stream or rank
+ * (torch.randn on the device in the reference: same distribution, no reproducible stream to match). */
+int bp_philox_normal(uint64_t seed, const int64_t* tile_ids, int32_t n, int32_t L, int32_t per_tile, float* eps,
+                     void* stream);
+
 /* ---- latent heads: reparametrisation sampler + KL (cvae.py:63-66, 76-77, 126-130) ----------- */
 typedef struct bp_latent {
   int32_t n;      /* batch M                         */

@@ -91,7 +91,9 @@ if r == 0:
     print("worst:", errs[:5])
     assert errs[0][0] < 5e-4, errs[:5]
     for (k, a), (_, b) in zip(dp.state_dict().items(), ref.state_dict().items()):
-        assert torch.allclose(a.double(), b.double(), rtol=2e-4, atol=1e-6), k      # parameters after the Adam steps
+        # parameters after the Adam steps; atol = 2 lr: a bias in front of a batch-norm has a pure-noise gradient,
+        # whose sign decides Adam's first step
+        assert torch.allclose(a.double(), b.double(), rtol=2e-4, atol=1.1e-4), k
     open(os.path.join(sys.argv[2], "dp.ok"), "w").write(str(errs[0][0]))
 dist.barrier()
 dist.destroy_process_group()

@@ -312,6 +312,10 @@ def test_bench_two_ranks_rehearsal():
     assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 4 and out["value"] > 0
     assert out["config"]["batch_norm"].startswith("global")
     assert out["roofline"]["achieved"] > 0
+    c = out["config"]["collectives_per_step"]
+    assert c["batch_norm_statistics"] == 44 and c["gradient_buffers"] == 3          # trunk early + the two remainders
+    assert out["config"]["gradient_bytes_per_step"] == 4 * 1662961
+    assert set(out["config"]["ms_per_step_inside_collectives"]) == {"bn", "grad"}
 
 
 def test_training_script_two_ranks_rehearsal(tmp_path):
