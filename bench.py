@@ -193,6 +193,7 @@ def main():
     ap.add_argument("--local-bn", action="store_true", help="do not all-reduce batch-norm statistics")
     ap.add_argument("--layers", action="store_true", help="also print a per-layer table to stderr")
     ap.add_argument("--no-paint", action="store_true", help="skip the paint() throughput leg")
+    ap.add_argument("--paint-tiles", type=int, default=1024, help="tiles streamed through paint() per rank")
     ap.add_argument("--torch-adam", action="store_true", help="torch.optim.Adam instead of the fused FlatAdam")
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
                     help="f32: the reference's arithmetic (configs[1], the headline); bf16: bf16 activations / gradients "
@@ -308,29 +309,62 @@ def main():
     prof_events, plan.prof = plan.prof, None
     model.overlap_weight_gradients(True)
 
-    # ---- paint(): eval-mode prior -> sampler -> generator, hipGraph-captured, tiles resident in HBM
+    # ---- paint() (SURVEY.md 8d metric (B), BASELINE.json configs[4]): RAW host tiles in -> physical host tiles out
+    # through CVAEPainter.paint_stream -- device-side transforms, Philox per-tile prior noise, one captured hipGraph
+    # per batch (prior + sampler + generator on four streams), pinned double-buffered H2D / D2H on side streams.
+    # This rank paints its contiguous share of the tiles; no collective.
     paint_leg = None
     if not args.no_paint:
+        from baryon_painter_amd.painter import CVAEPainter
+        from baryon_painter_amd.utils.datasets import SyntheticTileDataset
         model.train(False)
         pb = min(n, 64)
+        ds = SyntheticTileDataset(n_sample=8, tile_size=args.tile, seed=3)
+        pt = CVAEPainter.__new__(CVAEPainter)
+        pt.model, pt.compute_device, pt.sync = model, dev, None
+        pt.input_field, pt.label_fields = ds.input_field, ds.label_fields
+        pt.transform, pt.inverse_transform = ds.transform, ds.inverse_transform
+        n_paint = args.paint_tiles
+        raw = np.stack([ds.raw_fields(i)[0] for i in range(8)])
+        zs = np.array([ds.raw_fields(i)[2] for i in range(8)])
+        reps_p = (n_paint + 7) // 8
+        tin = torch.from_numpy(np.tile(raw, (reps_p, 1, 1))[:n_paint]).pin_memory()
+        zin = np.tile(zs, reps_p)[:n_paint]
+        tout = torch.empty((n_paint, args.tile, args.tile), dtype=torch.float32).pin_memory()
+        ids = np.arange(n_paint, dtype=np.int64) + rank * n_paint
         with torch.no_grad():
-            model.sample_P_graphed(y[:pb], aux_label=aux[:pb])          # capture
+            pt.paint_stream(tin[:2 * pb], zin[:2 * pb], batch_size=pb, tile_ids=ids[:2 * pb], out=tout[:2 * pb])   # capture
             torch.cuda.synchronize()
-            reps = 10
             t0p = time.perf_counter()
-            for _ in range(reps):
-                model.sample_P_graphed(y[:pb], aux_label=aux[:pb])
+            pt.paint_stream(tin, zin, batch_size=pb, tile_ids=ids, out=tout)
+            tp = time.perf_counter() - t0p
+            # the captured forward alone, tiles resident in HBM (no transforms, no copies): the kernel-side ceiling
+            g = model.paint_graph(pb)
             torch.cuda.synchronize()
-            tg = (time.perf_counter() - t0p) / reps
             t0p = time.perf_counter()
-            for _ in range(3):
-                model.sample_P(y[:pb], aux_label=aux[:pb])
+            for _ in range(10):
+                g["graph"].replay()
             torch.cuda.synchronize()
-            te = (time.perf_counter() - t0p) / 3
-        paint_leg = {"metric": "paint_tiles_per_sec", "value": round(world * pb / tg, 1), "unit": "tiles/s",
-                     "batch": pb, "ms_per_batch_graph": round(tg * 1e3, 3), "ms_per_batch_eager": round(te * 1e3, 3),
-                     "note": "sample_P (prior + sampler + generator, eval batch-norm) on resident tiles; "
-                             "per-rank, no collective"}
+            tg = (time.perf_counter() - t0p) / 10
+        assert np.isfinite(tout[-1].numpy()).all()
+        alg = 190e6 * (args.tile / 512) ** 2 * (0.5 if args.dtype == "bf16" else 1.0)   # fused-ideal
+        #                                                      activation bytes of one painted tile (fp32; half in bf16)
+        flop = 20.25e9 * (args.tile / 512) ** 2      # paint = prior + generator forward
+        paint_leg = {"metric": "paint_tiles_per_sec", "value": round(world * n_paint / tp, 1), "unit": "tiles/s",
+                     "tiles": n_paint, "batch": pb, "ms_per_batch": round(tp / (n_paint / pb) * 1e3, 3),
+                     "resident_tiles_per_sec": round(world * pb / tg, 1), "ms_per_batch_graph_only": round(tg * 1e3, 3),
+                     # fp32 paint is matrix-core bound like the fp32 train step (AI ~107 FLOP/B), bf16 paint HBM-bound
+                     "roofline": ({"bound": "hbm", "achieved": round(alg * n_paint / tp / 1e9, 1), "peak": PEAK_HBM_GBS,
+                                   "unit": "GB/s", "frac": round(alg * n_paint / tp / 1e9 / PEAK_HBM_GBS, 4),
+                                   "algorithmic_bytes_per_tile": alg} if args.dtype == "bf16" else
+                                  {"bound": "mfma", "achieved": round(flop * n_paint / tp / 1e12, 1),
+                                   "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                   "frac": round(flop * n_paint / tp / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+                                   "flop_per_tile": flop, "algorithmic_bytes_per_tile": alg}),
+                     "pcie_bytes_per_tile": 2 * 4 * args.tile ** 2,
+                     "note": "host float32 raw tile in -> host float32 physical tile out (pinned memory), per rank its "
+                             "own tiles, no collective; 'resident' = the captured forward alone on tiles already in "
+                             "HBM"}
         model.train(True)
 
     if rank == 0:
