@@ -280,46 +280,16 @@ __global__ __launch_bounds__(256, 2) void igemm_bf16_kernel(BArgs a) {
     }
   };
 
-  // Weights of one (chunk, tap row): nrun slabs of COB x 32 bf16, register-staged ONE step ahead -- the loads of
-  // step q+1 are issued before step q is multiplied and written to LDS after it, so their L2 latency hides behind
-  // nrun * MT * NT MFMAs instead of sitting between two barriers.
-  constexpr int slab8 = COB * 32 / 8;                // 16-byte groups per slab
-  constexpr int WS = (4 * slab8 + 255) / 256;        // staging registers for up to 4 runs per step
-  const bool wreg_ok = a.nrun <= 4;
-  uint4 wreg[WS];
-  auto wload = [&](int chunk, int ty) {
-#pragma unroll
-    for (int i = 0; i < WS; ++i) {
-      const int e = tid + i * 256;
-      if (e < a.nrun * slab8) {
-        const int s = e / slab8, o = e % slab8;
-        const u16* src = a.wp + ((((int64_t)(ph * a.tapsy + ty) * a.nrun + s) * a.nchunk + chunk) * a.cout_padP + co0) * 32;
-        wreg[i] = *reinterpret_cast<const uint4*>(src + o * 8);
-      }
-    }
-  };
-  auto wstore = [&]() {
-#pragma unroll
-    for (int i = 0; i < WS; ++i) {
-      const int e = tid + i * 256;
-      if (e < a.nrun * slab8) *reinterpret_cast<uint4*>(lds_w + (size_t)e * 8) = wreg[i];
-    }
-  };
-
   load_chunk(0);
-  if (wreg_ok) wload(0, 0);
   for (int chunk = 0; chunk < a.nchunk; ++chunk) {
     __syncthreads();                 // the previous chunk's readers are done with lds_in / lds_w
     store_chunk(chunk);
     if (chunk + 1 < a.nchunk) load_chunk(chunk + 1);      // in flight while this chunk is computed
     for (int ty = 0; ty < a.tapsy; ++ty) {
       if (ty) __syncthreads();       // readers of the previous tap row's weights are done
-      if (wreg_ok) {
-        wstore();
-        int nch = chunk, nty = ty + 1;
-        if (nty == a.tapsy) { nty = 0; ++nch; }
-        if (nch < a.nchunk) wload(nch, nty);
-      } else {
+      {
+        // weights of (phase, ty, all runs, chunk): nrun slabs of COB x 32 bf16
+        constexpr int slab8 = COB * 32 / 8;                // 16-byte groups per slab
         for (int e = tid; e < a.nrun * slab8; e += 256) {
           const int s = e / slab8, o = e % slab8;
           const u16* src = a.wp + ((((int64_t)(ph * a.tapsy + ty) * a.nrun + s) * a.nchunk + chunk) * a.cout_padP + co0) * 32;
@@ -327,7 +297,6 @@ __global__ __launch_bounds__(256, 2) void igemm_bf16_kernel(BArgs a) {
         }
       }
       __syncthreads();
-#pragma unroll 2
       for (int s = 0; s < a.nrun; ++s) {
         const int tapoff = (ty * a.ISx * a.IWq + a.run_off[s]) * CC;
         bf8 xf[MT], wf[NT];
