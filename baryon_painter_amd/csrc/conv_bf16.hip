@@ -46,6 +46,7 @@ struct BArgs {
   int tiles_x, tiles_y, TPR, BH;
   int nchunk, cout_padP;
   int IH, IWq;
+  int npixp;                // pixels of the LDS halo image, padded to 16 (plane stride of the CC = 32 layout)
 };
 
 __device__ __forceinline__ void b_tile_of_block(int* tile, int* by) {
@@ -175,10 +176,16 @@ __global__ __launch_bounds__(256, 2) void igemm_bf16_kernel(BArgs a) {
   constexpr int UPP = CC / U;                   // units per pixel
   constexpr int WM = 4 / WN;
   constexpr int COB = 16 * NT * WN;
+  // LDS images (bf16).  Input halo tile: CC = 32 as four k-group planes [channel octet][pixel][8] -- the 16 pixels
+  // of an MFMA fragment read are then 256 contiguous bytes per lane quarter (the plain [pixel][32] image has a
+  // 64-byte pixel stride: pixels p and p+4 share banks, measured 39 % conflict cycles); CC < 32: [pixel][CC], where a
+  // fragment is 8 consecutive bf16 across x-adjacent pixels.  Weights: [run][k octet][row][8], two slabs deep.
   extern __shared__ __attribute__((aligned(16))) u16 smem[];
   u16* lds_in = smem;
-  const int in_elems = a.IH * a.ISx * a.IWq * CC;
-  u16* lds_w = smem + ((in_elems + 7) & ~7);
+  const int in_elems = a.npixp * CC;
+  const int w_off = (in_elems + 511) & ~511;          // 1 KiB aligned: LDS-DMA pieces
+  u16* lds_w = smem + w_off;
+  const int slab_t = a.nrun * COB * 32;               // bf16 of the slabs of one (chunk, tap row)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -214,11 +221,12 @@ __global__ __launch_bounds__(256, 2) void igemm_bf16_kernel(BArgs a) {
   for (int mt = 0; mt < MT; ++mt) {
     const int t = wm * MT + mt;
     const int tr = t / a.TPR, tc = t % a.TPR;
-    abase[mt] = (tr * a.ISy * a.ISx * a.IWq + tc * 16 + lm) * CC + kq * 8;
+    if constexpr (CC == 32) abase[mt] = (kq * a.npixp + tr * a.ISy * a.ISx * a.IWq + tc * 16 + lm) * 8;
+    else abase[mt] = (tr * a.ISy * a.ISx * a.IWq + tc * 16 + lm) * CC + kq * 8;
   }
   int bbase[NT];
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt) bbase[nt] = ((wn * NT + nt) * 16 + lm) * 32 + kq * 8;
+  for (int nt = 0; nt < NT; ++nt) bbase[nt] = (kq * COB + (wn * NT + nt) * 16 + lm) * 8;
 
   v4f acc[MT][NT];
 #pragma unroll
@@ -276,34 +284,49 @@ __global__ __launch_bounds__(256, 2) void igemm_bf16_kernel(BArgs a) {
         }
         v[j] = t;
       }
-      lds_store_unit<U>(lds_in + (tid + i * 256) * U, v);
+      const int e = tid + i * 256;
+      if constexpr (CC == 32) lds_store_unit<U>(lds_in + ((e % UPP) * a.npixp + e / UPP) * 8, v);
+      else lds_store_unit<U>(lds_in + e * U, v);
+    }
+  };
+  // weights of (phase, ty, all runs, chunk) by LDS-DMA into slab buffer `slot`: nrun x COB/16 pieces of 1 KiB
+  // dealt to the four waves; the packed image holds each workgroup's [k octet][row][8] block contiguously
+  auto issue_w = [&](int chunk, int ty, int slot) {
+    constexpr int PPR = COB / 16;                    // pieces per run
+    for (int k = wave; k < a.nrun * PPR; k += 4) {
+      const int s = k / PPR, part = k - s * PPR;
+      const u16* src = a.wp + ((((int64_t)(ph * a.tapsy + ty) * a.nrun + s) * a.nchunk + chunk) * a.cout_padP + co0) * 32 +
+                       part * 512;
+      bp_glds16(reinterpret_cast<const float*>(src), (unsigned)lane * 16u, (w_off + slot * slab_t + k * 512) / 2);
     }
   };
 
+  // Pipeline: the slab of step q+1 is in flight (DMA, no registers) while step q is multiplied, the next channel
+  // chunk of the input is in flight in registers; one barrier per tap row plus one per chunk.
+  int slot = 0;
+  issue_w(0, 0, 0);
   load_chunk(0);
   for (int chunk = 0; chunk < a.nchunk; ++chunk) {
-    __syncthreads();                 // the previous chunk's readers are done with lds_in / lds_w
+    __syncthreads();                 // the previous chunk's readers are done with lds_in
     store_chunk(chunk);
-    if (chunk + 1 < a.nchunk) load_chunk(chunk + 1);      // in flight while this chunk is computed
     for (int ty = 0; ty < a.tapsy; ++ty) {
-      if (ty) __syncthreads();       // readers of the previous tap row's weights are done
+      bp_wait_dma_barrier();         // this step's slab has landed (and ty == 0: the chunk is stored); the previous
+      //                                step's readers are done with the other slab buffer
       {
-        // weights of (phase, ty, all runs, chunk): nrun slabs of COB x 32 bf16
-        constexpr int slab8 = COB * 32 / 8;                // 16-byte groups per slab
-        for (int e = tid; e < a.nrun * slab8; e += 256) {
-          const int s = e / slab8, o = e % slab8;
-          const u16* src = a.wp + ((((int64_t)(ph * a.tapsy + ty) * a.nrun + s) * a.nchunk + chunk) * a.cout_padP + co0) * 32;
-          *reinterpret_cast<uint4*>(lds_w + (size_t)s * COB * 32 + o * 8) = *reinterpret_cast<const uint4*>(src + o * 8);
-        }
+        int nch = chunk, nty = ty + 1;
+        if (nty == a.tapsy) { nty = 0; ++nch; }
+        if (nch < a.nchunk) issue_w(nch, nty, slot ^ 1);
       }
-      __syncthreads();
+      if (ty == 0 && chunk + 1 < a.nchunk) load_chunk(chunk + 1);      // in flight while this chunk is computed
+      const u16* lw = lds_w + slot * slab_t;
+      slot ^= 1;
       for (int s = 0; s < a.nrun; ++s) {
-        const int tapoff = (ty * a.ISx * a.IWq + a.run_off[s]) * CC;
+        const int tapoff = (ty * a.ISx * a.IWq + a.run_off[s]) * (CC == 32 ? 8 : CC);
         bf8 xf[MT], wf[NT];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) xf[mt] = lds_frag<CC>(lds_in + abase[mt] + tapoff);
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) wf[nt] = lds_frag<32>(lds_w + s * COB * 32 + bbase[nt]);
+        for (int nt = 0; nt < NT; ++nt) wf[nt] = lds_frag<32>(lw + s * COB * 32 + bbase[nt]);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -339,8 +362,8 @@ __global__ __launch_bounds__(256, 2) void igemm_bf16_p_kernel(BPArgs pa) {
   constexpr int COB = 16 * NT * WN;
   extern __shared__ __attribute__((aligned(16))) u16 smem[];
   u16* lds_in = smem;
-  const int in_elems = a.IH * a.ISx * a.IWq * CC;
-  u16* lds_w = smem + ((in_elems + 7) & ~7);
+  const int in_elems = a.npixp * CC;
+  u16* lds_w = smem + ((in_elems + 511) & ~511);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -373,11 +396,12 @@ __global__ __launch_bounds__(256, 2) void igemm_bf16_p_kernel(BPArgs pa) {
   for (int mt = 0; mt < MT; ++mt) {
     const int t = wm * MT + mt;
     const int tr = t / a.TPR, tc = t % a.TPR;
-    abase[mt] = (tr * a.ISy * a.ISx * a.IWq + tc * 16 + lm) * CC + kq * 8;
+    if constexpr (CC == 32) abase[mt] = (kq * a.npixp + tr * a.ISy * a.ISx * a.IWq + tc * 16 + lm) * 8;
+    else abase[mt] = (tr * a.ISy * a.ISx * a.IWq + tc * 16 + lm) * CC + kq * 8;
   }
   int bbase[NT];
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt) bbase[nt] = ((wn * NT + nt) * 16 + lm) * 32 + kq * 8;
+  for (int nt = 0; nt < NT; ++nt) bbase[nt] = (kq * COB + (wn * NT + nt) * 16 + lm) * 8;
 
   // this thread's staging units: (row, column) inside the halo image are the same for every tile
   const int E = a.IH * a.ISx * a.IWq * UPP;
@@ -443,11 +467,13 @@ __global__ __launch_bounds__(256, 2) void igemm_bf16_p_kernel(BPArgs pa) {
         }
         v[j] = t;
       }
-      lds_store_unit<U>(lds_in + (tid + i * 256) * U, v);
+      const int e = tid + i * 256;
+      if constexpr (CC == 32) lds_store_unit<U>(lds_in + ((e % UPP) * a.npixp + e / UPP) * 8, v);
+      else lds_store_unit<U>(lds_in + e * U, v);
     }
   };
 
-  // weights of every tap row of this phase and channel block: [ty][run][COB][32]
+  // weights of every tap row of this phase and channel block: [ty][run][k octet][COB][8]
   {
     constexpr int slab8 = COB * 32 / 8;
     const int total = a.tapsy * a.nrun * slab8;
@@ -472,7 +498,7 @@ __global__ __launch_bounds__(256, 2) void igemm_bf16_p_kernel(BPArgs pa) {
       for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = v4f{0.f, 0.f, 0.f, 0.f};
     for (int ty = 0; ty < a.tapsy; ++ty) {
       for (int s = 0; s < a.nrun; ++s) {
-        const int tapoff = (ty * a.ISx * a.IWq + a.run_off[s]) * CC;
+        const int tapoff = (ty * a.ISx * a.IWq + a.run_off[s]) * (CC == 32 ? 8 : CC);
         const u16* lw = lds_w + (ty * a.nrun + s) * COB * 32;
         bf8 xf[MT], wf[NT];
 #pragma unroll
@@ -501,7 +527,7 @@ __host__ __device__ __forceinline__ int b_channel_of(int NT, int jb /* index ins
 
 struct BConfig {
   int CC, R, NT, WN, MT, COB, nchunk, cout_padP, nrun, run_xm[16], run_xq[16];
-  int TPR, BH, IH, IWq, slots;
+  int TPR, BH, IH, IWq, slots, npixp;
   size_t lds_bytes;
   bool ok;
   bool persistent;          // igemm_bf16_p_kernel: one chunk, all tap rows' weights resident
@@ -540,8 +566,9 @@ static BConfig b_config_for(const ConvGeom& g, int NT, int WN) {
   const int U = c.CC < 8 ? c.CC : 8;
   const int E = c.IH * g.IS * c.IWq * (c.CC / U);
   c.slots = bp_ceil_div(E, 256);
-  const size_t in_b = (((size_t)c.IH * g.IS * c.IWq * c.CC + 7) & ~(size_t)7) * 2;
-  c.lds_bytes = in_b + (size_t)c.nrun * c.COB * 32 * 2;
+  c.npixp = bp_round_up(c.IH * g.IS * c.IWq, 16);
+  const size_t in_b = (((size_t)c.npixp * c.CC + 511) & ~(size_t)511) * 2;
+  c.lds_bytes = in_b + (size_t)2 * c.nrun * c.COB * 32 * 2;        // two weight slabs
   c.ok = c.lds_bytes <= 80 * 1024 && c.slots <= 12;       // two workgroups per CU
   c.lds_p = in_b + (size_t)g.taps * c.nrun * c.COB * 32 * 2;
   static const bool no_p = getenv("BP_BF16_NOPERSIST") != nullptr;
@@ -556,19 +583,19 @@ static BConfig b_config_for(const ConvGeom& g, int NT, int WN) {
 // of such a tile does not fit (strided gathers of 32-channel chunks): then two waves share each half tile.
 BConfig b_config(const ConvGeom& g) {
   const int nT = bp_ceil_div(g.cout_g, 16);
-  if (nT >= 5) return b_config_for(g, 4, 2);
-  if (nT >= 3) {
-    const BConfig c = b_config_for(g, 4, 1);
-    return c.ok ? c : b_config_for(g, 2, 2);
+  static const int cand[6][2] = {{4, 2}, {4, 1}, {2, 2}, {2, 1}, {1, 2}, {1, 1}};
+  const int first = nT >= 5 ? 0 : (nT >= 3 ? 1 : (nT == 2 ? 3 : 5));
+  BConfig c{};
+  for (int i = first; i < 6; ++i) {            // widest channel block whose tile + two weight slabs fit
+    if (16 * cand[i][0] * cand[i][1] > 16 * nT && i != first) continue;      // (never wider than the layer)
+    c = b_config_for(g, cand[i][0], cand[i][1]);
+    if (c.ok) break;
   }
-  if (nT == 2) {
-    const BConfig c = b_config_for(g, 2, 1);
-    return c.ok ? c : b_config_for(g, 1, 2);
-  }
-  return b_config_for(g, 1, 1);
+  return c;
 }
 
-// weights: torch layout (fp32) -> [phase][ty][run][chunk][cout_padP][32] bf16, k = j*CC + cc <-> tap xm + IS*(xq + j)
+// weights: torch layout (fp32) -> [phase][ty][run][chunk][channel block][k octet][row][8] bf16 (the LDS image of a
+// workgroup's slab, contiguous: one linear copy / LDS-DMA), k = 8*octet + i = j*CC + cc <-> tap xm + IS*(xq + j)
 struct BPackArgs {
   const float* w; u16* dst;
   int64_t sa, sb;
@@ -582,8 +609,12 @@ __global__ __launch_bounds__(256) void pack_bf16_kernel(BPackArgs a) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= a.total) return;
   int64_t r = i;
-  const int kk = r % 32; r /= 32;
-  const int jb_abs = r % a.cout_padP; r /= a.cout_padP;
+  const int k8 = r % 8; r /= 8;
+  const int row = r % a.COB; r /= a.COB;
+  const int kq = r % 4; r /= 4;
+  const int cb = r % (a.cout_padP / a.COB); r /= (a.cout_padP / a.COB);
+  const int kk = kq * 8 + k8;
+  const int jb_abs = cb * a.COB + row;
   const int chunk = r % a.nchunk; r /= a.nchunk;
   const int s = r % a.nrun; r /= a.nrun;
   const int ty = r % a.tapsy; r /= a.tapsy;
@@ -728,7 +759,7 @@ int bp_bf16_igemm_run(const ConvGeom& g, const bp_view* in, const PW& pw, const 
   a.transposed = g.gather_transposed; a.stride = g.stride; a.pad = g.pad;
   a.nrun = c.nrun;
   for (int s = 0; s < c.nrun; ++s) a.run_off[s] = c.run_xm[s] * c.IWq + c.run_xq[s];
-  a.TPR = c.TPR; a.BH = c.BH; a.IH = c.IH; a.IWq = c.IWq;
+  a.TPR = c.TPR; a.BH = c.BH; a.IH = c.IH; a.IWq = c.IWq; a.npixp = c.npixp;
   a.nchunk = c.nchunk; a.cout_padP = c.cout_padP;
   const int qh = bp_ceil_div(out->h, g.OS), qw = bp_ceil_div(out->w, g.OS);
   a.tiles_x = bp_ceil_div(qw, 16 * c.TPR);
