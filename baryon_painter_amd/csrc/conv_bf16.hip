@@ -799,17 +799,18 @@ struct WbArgs {
   int ncxb, nsplit, tiles_x, tiles_y, CXP, CYP;
 };
 
-template <int KHB, int KW, int S, int NTX, int NTY, int BH>
+template <int KHB, int KW, int S, int NTX, int NTY, int WX, int WY, int BH>
 struct WbCfg {
-  static constexpr int CXC = 16 * NTX, CYC = 16 * NTY;
+  static constexpr int WK = 4 / (WX * WY);          // waves that share a channel sub-block and split the tile's rows
+  static constexpr int CXC = 16 * NTX * WX, CYC = 16 * NTY * WY;
   static constexpr int XR = (BH - 1) * S + KHB;
   static constexpr int IW = 31 * S + KW;
   static constexpr int IWq = (IW + S - 1) / S;
   static constexpr int XT = XR * S * IWq * 16;     // bf16 per X channel tile
   static constexpr int YT = BH * 32 * 16;          // bf16 per Y channel tile
   static constexpr int TAPS = KHB * KW;
-  static constexpr size_t LDS_MAIN = (size_t)(NTX * XT + NTY * YT) * 2;
-  static constexpr size_t LDS_RED = (size_t)4 * NTX * NTY * 64 * 4 * 4;
+  static constexpr size_t LDS_MAIN = (size_t)(CXC / 16 * XT + CYC / 16 * YT) * 2;
+  static constexpr size_t LDS_RED = WK > 1 ? (size_t)WK * NTX * NTY * 64 * 4 * 4 : 0;
   static constexpr size_t LDS = LDS_MAIN > LDS_RED ? LDS_MAIN : LDS_RED;
 };
 
@@ -840,19 +841,25 @@ __device__ __forceinline__ void wb_load8(const void* base, int64_t off, int cmax
   }
 }
 
-template <int KHB, int KW, int S, int NTX, int NTY, int BH, bool XB, bool YB>
+// Workgroup = 4 waves as WX x WY x WK: WX*NTX X-channel tiles, WY*NTY Y-channel tiles; the WK waves of one channel
+// sub-block take the rows of a tile in turn and are summed through LDS at the end.  The wide layers use 2 x 2 x 1:
+// a 64 x 64 channel block per workgroup -- every pixel tile is staged (loaded, activated, rounded to bf16) once per
+// FOUR channel-block pairs instead of once per sixteen.
+template <int KHB, int KW, int S, int NTX, int NTY, int WX, int WY, int BH, bool XB, bool YB>
 __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(WbArgs a) {
-  using Cfg = WbCfg<KHB, KW, S, NTX, NTY, BH>;
+  using Cfg = WbCfg<KHB, KW, S, NTX, NTY, WX, WY, BH>;
   constexpr int CXC = Cfg::CXC, CYC = Cfg::CYC, XR = Cfg::XR, IWq = Cfg::IWq, XT = Cfg::XT, YT = Cfg::YT;
-  constexpr int TAPS = Cfg::TAPS;
-  static_assert(BH % 4 == 0, "rows are dealt to the four waves");
+  constexpr int TAPS = Cfg::TAPS, WK = Cfg::WK;
+  static_assert(BH % WK == 0, "rows are dealt to the waves of a channel sub-block");
+  static_assert(WK == 1 || (WX == 1 && WY == 1), "row-split variants own the whole channel block");
   extern __shared__ __attribute__((aligned(16))) u16 smem[];
   u16* xs = smem;
-  u16* ys = smem + NTX * XT;
+  u16* ys = smem + CXC / 16 * XT;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wx = wave / (WY * WK), wy = (wave / WK) % WY, wk = wave % WK;
   const int li = lane & 15, kq = lane >> 4;
 
   // XCD-aware block coordinates (see wt_block_coords in conv_wgrad_tiles.hip)
@@ -955,11 +962,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(WbArgs a) {
     __syncthreads();
     // ---- this wave's rows of the tile
 #pragma unroll 1
-    for (int r = wave; r < BH; r += 4) {
+    for (int r = wk; r < BH; r += WK) {
       bf8 yf[NTY];
 #pragma unroll
       for (int j = 0; j < NTY; ++j) {
-        const u16* p = ys + j * YT + r * 32 * 16 + trl;
+        const u16* p = ys + (wy * NTY + j) * YT + r * 32 * 16 + trl;
         yf[j] = frag_of(lds_tr(p), lds_tr(p + 16 * 16));
       }
 #pragma unroll
@@ -969,7 +976,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(WbArgs a) {
           const int toff = (((r * S + kyl) * S + kx % S) * IWq + kx / S) * 16;
 #pragma unroll
           for (int i = 0; i < NTX; ++i) {
-            const u16* p = xs + i * XT + toff + trl;
+            const u16* p = xs + (wx * NTX + i) * XT + toff + trl;
             const bf8 xf = frag_of(lds_tr(p), lds_tr(p + 16 * 16));
 #pragma unroll
             for (int j = 0; j < NTY; ++j)
@@ -979,45 +986,66 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(WbArgs a) {
     }
   }
 
-  // ---- sum the four waves through LDS, tap by tap; D[row = 4*kq + r : X channel][col = li : Y channel]
-  float* red = reinterpret_cast<float*>(smem);      // [4][NTX][NTY][64][4]
+  // ---- partial tiles of this split: D[row = 4*kq + r : X channel][col = li : Y channel]
+  if constexpr (WK == 1) {
 #pragma unroll
-  for (int kyl = 0; kyl < KHB; ++kyl)
-#pragma unroll
-    for (int kx = 0; kx < KW; ++kx) {
-      __syncthreads();
-#pragma unroll
-      for (int i = 0; i < NTX; ++i)
-#pragma unroll
-        for (int j = 0; j < NTY; ++j) {
-          const v4f v = acc[kyl * KW + kx][i][j];
-          *reinterpret_cast<float4*>(red + (((wave * NTX + i) * NTY + j) * 64 + lane) * 4) = make_float4(v[0], v[1], v[2], v[3]);
-        }
-      __syncthreads();
+    for (int kyl = 0; kyl < KHB; ++kyl) {
       const int ky = ky0 + kyl;
       if (ky < a.k) {
-        for (int e = tid; e < NTX * NTY * 64; e += 256) {
-          const int l = e & 63, ij = e >> 6;
-          const int i = ij / NTY, j = ij % NTY;
-          float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-          for (int w = 0; w < 4; ++w) {
-            const float4 t = *reinterpret_cast<const float4*>(red + (((w * NTX + i) * NTY + j) * 64 + l) * 4);
-            s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
-          }
-          const int cx = cx0 + i * 16 + 4 * (l >> 4);
-          const int cy = cy0 + j * 16 + (l & 15);
-          *reinterpret_cast<float4*>(a.ws + ((((int64_t)split * a.k + ky) * a.k + kx) * a.CYP + cy) * a.CXP + cx) = s;
-        }
+        for (int kx = 0; kx < KW; ++kx)
+#pragma unroll
+          for (int i = 0; i < NTX; ++i)
+#pragma unroll
+            for (int j = 0; j < NTY; ++j) {
+              const int cx = cx0 + (wx * NTX + i) * 16 + 4 * kq;
+              const int cy = cy0 + (wy * NTY + j) * 16 + li;
+              const v4f v = acc[kyl * KW + kx][i][j];
+              *reinterpret_cast<float4*>(a.ws + ((((int64_t)split * a.k + ky) * a.k + kx) * a.CYP + cy) * a.CXP + cx) =
+                  make_float4(v[0], v[1], v[2], v[3]);
+            }
       }
     }
+  } else {
+    float* red = reinterpret_cast<float*>(smem);      // [WK][NTX][NTY][64][4]: the row-split waves summed through LDS
+#pragma unroll
+    for (int kyl = 0; kyl < KHB; ++kyl)
+#pragma unroll
+      for (int kx = 0; kx < KW; ++kx) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NTX; ++i)
+#pragma unroll
+          for (int j = 0; j < NTY; ++j) {
+            const v4f v = acc[kyl * KW + kx][i][j];
+            *reinterpret_cast<float4*>(red + (((wk * NTX + i) * NTY + j) * 64 + lane) * 4) = make_float4(v[0], v[1], v[2], v[3]);
+          }
+        __syncthreads();
+        const int ky = ky0 + kyl;
+        if (ky < a.k) {
+          for (int e = tid; e < NTX * NTY * 64; e += 256) {
+            const int l = e & 63, ij = e >> 6;
+            const int i = ij / NTY, j = ij % NTY;
+            float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int w = 0; w < WK; ++w) {
+              const float4 t = *reinterpret_cast<const float4*>(red + (((w * NTX + i) * NTY + j) * 64 + l) * 4);
+              s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+            }
+            const int cx = cx0 + i * 16 + 4 * (l >> 4);
+            const int cy = cy0 + j * 16 + (l & 15);
+            *reinterpret_cast<float4*>(a.ws + ((((int64_t)split * a.k + ky) * a.k + kx) * a.CYP + cy) * a.CXP + cx) = s;
+          }
+        }
+      }
+  }
 }
 
-template <int KHB, int KW, int S, int NTX, int NTY, int BH>
+template <int KHB, int KW, int S, int NTX, int NTY, int WX, int WY, int BH>
 int wb_launch(const bp_conv* cv, const bp_view* X, const PW& pwx, const bp_view* Y, const PW& pwy, float* ws,
               size_t ws_bytes, size_t* need, int* nsplit_out, int* cxp, int* cyp, hipStream_t st, bool dry) {
-  using Cfg = WbCfg<KHB, KW, S, NTX, NTY, BH>;
-  static_assert(Cfg::LDS <= 64 * 1024, "LDS budget");
+  using Cfg = WbCfg<KHB, KW, S, NTX, NTY, WX, WY, BH>;
+  static_assert(Cfg::LDS <= 80 * 1024, "LDS budget: two workgroups per CU");
   WbArgs a{};
   a.X = X->ptr; a.xh = X->h; a.xw = X->w; a.xcs = X->cstride; a.xco = X->coff; a.cx = X->c; a.x_bf16 = X->dtype == BP_BF16;
   a.Y = Y->ptr; a.yh = Y->h; a.yw = Y->w; a.ycs = Y->cstride; a.yco = Y->coff; a.cy = Y->c; a.y_bf16 = Y->dtype == BP_BF16;
@@ -1042,7 +1070,14 @@ int wb_launch(const bp_conv* cv, const bp_view* X, const PW& pwx, const bp_view*
   if (!ws || ws_bytes < *need) return BP_EWORKSPACE;
   dim3 grid((unsigned)(a.ncxb * ncyb), (unsigned)kyg, (unsigned)a.nsplit);
   const bool xb = a.x_bf16, yb = a.y_bf16;
-#define BP_WB(XB_, YB_) hipLaunchKernelGGL((wgrad_bf16_kernel<KHB, KW, S, NTX, NTY, BH, XB_, YB_>), grid, dim3(256), Cfg::LDS, st, a)
+#define BP_WB(XB_, YB_)                                                                                             \
+  do {                                                                                                              \
+    static const hipError_t optin = hipFuncSetAttribute(                                                            \
+        reinterpret_cast<const void*>(&wgrad_bf16_kernel<KHB, KW, S, NTX, NTY, WX, WY, BH, XB_, YB_>),               \
+        hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);                                                     \
+    if (optin != hipSuccess) return BP_ELAUNCH;                                                                     \
+    hipLaunchKernelGGL((wgrad_bf16_kernel<KHB, KW, S, NTX, NTY, WX, WY, BH, XB_, YB_>), grid, dim3(256), Cfg::LDS, st, a); \
+  } while (0)
   if (xb && yb) BP_WB(true, true);
   else if (xb) BP_WB(true, false);
   else if (yb) BP_WB(false, true);
@@ -1069,19 +1104,21 @@ int bp_wgrad_bf16(const bp_conv* cv, const bp_view* X, const PW& pwx, const bp_v
   const int k = cv->k, s = cv->stride, cx = X->c, cy = Y->c;
 #define BP_WB_(...) return wb_launch<__VA_ARGS__>(cv, X, pwx, Y, pwy, ws, ws_bytes, need, nsplit, cxp, cyp, st, dry)
   if (k == 3 && s == 1) {
-    if (cx > 16 && cy > 16) BP_WB_(3, 3, 1, 2, 2, 8);
-    if (cy > 16) BP_WB_(3, 3, 1, 1, 2, 8);
-    if (cx > 16) BP_WB_(3, 3, 1, 2, 1, 8);
-    BP_WB_(3, 3, 1, 1, 1, 8);
+    if (cx > 32 && cy > 32) BP_WB_(3, 3, 1, 2, 2, 2, 2, 4);          // 64 x 64 channel block
+    if (cx > 16 && cy > 16) BP_WB_(3, 3, 1, 2, 2, 1, 1, 8);
+    if (cy > 16) BP_WB_(3, 3, 1, 1, 2, 1, 1, 8);
+    if (cx > 16) BP_WB_(3, 3, 1, 2, 1, 1, 1, 8);
+    BP_WB_(3, 3, 1, 1, 1, 1, 1, 8);
   }
   if (k == 4 && s == 2) {
-    if (cx > 16 && cy > 16) BP_WB_(2, 4, 2, 2, 2, 4);
-    if (cy > 16) BP_WB_(4, 4, 2, 1, 2, 4);
-    if (cx > 16) BP_WB_(4, 4, 2, 2, 1, 4);
-    BP_WB_(4, 4, 2, 1, 1, 4);
+    if (cx > 32 && cy > 32) BP_WB_(2, 4, 2, 2, 2, 2, 2, 2);          // 64 x 64 channel block, two tap rows per group
+    if (cx > 16 && cy > 16) BP_WB_(2, 4, 2, 2, 2, 1, 1, 4);
+    if (cy > 16) BP_WB_(4, 4, 2, 1, 2, 1, 1, 4);
+    if (cx > 16) BP_WB_(4, 4, 2, 2, 1, 1, 1, 4);
+    BP_WB_(4, 4, 2, 1, 1, 1, 1, 4);
   }
-  if (k == 5 && s == 1 && cx <= 16 && cy <= 16) BP_WB_(5, 5, 1, 1, 1, 8);
-  if (k == 7 && s == 1 && cx <= 16 && cy <= 16) BP_WB_(4, 7, 1, 1, 1, 8);
+  if (k == 5 && s == 1 && cx <= 16 && cy <= 16) BP_WB_(5, 5, 1, 1, 1, 1, 1, 8);
+  if (k == 7 && s == 1 && cx <= 16 && cy <= 16) BP_WB_(4, 7, 1, 1, 1, 1, 1, 8);
 #undef BP_WB_
   return BP_EUNSUPPORTED;
 }
