@@ -859,7 +859,9 @@ class CVAE(torch.nn.Module):
             run()                                 # warm-up outside capture (packs weights, sizes workspaces)
         torch.cuda.current_stream(self.device).wait_stream(side)
         graph = torch.cuda.CUDAGraph()
-        with torch.no_grad(), torch.cuda.graph(graph, stream=side):
+        # (thread-local capture: under data parallelism the process group's watchdog thread may query events while
+        #  this thread captures; that is harmless and must not invalidate the capture)
+        with torch.no_grad(), torch.cuda.graph(graph, stream=side, capture_error_mode="thread_local"):
             run()
         st["graph"] = graph
         return st
@@ -915,7 +917,7 @@ class CVAE(torch.nn.Module):
             run()
         torch.cuda.current_stream(dev).wait_stream(side)
         graph = torch.cuda.CUDAGraph()
-        with torch.no_grad(), torch.cuda.graph(graph, stream=side):
+        with torch.no_grad(), torch.cuda.graph(graph, stream=side, capture_error_mode="thread_local"):
             run()
         with torch.no_grad():
             for t, k in zip((self._flat_params, optimizer.exp_avg, optimizer.exp_avg_sq), keep):
