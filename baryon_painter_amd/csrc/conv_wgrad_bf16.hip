@@ -1,0 +1,350 @@
+// bf16 matrix-core weight gradient (see conv_bf16.hpp for the forward / data-gradient kernels and the shared helpers).
+#include "conv_bf16.hpp"
+
+using namespace bpbf16;
+// ---------------------------------------------------------------------------------------------- weight gradient
+//   ws[split][ky][kx][cy][cx] = sum over this split's pixels of act(X)[n, q*S + k - p, cx] * act(Y)[n, q, cy]
+// (X: the layer's fine-grid tensor, Y: its coarse-grid tensor, as in conv_wgrad_tiles.hip; the partials are summed
+// in fixed order by the reduce kernel of conv_wgrad.hip.)  A workgroup owns a (16*NTX) x (16*NTY) channel block
+// and KHB rows of taps; its four waves take the rows of a BH x 32 pixel tile in turn (one MFMA k-step = the 32
+// pixels of one row) and are summed through LDS at the end.
+// LDS images:  X  [CXC/16][rows][x % S][x / S][16]      Y  [CYC/16][BH][32][16]        (bf16)
+// Both MFMA fragments are "8 pixels of one channel": ds_read_b64_tr_b16 turns a 4-pixel x 16-channel block into
+// "lane i holds channel i of the 4 pixels"; two reads per fragment.  The k index of a fragment is a dummy index,
+// so lane group g reads pixels 4g..4g+3 and 16+4g..16+4g+3 -- each 32-lane half then touches 8 consecutive
+// 32-byte rows = 256 contiguous bytes: conflict-free.
+namespace {
+
+struct WbArgs {
+  const void* X; int xh, xw, xcs, xco, cx, x_bf16;
+  const void* Y; int yh, yw, ycs, yco, cy, y_bf16;
+  int n, k, pad;
+  PW pwx, pwy;
+  float* ws;
+  int ncxb, nsplit, tiles_x, tiles_y, CXP, CYP;
+};
+
+template <int KHB, int KW, int S, int NTX, int NTY, int WX, int WY, int BH>
+struct WbCfg {
+  static constexpr int WK = 4 / (WX * WY);          // waves that share a channel sub-block and split the tile's rows
+  static constexpr int CXC = 16 * NTX * WX, CYC = 16 * NTY * WY;
+  static constexpr int XR = (BH - 1) * S + KHB;
+  static constexpr int IW = 31 * S + KW;
+  static constexpr int IWq = (IW + S - 1) / S;
+  static constexpr int XT = XR * S * IWq * 16;     // bf16 per X channel tile
+  static constexpr int YT = BH * 32 * 16;          // bf16 per Y channel tile
+  static constexpr int TAPS = KHB * KW;
+  static constexpr size_t LDS_MAIN = (size_t)(CXC / 16 * XT + CYC / 16 * YT) * 2;
+  static constexpr size_t LDS_RED = WK > 1 ? (size_t)WK * NTX * NTY * 64 * 4 * 4 : 0;
+  static constexpr size_t LDS = LDS_MAIN > LDS_RED ? LDS_MAIN : LDS_RED;
+};
+
+__device__ __forceinline__ s4 lds_tr(const u16* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((s4 __attribute__((address_space(3)))*)p);
+}
+__device__ __forceinline__ bf8 frag_of(s4 a, s4 b) {
+  typedef short s8 __attribute__((ext_vector_type(8)));
+  const s8 v = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+  return __builtin_bit_cast(bf8, v);
+}
+
+template <bool BF>
+__device__ __forceinline__ void wb_load8(const void* base, int64_t off, int cmax, int ch, bool vec, float (&v)[8]) {
+  // 8 channels [ch, ch+8) of one pixel; channels >= cmax read as 0 (never dereferenced)
+  if (vec && ch + 7 < cmax) {
+    load_unit<8, BF>(base, off, v);
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float t = 0.f;
+      if (ch + j < cmax) {
+        if constexpr (BF) t = bf2f(reinterpret_cast<const u16*>(base)[off + j]);
+        else t = reinterpret_cast<const float*>(base)[off + j];
+      }
+      v[j] = t;
+    }
+  }
+}
+
+// Workgroup = 4 waves as WX x WY x WK: WX*NTX X-channel tiles, WY*NTY Y-channel tiles; the WK waves of one channel
+// sub-block take the rows of a tile in turn and are summed through LDS at the end.  The wide layers use 2 x 2 x 1:
+// a 64 x 64 channel block per workgroup -- every pixel tile is staged (loaded, activated, rounded to bf16) once per
+// FOUR channel-block pairs instead of once per sixteen.
+template <int KHB, int KW, int S, int NTX, int NTY, int WX, int WY, int BH, bool XB, bool YB>
+__global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(WbArgs a) {
+  using Cfg = WbCfg<KHB, KW, S, NTX, NTY, WX, WY, BH>;
+  constexpr int CXC = Cfg::CXC, CYC = Cfg::CYC, XR = Cfg::XR, IWq = Cfg::IWq, XT = Cfg::XT, YT = Cfg::YT;
+  constexpr int TAPS = Cfg::TAPS, WK = Cfg::WK;
+  static_assert(BH % WK == 0, "rows are dealt to the waves of a channel sub-block");
+  static_assert(WK == 1 || (WX == 1 && WY == 1), "row-split variants own the whole channel block");
+  extern __shared__ __attribute__((aligned(16))) u16 smem[];
+  u16* xs = smem;
+  u16* ys = smem + CXC / 16 * XT;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wx = wave / (WY * WK), wy = (wave / WK) % WY, wk = wave % WK;
+  const int li = lane & 15, kq = lane >> 4;
+
+  // XCD-aware block coordinates (see wt_block_coords in conv_wgrad_tiles.hip)
+  int bx, by, split;
+  {
+    const int gx = gridDim.x, gy = gridDim.y;
+    const int nb = gx * gy * gridDim.z;
+    const int L = (blockIdx.z * gy + blockIdx.y) * gx + blockIdx.x;
+    const int q = nb >> 3, r = nb & 7;
+    const int xcd = L & 7, idx = L >> 3;
+    const int Lp = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    bx = Lp % gx; by = (Lp / gx) % gy; split = Lp / (gx * gy);
+  }
+  const int cxb = bx % a.ncxb, cyb = bx / a.ncxb;
+  const int ky0 = by * KHB;
+  const int cx0 = cxb * CXC, cy0 = cyb * CYC;
+
+  v4f acc[TAPS][NTX][NTY];
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+    for (int i = 0; i < NTX; ++i)
+#pragma unroll
+      for (int j = 0; j < NTY; ++j) acc[t][i][j] = v4f{0.f, 0.f, 0.f, 0.f};
+
+  // transposing-read address of this lane inside a [pixel][16] image: pixel 4*kq + (li >> 2), channels 4*(li & 3)
+  const int trl = (4 * kq + (li >> 2)) * 16 + 4 * (li & 3);
+
+  // staging: fixed 8-channel group per thread
+  constexpr int XU = CXC / 8, YU = CYC / 8;          // units per pixel
+  const int xcu = tid % XU, ycu = tid % YU;
+  float xsc[8], xsf[8], xsl[8], ysc[8], ysf[8], ysl[8];
+  const bool xon = a.pwx.scale != nullptr, yon = a.pwy.scale != nullptr;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int cxj = cx0 + xcu * 8 + j, cyj = cy0 + ycu * 8 + j;
+    const bool okx = xon && cxj < a.cx, oky = yon && cyj < a.cy;
+    xsc[j] = okx ? a.pwx.scale[cxj] : 1.f; xsf[j] = okx ? a.pwx.shift[cxj] : 0.f; xsl[j] = okx ? a.pwx.slope[cxj] : 1.f;
+    ysc[j] = oky ? a.pwy.scale[cyj] : 1.f; ysf[j] = oky ? a.pwy.shift[cyj] : 0.f; ysl[j] = oky ? a.pwy.slope[cyj] : 1.f;
+  }
+  const bool xvec = (a.cx & 7) == 0, yvec = (a.cy & 7) == 0;
+
+  const int tiles_per_img = a.tiles_x * a.tiles_y;
+  const int ntiles = a.n * tiles_per_img;
+  for (int tile = split; tile < ntiles; tile += a.nsplit) {
+    const int n = tile / tiles_per_img;
+    const int trem = tile - n * tiles_per_img;
+    const int ty_ = trem / a.tiles_x, tx_ = trem - ty_ * a.tiles_x;
+    const int qy0 = ty_ * BH, qx0 = tx_ * 32;
+    const int gy0 = qy0 * S + ky0 - a.pad, gx0 = qx0 * S - a.pad;
+    __syncthreads();
+    {   // ---- X tile
+      const int64_t img = (int64_t)n * a.xh * a.xw * a.xcs + a.xco;
+      const int ch = cx0 + xcu * 8;
+      for (int e = tid; e < XR * S * IWq * XU; e += 256) {
+        const int pi = e / XU;
+        const int xq = pi % IWq;
+        const int t = pi / IWq;
+        const int xm = t % S, r = t / S;
+        const int iy = gy0 + r, ix = gx0 + xq * S + xm;
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = 0.f;
+        if (iy >= 0 && iy < a.xh && ix >= 0 && ix < a.xw && ch < a.cx) {
+          wb_load8<XB>(a.X, img + ((int64_t)iy * a.xw + ix) * a.xcs + ch, a.cx, ch, xvec, v);
+          if (xon) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              const float u = fmaf(v[j], xsc[j], xsf[j]);
+              v[j] = (ch + j < a.cx) ? (u > 0.f ? u : u * xsl[j]) : 0.f;
+            }
+          }
+        }
+        lds_store_unit<8>(xs + (xcu >> 1) * XT + pi * 16 + (xcu & 1) * 8, v);
+      }
+    }
+    {   // ---- Y tile
+      const int64_t img = (int64_t)n * a.yh * a.yw * a.ycs + a.yco;
+      const int ch = cy0 + ycu * 8;
+      for (int e = tid; e < BH * 32 * YU; e += 256) {
+        const int pi = e / YU;
+        const int c = pi & 31, r = pi >> 5;
+        const int qy = qy0 + r, qx = qx0 + c;
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = 0.f;
+        if (qy < a.yh && qx < a.yw && ch < a.cy) {
+          wb_load8<YB>(a.Y, img + ((int64_t)qy * a.yw + qx) * a.ycs + ch, a.cy, ch, yvec, v);
+          if (yon) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              const float u = fmaf(v[j], ysc[j], ysf[j]);
+              v[j] = (ch + j < a.cy) ? (u > 0.f ? u : u * ysl[j]) : 0.f;
+            }
+          }
+        }
+        lds_store_unit<8>(ys + (ycu >> 1) * YT + pi * 16 + (ycu & 1) * 8, v);
+      }
+    }
+    __syncthreads();
+    // ---- this wave's rows of the tile
+#pragma unroll 1
+    for (int r = wk; r < BH; r += WK) {
+      bf8 yf[NTY];
+#pragma unroll
+      for (int j = 0; j < NTY; ++j) {
+        const u16* p = ys + (wy * NTY + j) * YT + r * 32 * 16 + trl;
+        yf[j] = frag_of(lds_tr(p), lds_tr(p + 16 * 16));
+      }
+#pragma unroll
+      for (int kyl = 0; kyl < KHB; ++kyl)
+#pragma unroll
+        for (int kx = 0; kx < KW; ++kx) {
+          const int toff = (((r * S + kyl) * S + kx % S) * IWq + kx / S) * 16;
+#pragma unroll
+          for (int i = 0; i < NTX; ++i) {
+            const u16* p = xs + (wx * NTX + i) * XT + toff + trl;
+            const bf8 xf = frag_of(lds_tr(p), lds_tr(p + 16 * 16));
+#pragma unroll
+            for (int j = 0; j < NTY; ++j)
+              acc[kyl * KW + kx][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf, yf[j], acc[kyl * KW + kx][i][j], 0, 0, 0);
+          }
+        }
+    }
+  }
+
+  // ---- partial tiles of this split: D[row = 4*kq + r : X channel][col = li : Y channel]
+  if constexpr (WK == 1) {
+#pragma unroll
+    for (int kyl = 0; kyl < KHB; ++kyl) {
+      const int ky = ky0 + kyl;
+      if (ky < a.k) {
+#pragma unroll
+        for (int kx = 0; kx < KW; ++kx)
+#pragma unroll
+          for (int i = 0; i < NTX; ++i)
+#pragma unroll
+            for (int j = 0; j < NTY; ++j) {
+              const int cx = cx0 + (wx * NTX + i) * 16 + 4 * kq;
+              const int cy = cy0 + (wy * NTY + j) * 16 + li;
+              const v4f v = acc[kyl * KW + kx][i][j];
+              *reinterpret_cast<float4*>(a.ws + ((((int64_t)split * a.k + ky) * a.k + kx) * a.CYP + cy) * a.CXP + cx) =
+                  make_float4(v[0], v[1], v[2], v[3]);
+            }
+      }
+    }
+  } else {
+    float* red = reinterpret_cast<float*>(smem);      // [WK][NTX][NTY][64][4]: the row-split waves summed through LDS
+#pragma unroll
+    for (int kyl = 0; kyl < KHB; ++kyl)
+#pragma unroll
+      for (int kx = 0; kx < KW; ++kx) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NTX; ++i)
+#pragma unroll
+          for (int j = 0; j < NTY; ++j) {
+            const v4f v = acc[kyl * KW + kx][i][j];
+            *reinterpret_cast<float4*>(red + (((wk * NTX + i) * NTY + j) * 64 + lane) * 4) = make_float4(v[0], v[1], v[2], v[3]);
+          }
+        __syncthreads();
+        const int ky = ky0 + kyl;
+        if (ky < a.k) {
+          for (int e = tid; e < NTX * NTY * 64; e += 256) {
+            const int l = e & 63, ij = e >> 6;
+            const int i = ij / NTY, j = ij % NTY;
+            float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int w = 0; w < WK; ++w) {
+              const float4 t = *reinterpret_cast<const float4*>(red + (((w * NTX + i) * NTY + j) * 64 + l) * 4);
+              s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+            }
+            const int cx = cx0 + i * 16 + 4 * (l >> 4);
+            const int cy = cy0 + j * 16 + (l & 15);
+            *reinterpret_cast<float4*>(a.ws + ((((int64_t)split * a.k + ky) * a.k + kx) * a.CYP + cy) * a.CXP + cx) = s;
+          }
+        }
+      }
+  }
+}
+
+template <int KHB, int KW, int S, int NTX, int NTY, int WX, int WY, int BH>
+int wb_launch(const bp_conv* cv, const bp_view* X, const PW& pwx, const bp_view* Y, const PW& pwy, float* ws,
+              size_t ws_bytes, size_t* need, int* nsplit_out, int* cxp, int* cyp, hipStream_t st, bool dry) {
+  using Cfg = WbCfg<KHB, KW, S, NTX, NTY, WX, WY, BH>;
+  static_assert(Cfg::LDS <= 80 * 1024, "LDS budget: two workgroups per CU");
+  WbArgs a{};
+  a.X = X->ptr; a.xh = X->h; a.xw = X->w; a.xcs = X->cstride; a.xco = X->coff; a.cx = X->c; a.x_bf16 = X->dtype == BP_BF16;
+  a.Y = Y->ptr; a.yh = Y->h; a.yw = Y->w; a.ycs = Y->cstride; a.yco = Y->coff; a.cy = Y->c; a.y_bf16 = Y->dtype == BP_BF16;
+  a.n = X->n; a.k = cv->k; a.pad = cv->pad; a.pwx = pwx; a.pwy = pwy; a.ws = ws;
+  a.ncxb = bp_ceil_div(X->c, Cfg::CXC);
+  const int ncyb = bp_ceil_div(Y->c, Cfg::CYC);
+  a.CXP = a.ncxb * Cfg::CXC;
+  a.CYP = ncyb * Cfg::CYC;
+  a.tiles_x = bp_ceil_div(Y->w, 32);
+  a.tiles_y = bp_ceil_div(Y->h, BH);
+  const int kyg = bp_ceil_div(cv->k, KHB);
+  const int64_t ntiles = (int64_t)Y->n * a.tiles_x * a.tiles_y;
+  const int64_t base = (int64_t)a.ncxb * ncyb * kyg;
+  int64_t ns = (1024 + base - 1) / base;     // ~4 workgroups per CU
+  if (ns > ntiles) ns = ntiles;
+  if (ns < 1) ns = 1;
+  if (ns > 65535) ns = 65535;
+  a.nsplit = (int)ns;
+  *need = (size_t)a.nsplit * cv->k * cv->k * a.CYP * a.CXP * sizeof(float);
+  *nsplit_out = a.nsplit; *cxp = a.CXP; *cyp = a.CYP;
+  if (dry) return BP_OK;
+  if (!ws || ws_bytes < *need) return BP_EWORKSPACE;
+  dim3 grid((unsigned)(a.ncxb * ncyb), (unsigned)kyg, (unsigned)a.nsplit);
+  const bool xb = a.x_bf16, yb = a.y_bf16;
+#define BP_WB(XB_, YB_)                                                                                             \
+  do {                                                                                                              \
+    static const hipError_t optin = hipFuncSetAttribute(                                                            \
+        reinterpret_cast<const void*>(&wgrad_bf16_kernel<KHB, KW, S, NTX, NTY, WX, WY, BH, XB_, YB_>),               \
+        hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);                                                     \
+    if (optin != hipSuccess) return BP_ELAUNCH;                                                                     \
+    hipLaunchKernelGGL((wgrad_bf16_kernel<KHB, KW, S, NTX, NTY, WX, WY, BH, XB_, YB_>), grid, dim3(256), Cfg::LDS, st, a); \
+  } while (0)
+  if (xb && yb) BP_WB(true, true);
+  else if (xb) BP_WB(true, false);
+  else if (yb) BP_WB(false, true);
+  else BP_WB(false, false);
+#undef BP_WB
+  BP_CHECK_LAUNCH();
+  return BP_OK;
+}
+
+// 16-byte loads of 8 channels need 16-byte aligned pixel rows; ragged channel counts take the scalar path
+bool wb_view_ok(const bp_view* v) {
+  const int esz = v->dtype == BP_BF16 ? 2 : 4;
+  if (reinterpret_cast<uintptr_t>(v->ptr) % 16) return false;
+  if (v->c % 8 == 0) return (v->cstride * esz) % 16 == 0 && (v->coff * esz) % 16 == 0;
+  return true;
+}
+
+}  // namespace
+
+// Same contract as bp_wgrad_tiles (conv_wgrad_tiles.hip): partial sums to ws, BP_EUNSUPPORTED if no variant fits.
+int bp_wgrad_bf16(const bp_conv* cv, const bp_view* X, const PW& pwx, const bp_view* Y, const PW& pwy, float* ws,
+                  size_t ws_bytes, size_t* need, int* nsplit, int* cxp, int* cyp, hipStream_t st, bool dry) {
+  if (!wb_view_ok(X) || !wb_view_ok(Y)) return BP_EUNSUPPORTED;
+  const int k = cv->k, s = cv->stride, cx = X->c, cy = Y->c;
+#define BP_WB_(...) return wb_launch<__VA_ARGS__>(cv, X, pwx, Y, pwy, ws, ws_bytes, need, nsplit, cxp, cyp, st, dry)
+  if (k == 3 && s == 1) {
+    if (cx > 32 && cy > 32) BP_WB_(3, 3, 1, 2, 2, 2, 2, 4);          // 64 x 64 channel block
+    if (cx > 16 && cy > 16) BP_WB_(3, 3, 1, 2, 2, 1, 1, 8);
+    if (cy > 16) BP_WB_(3, 3, 1, 1, 2, 1, 1, 8);
+    if (cx > 16) BP_WB_(3, 3, 1, 2, 1, 1, 1, 8);
+    BP_WB_(3, 3, 1, 1, 1, 1, 1, 8);
+  }
+  if (k == 4 && s == 2) {
+    if (cx > 32 && cy > 32) BP_WB_(2, 4, 2, 2, 2, 2, 2, 2);          // 64 x 64 channel block, two tap rows per group
+    if (cx > 16 && cy > 16) BP_WB_(2, 4, 2, 2, 2, 1, 1, 4);
+    if (cy > 16) BP_WB_(4, 4, 2, 1, 2, 1, 1, 4);
+    if (cx > 16) BP_WB_(4, 4, 2, 2, 1, 1, 1, 4);
+    BP_WB_(4, 4, 2, 1, 1, 1, 1, 4);
+  }
+  if (k == 5 && s == 1 && cx <= 16 && cy <= 16) BP_WB_(5, 5, 1, 1, 1, 1, 1, 8);
+  if (k == 7 && s == 1 && cx <= 16 && cy <= 16) BP_WB_(4, 7, 1, 1, 1, 1, 1, 8);
+#undef BP_WB_
+  return BP_EUNSUPPORTED;
+}
+
