@@ -42,14 +42,17 @@ class Painter:
 
 class CVAEPainter(Painter):
     def __init__(self, filename=None, training_data_set=None, test_data_set=None, architecture="test",
-                 compute_device="cuda:0", sync=None):
+                 compute_device="cuda:0", sync=None, dtype="f32"):
+        """The reference's arguments (painter.py:34-38) plus ``sync`` (data parallel, baryon_painter_amd.dist.Sync) and
+        ``dtype``: "f32" = the reference's arithmetic, "bf16" = the bf16 throughput mode of ``models.cvae.CVAE``."""
         self.sync = sync
+        self.dtype = dtype
         if filename is not None:
             self.load_state_from_file(filename, compute_device)
         else:
             self.architecture = architecture
             self.compute_device = compute_device
-            self.model = _cvae.CVAE(architecture, torch.device(compute_device), sync=sync)
+            self.model = _cvae.CVAE(architecture, torch.device(compute_device), sync=sync, dtype=dtype)
         self.training_data = training_data_set
         self.test_data = test_data_set
 
@@ -460,7 +463,7 @@ class CVAEPainter(Painter):
         with open(filename[1], "rb") as f:
             d = _pickler.load(f)
         self.model = _cvae.CVAE(d["model_architecture"], torch.device(self.compute_device),
-                                sync=getattr(self, "sync", None))
+                                sync=getattr(self, "sync", None), dtype=getattr(self, "dtype", "f32"))
         self.model.load_state_dict(state_dict)
         self.architecture = d["model_architecture"]
         for k in ("L", "n_grid", "tile_L", "n_tile", "tile_size", "input_field", "label_fields", "scale_to_SLICS"):

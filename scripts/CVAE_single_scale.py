@@ -10,6 +10,8 @@ overrides so the script can be exercised without the BAHAMAS stacks:
   BP_OUTPUT_PATH  run directory (default ../output/)
   BP_DEVICE       compute device (default cuda:0)
   BP_N_PEPOCH / BP_TILE  shorten the run / shrink the tiles for smoke tests
+  BP_DTYPE         f32 (default: the reference's arithmetic) or bf16 (bf16 activations / gradients in the generator
+                   trunk, fp32 accumulation, master weights and statistics)
   BP_DIST_BACKEND  collective backend under torch.distributed.run (default nccl = RCCL; gloo to rehearse the
                   multi-rank path with all ranks on one GPU)
 Launch under ``python -m torch.distributed.run --nproc-per-node N`` for data-parallel training
@@ -109,7 +111,8 @@ if __name__ == "__main__":
 
     painter = baryon_painter_amd.painter.CVAEPainter(training_data_set=training_dataset,
                                                      test_data_set=validation_dataset,
-                                                     architecture=test_net, compute_device=compute_device, sync=sync)
+                                                     architecture=test_net, compute_device=compute_device, sync=sync,
+                                                     dtype=os.environ.get("BP_DTYPE", "f32"))
     print(painter.model)
 
     def adaptive_batch_size(pepoch, min_batch_size=1, max_batch_size=24):

@@ -56,6 +56,7 @@ def painter(tmp_path_factory):
     tiles = np.stack([np.asarray(ds.get_input_sample(i % len(ds), transform=False), np.float32) for i in range(11)])
     tiles *= (1.0 + 0.1 * np.arange(11, dtype=np.float32))[:, None, None]          # 11 distinct tiles
     zs = np.array([0.0, 0.3, 2.0, 0.5, 1.1, 0.0, 2.0, 0.125, 1.9, 0.7, 0.3])
+    q.checkpoint_files = files
     return q, arch, tiles, zs
 
 
@@ -128,3 +129,20 @@ def test_paint_plane_equals_the_per_tile_loop(painter):
     ok = np.isfinite(ref)
     assert np.array_equal(np.isfinite(plane), ok) and ok.mean() > 0.95
     assert np.abs(plane[ok] - ref[ok]).max() <= 1e-6 * np.abs(ref[ok]).max()
+
+
+def test_paint_stream_bf16_mode(painter):
+    """CVAEPainter(dtype="bf16") on the same checkpoint files: painting with the bf16 trunk stays within the stated bf16
+    tolerance of the fp32 painting of the same tiles with the same noise (compared in the network's log domain: the
+    inverse transform exponentiates 4x the network output, which turns 1e-2 of the output into 4e-2 of the field)."""
+    from baryon_painter_amd.painter import CVAEPainter
+    q, arch, tiles, zs = painter
+    b = CVAEPainter(filename=q.checkpoint_files, compute_device="cuda:0", dtype="bf16")
+    assert b.model.dtype == "bf16"
+    ref = q.paint_stream(tiles, zs, batch_size=4, seed=3).astype(np.float64)
+    got = b.paint_stream(tiles, zs, batch_size=4, seed=3).astype(np.float64)
+    plan = next(iter(b.model._graphs.values()))["plans"][0]
+    assert plan.h.buf.dtype == torch.bfloat16, "the generator trunk must be stored as bf16"
+    sigma = ref.std()
+    lr, lg = np.log1p(np.maximum(ref, 0) / sigma), np.log1p(np.maximum(got, 0) / sigma)
+    assert np.linalg.norm(lg - lr) / np.linalg.norm(lr) <= 2e-2
