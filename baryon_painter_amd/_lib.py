@@ -106,6 +106,10 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch first: its wheel bundles the HIP runtime this process must share.  Loading libbp_hip.so before torch
+    # brings in the system runtime instead and the first launch fails (seen as "kernel launch failed" when
+    # __graft_entry__.build() and smoke() ran in one process).
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(
             f"{LIB_PATH} not found: the HIP kernels are not built. Run "
