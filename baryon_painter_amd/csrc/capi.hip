@@ -11,7 +11,8 @@ int bp_igemm_pack_job(const ConvGeom& g, const WeightMap& wm, const float* w_tor
 int bp_igemm_pack_jobs(const void* jobs_dev, const int64_t* first_block_dev, int njobs, int64_t total_blocks,
                        hipStream_t st);
 int bp_igemm_run(const ConvGeom& g, const bp_view* in, const PW& pw, const float* packed, const float* bias,
-                 const bp_view* out, hipStream_t st);
+                 const bp_view* out, hipStream_t st, const IgemmStatsReq* stats = nullptr);
+size_t bp_igemm_stats_workspace(const ConvGeom& g, const bp_view* in, const bp_view* out);
 int bp_direct_gather(const ConvGeom& g, const WeightMap& wm, const bp_view* in, const PW& pw, const float* w_torch,
                      const float* bias, const bp_view* out, hipStream_t st);
 int bp_direct_wgrad(const bp_conv* cv, const bp_view* X, const PW& pwx, const bp_view* Y, const PW& pwy, float* dst,
@@ -128,6 +129,29 @@ int bp_conv_forward(const bp_conv* cv, const bp_view* x, const bp_pointwise* x_p
   }
   if (!w_torch) return BP_EINVAL;
   return bp_direct_gather(g, bp_wmap(cv, BP_PACK_FWD), x, bp_pw(x_pw), w_torch, bias, y, bp_stream(stream));
+}
+
+size_t bp_conv_stats_workspace(const bp_conv* cv, int dir, const bp_view* x, const bp_view* y) {
+  if (!conv_ok(cv) || !shapes_ok(cv, x, y) || (dir != BP_PACK_FWD && dir != BP_PACK_BWD)) return 0;
+  return dir == BP_PACK_FWD ? bp_igemm_stats_workspace(bp_geom_forward(cv), x, y)
+                            : bp_igemm_stats_workspace(bp_geom_backward_data(cv), y, x);
+}
+
+int bp_conv_forward_stats(const bp_conv* cv, const bp_view* x, const bp_pointwise* x_pw, const float* packed_fwd,
+                          const bp_view* y, double* sums, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!conv_ok(cv) || !shapes_ok(cv, x, y) || !packed_fwd || !sums) return BP_EINVAL;
+  const IgemmStatsReq sr{1, nullptr, PW{nullptr, nullptr, nullptr}, sums, workspace, workspace_bytes};
+  return bp_igemm_run(bp_geom_forward(cv), x, bp_pw(x_pw), packed_fwd, nullptr, y, bp_stream(stream), &sr);
+}
+
+int bp_conv_backward_data_stats(const bp_conv* cv, const bp_view* dy, const float* packed_bwd, const bp_view* dx,
+                                const bp_view* x_raw, const bp_pointwise* x_pw, double* sums, void* workspace,
+                                size_t workspace_bytes, void* stream) {
+  if (!conv_ok(cv) || !shapes_ok(cv, dx, dy) || !packed_bwd || !sums || !bp_view_ok(x_raw)) return BP_EINVAL;
+  if (x_raw->n != dx->n || x_raw->h != dx->h || x_raw->w != dx->w || x_raw->c != dx->c) return BP_EINVAL;
+  const IgemmStatsReq sr{2, x_raw, bp_pw(x_pw), sums, workspace, workspace_bytes};
+  return bp_igemm_run(bp_geom_backward_data(cv), dy, PW{nullptr, nullptr, nullptr}, packed_bwd, nullptr, dx,
+                      bp_stream(stream), &sr);
 }
 
 int bp_conv_backward_data(const bp_conv* cv, const bp_view* dy, const float* packed_bwd, const float* w_torch,

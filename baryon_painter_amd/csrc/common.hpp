@@ -41,6 +41,19 @@ static inline PW bp_pw(const bp_pointwise* p) {
   return r;
 }
 
+// Request for per-channel sums out of an igemm epilogue (conv_igemm.hip, IgemmArgs::stat).  mode 1: {sum y,
+// sum y^2} of the produced tensor; mode 2: the produced tensor is d(loss)/d(activated slot), `raw` / `spw` are that
+// slot's raw values and pending activation: {sum g, sum g*raw} with g = d * act'(spw(raw)).  sums[2c].
+struct IgemmStatsReq {
+  int mode;
+  const bp_view* raw;
+  PW spw;
+  double* sums;
+  void* ws;
+  size_t ws_bytes;
+};
+int bp_sum_partials(const double* partial, int nblk, int n, double* out, hipStream_t st);
+
 __device__ __forceinline__ float pw_apply(const PW& pw, int ch, float x) {
   if (pw.scale == nullptr) return x;
   float t = fmaf(x, pw.scale[ch], pw.shift[ch]);

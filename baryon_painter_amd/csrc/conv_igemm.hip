@@ -41,6 +41,14 @@ struct IgemmArgs {
   int out_vec;   // 16-byte stores allowed
   int in_pad4;   // DMA variants: float4 groups per input buffer, padded to whole 1-KiB pieces
   int ts, in_bufs;   // igemm_dmaf_kernel: taps per step, input buffers (1 or 2)
+  // Per-channel sums taken from the accumulators in the epilogue (igemm_stats): partial rows
+  // stat[workgroup (x, y)][2][stat_c], folded afterwards in a fixed order.  mode 1: {sum y, sum y^2} of the produced
+  // tensor (training-mode batch-norm statistics); mode 2: the produced tensor is the gradient d of an activated
+  // slot whose raw values are `raw` and pending activation `spw`: {sum g, sum g*raw}, g = d * act'(spw(raw)) --
+  // the two sums the batch-norm backward of that slot's producer needs.
+  double* stat; int stat_c, stat_mode;
+  const float* raw; int raw_cs, raw_co, raw_vec;
+  PW spw;
 };
 
 template <int VW> struct Frag;
@@ -102,6 +110,121 @@ __device__ __forceinline__ void igemm_store(const IgemmArgs& a, const v4f (&acc)
   }
 }
 
+// Channel sums of this workgroup's output (IgemmArgs::stat).  A lane owns channels j0..j0+3 of MT (x NPH) pixels:
+// it adds them up in double (exact products, as the streaming passes do: the batch-norm backward these sums feed is
+// cancellation-dominated), the 16 lanes that share the channels (lm) are folded by shuffles, the waves that share
+// them (wm) through LDS, and one thread per channel writes the workgroup's row.  `accf(p, mt,
+// nt)` hands out the accumulators.  Fixed order throughout: the sums do not depend on scheduling.
+template <int NT, int MT, int NPH, typename AccF>
+__device__ __forceinline__ void igemm_stats(const IgemmArgs& a, AccF accf, float* smem, int n, int WM, int COB,
+                                            int wm, int wn, int lm, int kq, int co0, int qy0, int qx0, int ph0) {
+  double* red = reinterpret_cast<double*>(smem);   // [WM][COB][2]
+  const int tid = threadIdx.x;
+  __syncthreads();                                  // the main loop's LDS reads are over
+  const bool m2 = a.stat_mode == 2;
+  const float* raw_n = m2 ? a.raw + (int64_t)n * a.out_h * a.out_w * a.raw_cs + a.raw_co : nullptr;
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int jl = (wn * NT + nt) * 16 + kq * 4;
+    const int j0 = co0 + jl;
+    double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};
+    float sc[4] = {1.f, 1.f, 1.f, 1.f}, sf[4] = {0.f, 0.f, 0.f, 0.f}, sl[4] = {1.f, 1.f, 1.f, 1.f};
+    if (m2 && a.spw.scale) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ch = min(j0 + r, a.cout - 1);
+        sc[r] = a.spw.scale[ch]; sf[r] = a.spw.shift[ch]; sl[r] = a.spw.slope[ch];
+      }
+    }
+#pragma unroll
+    for (int p = 0; p < NPH; ++p) {
+      const int ph = NPH == 1 ? ph0 : p;
+      const int py = ph / a.nphase, px = ph % a.nphase;
+      const int qh = (a.out_h - py + a.OS - 1) / a.OS;
+      const int qw = (a.out_w - px + a.OS - 1) / a.OS;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const int t = wm * MT + mt;
+        const int tr = t / a.TPR, tc = t % a.TPR;
+        const int qy = qy0 + tr;
+        const int qx = qx0 + tc * 16 + lm;
+        if (qy >= qh || qx >= qw) continue;
+        const v4f v = accf(p, mt, nt);              // (channels past cout: zero weights, zero sums)
+        if (!m2) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { s1[r] += (double)v[r]; s2[r] = fma((double)v[r], (double)v[r], s2[r]); }
+        } else {
+          const int Y = py + a.OS * qy, X = px + a.OS * qx;
+          const float* rp = raw_n + ((int64_t)Y * a.out_w + X) * a.raw_cs + j0;
+          float rv[4];
+          if (a.raw_vec && j0 + 3 < a.cout) {
+            const float4 q = *reinterpret_cast<const float4*>(rp);
+            rv[0] = q.x; rv[1] = q.y; rv[2] = q.z; rv[3] = q.w;
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) rv[r] = j0 + r < a.cout ? rp[r] : 0.f;
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float tt = fmaf(rv[r], sc[r], sf[r]);
+            const float g = tt > 0.f ? v[r] : v[r] * sl[r];
+            s1[r] += (double)g; s2[r] = fma((double)g, (double)rv[r], s2[r]);
+          }
+        }
+      }
+    }
+    // fold over the 16 lanes (lm) that hold the same channels: halve the values a lane carries at every step
+    // (8 -> 4 -> 2 -> 1), so 8 exchanges of a double instead of 32; lane lm ends with value index lm >> 1
+    // (index = 4 * s + r) summed over all 16 lanes, even lanes write it.
+    double h4[4], h2[2], h1;
+    {
+      const bool up = lm & 8;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const double lo = s1[i], hi = s2[i];                        // values i (s1) and 4 + i (s2)
+        const double send = up ? lo : hi, keep = up ? hi : lo;
+        h4[i] = keep + __shfl_xor(send, 8, 16);
+      }
+    }
+    {
+      const bool up = lm & 4;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const double send = up ? h4[i] : h4[2 + i], keep = up ? h4[2 + i] : h4[i];
+        h2[i] = keep + __shfl_xor(send, 4, 16);
+      }
+    }
+    {
+      const bool up = lm & 2;
+      const double send = up ? h2[0] : h2[1], keep = up ? h2[1] : h2[0];
+      h1 = keep + __shfl_xor(send, 2, 16);
+    }
+    h1 += __shfl_xor(h1, 1, 16);
+    if ((lm & 1) == 0) {
+      const int idx = lm >> 1;                     // = 4 * s + r
+      red[(wm * COB + jl + (idx & 3)) * 2 + (idx >> 2)] = h1;
+    }
+  }
+  __syncthreads();
+  if (tid < COB && co0 + tid < a.cout) {
+    double t1 = 0.0, t2 = 0.0;
+    for (int w = 0; w < WM; ++w) { t1 += red[(w * COB + tid) * 2]; t2 += red[(w * COB + tid) * 2 + 1]; }
+    const int64_t L = (int64_t)blockIdx.y * gridDim.x + blockIdx.x;
+    a.stat[(L * 2) * a.stat_c + co0 + tid] = t1;
+    a.stat[(L * 2 + 1) * a.stat_c + co0 + tid] = t2;
+  }
+}
+
+// a workgroup with nothing to produce still owns a row of the partial sums
+__device__ __forceinline__ void igemm_stats_zero(const IgemmArgs& a, int COB, int co0) {
+  const int tid = threadIdx.x;
+  if (tid < COB && co0 + tid < a.cout) {
+    const int64_t L = (int64_t)blockIdx.y * gridDim.x + blockIdx.x;
+    a.stat[(L * 2) * a.stat_c + co0 + tid] = 0.0;
+    a.stat[(L * 2 + 1) * a.stat_c + co0 + tid] = 0.0;
+  }
+}
+
 // XCD-aware workgroup -> (tile, image x phase) mapping.  Workgroups are dealt to the 8 XCDs round-robin by
 // linear id, and each XCD has its own L2: with the natural order the tiles of one image (which share halo rows
 // and columns) land on 8 different L2s and every halo is fetched from HBM once per XCD.  Here XCD x works through
@@ -146,7 +269,10 @@ __global__ __launch_bounds__(256, (MT == 4 && NT == 4) ? 4 : 1) void igemm_kerne
   // phase grid extents
   const int qh = (a.out_h - py + a.OS - 1) / a.OS;
   const int qw = a.PP > 1 ? (a.out_w + a.PP - 1) / a.PP : (a.out_w - px + a.OS - 1) / a.OS;   // groups
-  if (qy0 >= qh || qx0 >= qw) return;  // uniform per block
+  if (qy0 >= qh || qx0 >= qw) {        // uniform per block
+    if (a.stat) igemm_stats_zero(a, COB, co0);
+    return;
+  }
 
   int iy0, ix0;
   if (a.transposed) {
@@ -282,6 +408,9 @@ __global__ __launch_bounds__(256, (MT == 4 && NT == 4) ? 4 : 1) void igemm_kerne
   // channels of one pixel, which is one 16-byte store in NHWC.
   float* out_n = a.out + (int64_t)n * a.out_h * a.out_w * a.out_cs + a.out_co;
   igemm_store<NT, MT>(a, acc, out_n, wm, wn, lm, kq, co0, qy0, qx0, qh, qw, py, px);
+  if (a.stat)
+    igemm_stats<NT, MT, 1>(a, [&](int, int mt, int nt) { return acc[mt][nt]; }, smem, n, WM, COB, wm, wn, lm, kq, co0,
+                           qy0, qx0, ph);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -329,7 +458,10 @@ __global__ __launch_bounds__(64 * NW, NT == 4 ? ((WN == 2 && (SLOTS == 3 || NW =
   const int qy0 = tile_y * a.BH, qx0 = tile_x * BW;
   const int qh = (a.out_h - py + a.OS - 1) / a.OS;
   const int qw = (a.out_w - px + a.OS - 1) / a.OS;
-  if (qy0 >= qh || qx0 >= qw) return;  // uniform per block
+  if (qy0 >= qh || qx0 >= qw) {        // uniform per block
+    if (a.stat) igemm_stats_zero(a, COB, co0);
+    return;
+  }
 
   int iy0, ix0;
   if (a.transposed) {
@@ -477,6 +609,9 @@ __global__ __launch_bounds__(64 * NW, NT == 4 ? ((WN == 2 && (SLOTS == 3 || NW =
 
   float* out_n = a.out + (int64_t)n * a.out_h * a.out_w * a.out_cs + a.out_co;
   igemm_store<NT, MT>(a, acc, out_n, wm, wn, lm, kq, co0, qy0, qx0, qh, qw, py, px);
+  if (a.stat)
+    igemm_stats<NT, MT, 1>(a, [&](int, int mt, int nt) { return acc[mt][nt]; }, smem, n, WM, COB, wm, wn, lm, kq, co0,
+                           qy0, qx0, ph);
 }
 
 
@@ -524,7 +659,10 @@ __global__ __launch_bounds__(256, 2) void igemm_dmaf_kernel(IgemmArgs a) {
     // extents of the (largest) phase grid this workgroup works on
     const int qh = (a.out_h - py0 + a.OS - 1) / a.OS;
     const int qw = a.PP > 1 ? (a.out_w + a.PP - 1) / a.PP : (a.out_w - px0 + a.OS - 1) / a.OS;
-    if (qy0 >= qh || qx0 >= qw) return;  // uniform per block
+    if (qy0 >= qh || qx0 >= qw) {        // uniform per block
+    if (a.stat) igemm_stats_zero(a, COB, co0);
+    return;
+  }
   }
 
   // origin of the staged tile: the first gathered row/column of phase (py0, px0) -- with fused phases that is
@@ -696,6 +834,9 @@ __global__ __launch_bounds__(256, 2) void igemm_dmaf_kernel(IgemmArgs a) {
     const int qw = a.PP > 1 ? (a.out_w + a.PP - 1) / a.PP : (a.out_w - px + a.OS - 1) / a.OS;
     igemm_store<NT, MT>(a, acc[p], out_n, wm, 0, lm, kq, co0, qy0, qx0, qh, qw, py, px);
   }
+  if (a.stat)
+    igemm_stats<NT, MT, NPH>(a, [&](int p, int mt, int nt) { return acc[p][mt][nt]; }, smem, n, 4, COB, wm, 0, lm, kq,
+                             co0, qy0, qx0, ph0);
 }
 
 // weights: torch layout -> [phase][ty][tx][chunk][cout_padP][CC]
@@ -754,6 +895,34 @@ __global__ __launch_bounds__(256) void pack_jobs_kernel(const PackArgs* jobs, co
   pack_element(a, (b - first_block[lo]) * 256 + threadIdx.x);
 }
 
+// First fold of the epilogue statistics: rows [b*R, (b+1)*R) of partial[rows][n] -> out[b][n].  A workgroup's rows
+// are one contiguous range, read with unit stride; n is a power of two (<= 1024), so a thread meets a fixed set of
+// n/256 (or one) columns.  bp_sum_partials folds the <= 256 rows that remain.
+__global__ __launch_bounds__(256) void stats_fold_kernel(const double* partial, int64_t rows, int64_t R, int n, double* out) {
+  __shared__ double sh[256];
+  const int tid = threadIdx.x;
+  const int64_t r0 = (int64_t)blockIdx.x * R;
+  int64_t r1 = r0 + R;
+  if (r1 > rows) r1 = rows;
+  const double* src = partial + r0 * n;
+  const int64_t total = (r1 - r0) * n;
+  const int NA = n > 256 ? n / 256 : 1;
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};
+  int64_t e = tid;
+  for (int64_t k = 0; e < total; ++k, e += 256) acc[k & (NA - 1)] += src[e];
+  if (n >= 256) {
+    for (int q = 0; q < NA; ++q) out[(int64_t)blockIdx.x * n + q * 256 + tid] = acc[q];
+    return;
+  }
+  sh[tid] = acc[0];
+  __syncthreads();
+  if (tid < n) {
+    double t = 0.0;
+    for (int i = tid; i < 256; i += n) t += sh[i];
+    out[(int64_t)blockIdx.x * n + tid] = t;
+  }
+}
+
 // Spatial tile of one workgroup and the halo it gathers.
 struct TileGeom {
   int TPR, BH, IH, IW, IWq;
@@ -798,7 +967,10 @@ IgemmConfig igemm_config(const ConvGeom& g) {
   // Few produced channels on a unit-stride grid: pack PP neighbouring pixels into the 16 MFMA columns
   // (column = (pixel-in-group, channel)); costs PP-1 extra taps along x, saves a factor PP of M tiles.
   c.PP = 1; c.COP = 16; c.tapsx = g.taps; c.ISx = g.IS;
-  if (g.cout_g <= 8 && g.IS == 1 && g.OS == 1 && g.nphase == 1) {
+  // (not with many gathered channels: the PP-1 extra taps multiply a long K, and the halo forces narrow chunks --
+  // the 64->2 and 32->2 k5 latent heads at 16x16 ran 4x slower packed)
+  static const int pp_max_cin = getenv("BP_IGEMM_PPCIN") ? atoi(getenv("BP_IGEMM_PPCIN")) : 16;
+  if (g.cout_g <= 8 && g.IS == 1 && g.OS == 1 && g.nphase == 1 && g.cin_g <= pp_max_cin) {
     c.COP = g.cout_g <= 1 ? 1 : (g.cout_g <= 2 ? 2 : (g.cout_g <= 4 ? 4 : 8));
     c.PP = 16 / c.COP;
     c.tapsx = g.taps + c.PP - 1;
@@ -815,7 +987,8 @@ IgemmConfig igemm_config(const ConvGeom& g) {
   static const bool no_dma = getenv("BP_IGEMM_NODMA") != nullptr;
   static const bool no_nw8 = getenv("BP_IGEMM_NONW8") != nullptr;
   static const bool no_dmaf = getenv("BP_IGEMM_NODMAF") != nullptr;
-  if (c.NT <= 2 && c.PP == 1 && !no_dma && !no_dmaf) {   // (pixel-packed heads measured slower here)
+  static const int pp_dma = getenv("BP_IGEMM_PPDMA") ? atoi(getenv("BP_IGEMM_PPDMA")) : 1;
+  if (c.NT <= 2 && c.PP <= pp_dma && !no_dma && !no_dmaf) {   // (pixel-packed heads measured slower here)
     const int T = g.taps * c.tapsx;
     for (int CC = cc_first; CC >= 8 && !c.dma; CC /= 2) {
       if (g.cin_g % CC != 0 || (c.COB * CC) % 256 != 0) continue;
@@ -979,13 +1152,23 @@ int bp_small_pack(const ConvGeom& g, const WeightMap& wm, const float* w_torch, 
 int bp_small_run(const ConvGeom& g, const bp_view* in, const PW& pw, const float* packed, const float* bias,
                  const bp_view* out, hipStream_t st);
 
+// conv_stem.hip: the 3 -> 16 k5 stem (flattened (tap column, channel) K, weights in registers)
+bool bp_stem_ok(const ConvGeom& g);
+int64_t bp_stem_packed_floats();
+int bp_stem_pack(const WeightMap& wm, const float* w_torch, float* packed, hipStream_t st);
+size_t bp_stem_stats_workspace(const bp_view* out);
+int bp_stem_run(const bp_view* in, const PW& pw, const float* packed, const float* bias, const bp_view* out,
+                hipStream_t st, const IgemmStatsReq* sr);
+
 int bp_igemm_kernel_id(const ConvGeom& g) {
+  if (bp_stem_ok(g)) return 700000;
   if (bp_small_ok(g)) return bp_small_kernel_id(g);
   const IgemmConfig c = igemm_config(g);
   return c.ok ? (c.dma ? 100000 * (c.dmaf ? 3 : c.NW / 4) : 0) + c.CC * 1000 + c.NT * 100 + c.WN * 10 + c.MT : -1;
 }
 
 int64_t bp_igemm_packed_floats(const ConvGeom& g) {
+  if (bp_stem_ok(g)) return bp_stem_packed_floats();
   if (bp_small_ok(g)) return bp_small_packed_floats(g);
   const IgemmConfig c = igemm_config(g);
   if (!c.ok) return -1;
@@ -1006,6 +1189,7 @@ static bool igemm_pack_args(const ConvGeom& g, const WeightMap& wm, const float*
 
 int bp_igemm_pack(const ConvGeom& g, const WeightMap& wm, const float* w_torch, float* packed,
                   hipStream_t st) {
+  if (bp_stem_ok(g)) return bp_stem_pack(wm, w_torch, packed, st);
   if (bp_small_ok(g)) return bp_small_pack(g, wm, w_torch, packed, st);
   PackArgs a;
   if (!igemm_pack_args(g, wm, w_torch, packed, a)) return BP_EUNSUPPORTED;
@@ -1019,7 +1203,7 @@ size_t bp_igemm_pack_job_bytes() { return sizeof(PackArgs); }
 
 int bp_igemm_pack_job(const ConvGeom& g, const WeightMap& wm, const float* w_torch, float* packed, void* job,
                       int64_t* nblocks) {
-  if (bp_small_ok(g)) return BP_EUNSUPPORTED;       // (its own tiny pack kernel: packed by bp_conv_pack)
+  if (bp_stem_ok(g) || bp_small_ok(g)) return BP_EUNSUPPORTED;       // (their own tiny pack kernels: packed by bp_conv_pack)
   PackArgs a;
   if (!igemm_pack_args(g, wm, w_torch, packed, a)) return BP_EUNSUPPORTED;
   *reinterpret_cast<PackArgs*>(job) = a;
@@ -1036,11 +1220,56 @@ int bp_igemm_pack_jobs(const void* jobs_dev, const int64_t* first_block_dev, int
   return BP_OK;
 }
 
+// Launch shape of a layer on these views: which kernel family, its tile and its grid.
+struct IgemmLaunch { bool dma; TileGeom t; dim3 grid; int vec_ok, out_vec; size_t lds; int WM; };
+static bool igemm_launch_of(const ConvGeom& g, const IgemmConfig& c, const bp_view* in, const bp_view* out, IgemmLaunch& l) {
+  l.vec_ok = (in->cstride % 4 == 0 && in->coff % 4 == 0 && (reinterpret_cast<uintptr_t>(in->ptr) % 16 == 0)) ? 1 : 0;
+  l.out_vec = (out->cstride % 4 == 0 && out->coff % 4 == 0 && reinterpret_cast<uintptr_t>(out->ptr) % 16 == 0) ? 1 : 0;
+  l.dma = c.dma && l.vec_ok;
+  l.t = l.dma ? c.td : c.t;
+  const int qh = bp_ceil_div(out->h, g.OS), qw = c.PP > 1 ? bp_ceil_div(out->w, c.PP) : bp_ceil_div(out->w, g.OS);
+  const int tiles_x = bp_ceil_div(qw, 16 * l.t.TPR), tiles_y = bp_ceil_div(qh, l.t.BH);
+  const int64_t gz = (int64_t)in->n * ((l.dma && c.dmaf && c.nph > 1) ? 1 : g.nphase * g.nphase);
+  if (gz > 65535 || c.cout_padP / c.COB > 65535) return false;
+  l.grid = dim3((unsigned)(tiles_x * tiles_y), (unsigned)gz, (unsigned)(c.cout_padP / c.COB));
+  l.lds = l.dma ? c.lds_dma : c.lds_bytes;
+  l.WM = l.dma ? (c.dmaf ? 4 : c.NW / c.WN) : 4 / c.WN;
+  return true;
+}
+
+// Epilogue statistics (IgemmArgs::stat): partial rows, their first fold, and whether this layer's kernel has them.
+struct StatsPlan { int64_t rows; int n; int nfold; int64_t R; size_t bytes; };
+static bool stats_plan(const ConvGeom& g, const IgemmConfig& c, const IgemmLaunch& l, StatsPlan& p) {
+  const int C = g.cout_g;
+  if (c.PP != 1 || C <= 0 || (C & (C - 1)) != 0 || C > 512) return false;
+  if ((size_t)l.WM * c.COB * 2 * sizeof(double) > l.lds) return false;
+  p.rows = (int64_t)l.grid.x * l.grid.y;
+  p.n = 2 * C;
+  p.nfold = p.rows <= 128 ? 0 : (int)(p.rows / 32 < 256 ? (p.rows + 31) / 32 : 256);
+  p.R = p.nfold ? (p.rows + p.nfold - 1) / p.nfold : 0;
+  if (p.nfold) p.nfold = (int)((p.rows + p.R - 1) / p.R);
+  p.bytes = (size_t)(p.rows + p.nfold) * p.n * sizeof(double);
+  return true;
+}
+
+size_t bp_igemm_stats_workspace(const ConvGeom& g, const bp_view* in, const bp_view* out) {
+  if (bp_stem_ok(g)) return bp_stem_stats_workspace(out);
+  if (bp_small_ok(g)) return 0;
+  const IgemmConfig c = igemm_config(g);
+  IgemmLaunch l;
+  StatsPlan p;
+  if (!c.ok || !igemm_launch_of(g, c, in, out, l) || !stats_plan(g, c, l, p)) return 0;
+  return p.bytes;
+}
+
 int bp_igemm_run(const ConvGeom& g, const bp_view* in, const PW& pw, const float* packed,
-                 const float* bias, const bp_view* out, hipStream_t st) {
-  if (bp_small_ok(g)) return bp_small_run(g, in, pw, packed, bias, out, st);
+                 const float* bias, const bp_view* out, hipStream_t st, const IgemmStatsReq* sr) {
+  if (bp_stem_ok(g)) return bp_stem_run(in, pw, packed, bias, out, st, sr);
+  if (bp_small_ok(g)) return sr ? BP_EUNSUPPORTED : bp_small_run(g, in, pw, packed, bias, out, st);
   const IgemmConfig c = igemm_config(g);
   if (!c.ok) return BP_EUNSUPPORTED;
+  IgemmLaunch l;
+  if (!igemm_launch_of(g, c, in, out, l)) return BP_EUNSUPPORTED;
   IgemmArgs a{};
   a.in = in->ptr; a.in_h = in->h; a.in_w = in->w; a.in_cs = in->cstride; a.in_co = in->coff; a.cin = g.cin_g;
   a.out = out->ptr; a.out_h = out->h; a.out_w = out->w; a.out_cs = out->cstride; a.out_co = out->coff;
@@ -1049,22 +1278,39 @@ int bp_igemm_run(const ConvGeom& g, const bp_view* in, const PW& pw, const float
   a.transposed = g.gather_transposed; a.PP = c.PP; a.COP = c.COP;
   a.stride = g.stride; a.pad = g.pad;
   a.nchunk = c.nchunk; a.cout_padP = c.cout_padP;
-  a.vec_ok = (in->cstride % 4 == 0 && in->coff % 4 == 0 &&
-              (reinterpret_cast<uintptr_t>(in->ptr) % 16 == 0)) ? 1 : 0;
-  a.out_vec = (out->cstride % 4 == 0 && out->coff % 4 == 0 && reinterpret_cast<uintptr_t>(out->ptr) % 16 == 0) ? 1 : 0;
-  const bool dma = c.dma && a.vec_ok;
-  const TileGeom& t = dma ? c.td : c.t;
+  a.vec_ok = l.vec_ok; a.out_vec = l.out_vec;
+  const bool dma = l.dma;
+  const TileGeom& t = l.t;
   a.TPR = t.TPR; a.BH = t.BH; a.IH = t.IH; a.IW = t.IW; a.IWq = t.IWq;
   const int qh = bp_ceil_div(out->h, g.OS), qw = c.PP > 1 ? bp_ceil_div(out->w, c.PP) : bp_ceil_div(out->w, g.OS);
   a.tiles_x = bp_ceil_div(qw, 16 * t.TPR);
   a.tiles_y = bp_ceil_div(qh, t.BH);
-  const int64_t gz = (int64_t)in->n * ((dma && c.dmaf && c.nph > 1) ? 1 : g.nphase * g.nphase);
-  if (gz > 65535 || c.cout_padP / c.COB > 65535) return BP_EUNSUPPORTED;
-  dim3 grid((unsigned)(a.tiles_x * a.tiles_y), (unsigned)gz, (unsigned)(c.cout_padP / c.COB));
+  const dim3 grid = l.grid;
   a.in_pad4 = c.in_pad4; a.ts = c.ts; a.in_bufs = c.in_bufs;
-  if (dma && c.dmaf) return launch_dmaf(c, a, grid, st);
-  if (dma) return launch_dma(c, a, grid, st);
-  if (c.MT == 4) return launch_mt<4>(c, a, grid, st);
-  return launch_mt<1>(c, a, grid, st);
+  StatsPlan sp{};
+  if (sr) {
+    if (bias || !stats_plan(g, c, l, sp)) return BP_EUNSUPPORTED;
+    if (!sr->ws || sr->ws_bytes < sp.bytes || !sr->sums) return BP_EWORKSPACE;
+    a.stat = reinterpret_cast<double*>(sr->ws); a.stat_c = g.cout_g; a.stat_mode = sr->mode;
+    if (sr->mode == 2) {
+      const bp_view* r = sr->raw;
+      a.raw = r->ptr; a.raw_cs = r->cstride; a.raw_co = r->coff; a.spw = sr->spw;
+      a.raw_vec = (r->cstride % 4 == 0 && r->coff % 4 == 0 && reinterpret_cast<uintptr_t>(r->ptr) % 16 == 0) ? 1 : 0;
+    }
+  }
+  int rc;
+  if (dma && c.dmaf) rc = launch_dmaf(c, a, grid, st);
+  else if (dma) rc = launch_dma(c, a, grid, st);
+  else if (c.MT == 4) rc = launch_mt<4>(c, a, grid, st);
+  else rc = launch_mt<1>(c, a, grid, st);
+  if (rc != BP_OK || !sr) return rc;
+  const double* rows = a.stat;
+  int64_t nrows = sp.rows;
+  if (sp.nfold) {
+    double* folded = a.stat + sp.rows * sp.n;
+    hipLaunchKernelGGL(stats_fold_kernel, dim3((unsigned)sp.nfold), dim3(256), 0, st, rows, sp.rows, sp.R, sp.n, folded);
+    BP_CHECK_LAUNCH();
+    rows = folded; nrows = sp.nfold;
+  }
+  return bp_sum_partials(rows, (int)nrows, sp.n, sr->sums, st);
 }
-

@@ -141,6 +141,159 @@ __global__ __launch_bounds__(256) void small_conv_kernel(SmallArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Strided layers with one or two channels on one side (the 512^2 ends of the recognition / prior networks:
+// Conv2d k4s2 {1,2}->8; the latent up-sampler ConvTranspose2d k8s4 / k4s2 1->1 and its data gradient).  A matrix
+// tile would be > 90 % padding and the layers are a few hundred MB of HBM traffic with almost no arithmetic, so:
+// one thread per produced pixel, all of its channels in registers, operands straight from global memory (every
+// input value is used by (K/S)^2 neighbouring threads: the vector L1 serves the re-reads), weights from scalar
+// loads (gather form) or a 1-KiB table in L1 (transposed form, where the tap set depends on the pixel's phase).
+struct TinyArgs {
+  const float* in; int in_h, in_w, in_cs, in_co;
+  float* out; int out_h, out_w, out_cs, out_co;
+  const float* wp; const float* bias;
+  PW pw;
+  int pad;
+  int64_t total;   // produced pixels per image
+  int n;
+};
+
+// gather form: out[y, x, :] = sum_{ty,tx,ci} act(in[S*y - pad + ty, S*x - pad + tx, ci]) * wp[ty][tx][ci][:]
+template <int K, int S, int CI, int CO>
+__global__ __launch_bounds__(256) void tiny_gather_kernel(TinyArgs a) {
+  const unsigned i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= (unsigned)a.total) return;
+  const int x = i % (unsigned)a.out_w;
+  const int y = i / (unsigned)a.out_w;
+  const int n = blockIdx.y;
+  const float* in_n = a.in + (int64_t)n * a.in_h * a.in_w * a.in_cs + a.in_co;
+  float acc[CO];
+#pragma unroll
+  for (int co = 0; co < CO; ++co) acc[co] = a.bias ? a.bias[co] : 0.f;
+  float sc[CI], sf[CI], sl[CI];
+  const bool pw_on = a.pw.scale != nullptr;
+#pragma unroll
+  for (int ci = 0; ci < CI; ++ci) {
+    sc[ci] = pw_on ? a.pw.scale[ci] : 1.f; sf[ci] = pw_on ? a.pw.shift[ci] : 0.f; sl[ci] = pw_on ? a.pw.slope[ci] : 1.f;
+  }
+  const int iy0 = S * y - a.pad, ix0 = S * x - a.pad;
+  const bool vec2 = CI == 2 && a.in_cs % 2 == 0 && a.in_co % 2 == 0 && (reinterpret_cast<uintptr_t>(a.in) & 7) == 0;
+#pragma unroll
+  for (int ty = 0; ty < K; ++ty) {
+    const int iy = iy0 + ty;
+    const bool yin = iy >= 0 && iy < a.in_h;
+    const float* row = in_n + (int64_t)iy * a.in_w * a.in_cs;
+#pragma unroll
+    for (int tx = 0; tx < K; ++tx) {
+      const int ix = ix0 + tx;
+      const bool in = yin && ix >= 0 && ix < a.in_w;
+      float vin[CI];
+#pragma unroll
+      for (int ci = 0; ci < CI; ++ci) vin[ci] = 0.f;
+      if (in) {
+        if (CI == 2 && vec2) {
+          const float2 q = *reinterpret_cast<const float2*>(row + ix * a.in_cs);
+          vin[0] = q.x; vin[CI - 1] = q.y;
+        } else {
+#pragma unroll
+          for (int ci = 0; ci < CI; ++ci) vin[ci] = row[ix * a.in_cs + ci];
+        }
+      }
+#pragma unroll
+      for (int ci = 0; ci < CI; ++ci) {
+        float v = vin[ci];
+        if (in && pw_on) { const float t = fmaf(v, sc[ci], sf[ci]); v = t > 0.f ? t : t * sl[ci]; }
+#pragma unroll
+        for (int co = 0; co < CO; ++co) acc[co] = fmaf(v, a.wp[((ty * K + tx) * CI + ci) * CO + co], acc[co]);
+      }
+    }
+  }
+  float* o = a.out + (((int64_t)n * a.out_h + y) * a.out_w + x) * a.out_cs + a.out_co;
+  if (CO % 4 == 0 && a.out_cs % 4 == 0 && a.out_co % 4 == 0 && (reinterpret_cast<uintptr_t>(a.out) & 15) == 0) {
+#pragma unroll
+    for (int q = 0; q < CO / 4; ++q)
+      *reinterpret_cast<float4*>(o + 4 * q) = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+  } else {
+#pragma unroll
+    for (int co = 0; co < CO; ++co) o[co] = acc[co];
+  }
+}
+
+// transposed form: out[Y, X, :] = sum_{j,i,ci} act(in[(Y+pad)/S - j, (X+pad)/S - i, ci]) * wp[ry + S*j][rx + S*i][ci][:],
+// r = (Y+pad) % S: K/S taps per dimension.
+template <int K, int S, int CI, int CO>
+__global__ __launch_bounds__(256) void tiny_transposed_kernel(TinyArgs a) {
+  const unsigned i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= (unsigned)a.total) return;
+  constexpr int T = K / S;
+  const int X = i % (unsigned)a.out_w;
+  const int Y = i / (unsigned)a.out_w;
+  const int n = blockIdx.y;
+  const float* in_n = a.in + (int64_t)n * a.in_h * a.in_w * a.in_cs + a.in_co;
+  float acc[CO];
+#pragma unroll
+  for (int co = 0; co < CO; ++co) acc[co] = a.bias ? a.bias[co] : 0.f;
+  const bool pw_on = a.pw.scale != nullptr;
+  const int qy = (Y + a.pad) / S, ry = (Y + a.pad) % S;
+  const int qx = (X + a.pad) / S, rx = (X + a.pad) % S;
+#pragma unroll
+  for (int j = 0; j < T; ++j) {
+    const int iy = qy - j;
+    const bool yin = iy >= 0 && iy < a.in_h;
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      const int ix = qx - t;
+      if (!(yin && ix >= 0 && ix < a.in_w)) continue;
+      const float* p = in_n + ((int64_t)iy * a.in_w + ix) * a.in_cs;
+      const float* w = a.wp + (((ry + S * j) * K + rx + S * t) * CI) * CO;
+#pragma unroll
+      for (int ci = 0; ci < CI; ++ci) {
+        float v = p[ci];
+        if (pw_on) { const float tt = fmaf(v, a.pw.scale[ci], a.pw.shift[ci]); v = tt > 0.f ? tt : tt * a.pw.slope[ci]; }
+#pragma unroll
+        for (int co = 0; co < CO; ++co) acc[co] = fmaf(v, w[ci * CO + co], acc[co]);
+      }
+    }
+  }
+  float* o = a.out + (((int64_t)n * a.out_h + Y) * a.out_w + X) * a.out_cs + a.out_co;
+#pragma unroll
+  for (int co = 0; co < CO; ++co) o[co] = acc[co];
+}
+
+template <int K, int S, int CI, int CO>
+int launch_tiny(const TinyArgs& a, bool transposed, hipStream_t st) {
+  const dim3 grid((unsigned)((a.total + 255) / 256), (unsigned)a.n);
+  if (transposed) hipLaunchKernelGGL((tiny_transposed_kernel<K, S, CI, CO>), grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((tiny_gather_kernel<K, S, CI, CO>), grid, dim3(256), 0, st, a);
+  BP_CHECK_LAUNCH();
+  return BP_OK;
+}
+
+bool tiny_ok(const ConvGeom& g) {
+  static const bool off = getenv("BP_NOTINY") != nullptr;
+  if (off || g.stride < 2) return false;
+  const bool ks = (g.k == 4 && g.stride == 2) || (g.k == 8 && g.stride == 4);
+  if (!ks) return false;
+  if (g.gather_transposed) return g.cin_g == 1 && g.cout_g == 1;
+  return (g.cin_g == 1 && g.cout_g == 1) || (g.k == 4 && g.cin_g <= 2 && g.cout_g == 8);
+}
+
+int tiny_run(const ConvGeom& g, const bp_view* in, const PW& pw, const float* packed, const float* bias,
+             const bp_view* out, hipStream_t st) {
+  TinyArgs a{};
+  a.in = in->ptr; a.in_h = in->h; a.in_w = in->w; a.in_cs = in->cstride; a.in_co = in->coff;
+  a.out = out->ptr; a.out_h = out->h; a.out_w = out->w; a.out_cs = out->cstride; a.out_co = out->coff;
+  a.wp = packed; a.bias = bias; a.pw = pw; a.pad = g.pad;
+  a.total = (int64_t)out->h * out->w; a.n = out->n;
+  if (a.total > 0x7fffff00LL || out->n > 65535) return BP_EUNSUPPORTED;
+  const bool tr = g.gather_transposed != 0;
+  if (g.k == 4 && g.cin_g == 1 && g.cout_g == 1) return launch_tiny<4, 2, 1, 1>(a, tr, st);
+  if (g.k == 8 && g.cin_g == 1 && g.cout_g == 1) return launch_tiny<8, 4, 1, 1>(a, tr, st);
+  if (g.k == 4 && g.cin_g == 1 && g.cout_g == 8 && !tr) return launch_tiny<4, 2, 1, 8>(a, tr, st);
+  if (g.k == 4 && g.cin_g == 2 && g.cout_g == 8 && !tr) return launch_tiny<4, 2, 2, 8>(a, tr, st);
+  return BP_EUNSUPPORTED;
+}
+
 struct SmallPackArgs {
   const float* w; float* dst;
   int64_t sa, sb;
@@ -173,6 +326,7 @@ int launch(SmallArgs a, const bp_view* out, int n, hipStream_t st) {
 // Does (k, gathered channels, produced channels) of this unit-stride correlation have an instantiation?
 bool bp_small_ok(const ConvGeom& g) {
   static const bool off = getenv("BP_NOSMALL") != nullptr;
+  if (!off && tiny_ok(g)) return true;
   if (off || g.IS != 1 || g.OS != 1 || g.nphase != 1 || g.stride != 1) return false;
   return (g.k == 5 && g.cin_g == 8 && g.cout_g == 1) || (g.k == 5 && g.cin_g == 1 && g.cout_g == 8) ||
          (g.k == 5 && g.cin_g == 16 && g.cout_g == 1) || (g.k == 3 && g.cin_g == 1 && g.cout_g == 1) ||
@@ -182,12 +336,16 @@ bool bp_small_ok(const ConvGeom& g) {
 
 int64_t bp_small_packed_floats(const ConvGeom& g) { return (int64_t)g.k * g.k * g.cin_g * g.cout_g; }
 
-int bp_small_kernel_id(const ConvGeom& g) { return 900000 + g.k * 1000 + g.cin_g * 10 + g.cout_g; }
+int bp_small_kernel_id(const ConvGeom& g) {
+  if (tiny_ok(g)) return 800000 + g.k * 10000 + g.stride * 1000 + g.cin_g * 100 + g.cout_g * 10 + g.gather_transposed;
+  return 900000 + g.k * 1000 + g.cin_g * 10 + g.cout_g;
+}
 
 int bp_small_pack(const ConvGeom& g, const WeightMap& wm, const float* w_torch, float* packed, hipStream_t st) {
   SmallPackArgs a{};
   a.w = w_torch; a.dst = packed; a.sa = wm.sa; a.sb = wm.sb;
-  a.k = g.k; a.ci = g.cin_g; a.co = g.cout_g; a.flip = g.gather_transposed;
+  a.k = g.k; a.ci = g.cin_g; a.co = g.cout_g;
+  a.flip = tiny_ok(g) ? 0 : g.gather_transposed;       // (the strided kernels index taps by the torch (ky, kx))
   a.total = (int)bp_small_packed_floats(g);
   hipLaunchKernelGGL(small_pack_kernel, dim3((unsigned)((a.total + 255) / 256)), dim3(256), 0, st, a);
   BP_CHECK_LAUNCH();
@@ -196,6 +354,7 @@ int bp_small_pack(const ConvGeom& g, const WeightMap& wm, const float* w_torch, 
 
 int bp_small_run(const ConvGeom& g, const bp_view* in, const PW& pw, const float* packed, const float* bias,
                  const bp_view* out, hipStream_t st) {
+  if (tiny_ok(g)) return tiny_run(g, in, pw, packed, bias, out, st);
   SmallArgs a{};
   a.in = in->ptr; a.in_h = in->h; a.in_w = in->w; a.in_cs = in->cstride; a.in_co = in->coff;
   a.out = out->ptr; a.out_h = out->h; a.out_w = out->w; a.out_cs = out->cstride; a.out_co = out->coff;

@@ -292,7 +292,23 @@ int bp_wgrad_bf16_run(const bp_conv* cv, const bp_view* X, const PW& pwx, const 
   return wgrad_reduce(reinterpret_cast<const float*>(workspace), dst, cv->k, X->c, Y->c, cxp, cyp, ns, st);
 }
 
+// conv_stem.hip: weight gradient of the 3 -> 16 k5 stem
+bool bp_stem_wgrad_ok(const bp_conv* cv, const bp_view* X, const bp_view* Y, const PW& pwy, const float* dbias);
+size_t bp_stem_wgrad_workspace(const bp_view* X);
+int bp_stem_wgrad(const bp_view* X, const PW& pwx, const bp_view* Y, float* dst, void* workspace, size_t workspace_bytes,
+                  hipStream_t st);
+static size_t wgrad_general_workspace(const bp_conv* cv, const bp_view* X, const bp_view* Y);
+
 size_t bp_wgrad_mfma_workspace(const bp_conv* cv, const bp_view* X, const bp_view* Y) {
+  const size_t general = wgrad_general_workspace(cv, X, Y);
+  if (bp_stem_wgrad_ok(cv, X, Y, PW{nullptr, nullptr, nullptr}, nullptr)) {
+    const size_t stem = bp_stem_wgrad_workspace(X);
+    return stem > general ? stem : general;
+  }
+  return general;
+}
+
+static size_t wgrad_general_workspace(const bp_conv* cv, const bp_view* X, const bp_view* Y) {
   size_t need = 0;
   int ns, cxp, cyp;
   const PW none{nullptr, nullptr, nullptr};
@@ -307,6 +323,7 @@ size_t bp_wgrad_mfma_workspace(const bp_conv* cv, const bp_view* X, const bp_vie
 
 int bp_wgrad_mfma(const bp_conv* cv, const bp_view* X, const PW& pwx, const bp_view* Y, const PW& pwy,
                   float* dst, void* workspace, size_t workspace_bytes, hipStream_t st) {
+  if (bp_stem_wgrad_ok(cv, X, Y, pwy, nullptr)) return bp_stem_wgrad(X, pwx, Y, dst, workspace, workspace_bytes, st);
   {
     bool on_x = false;
     if (wide_side_chunks(cv, X, Y, &on_x)) {

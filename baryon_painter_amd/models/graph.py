@@ -14,10 +14,18 @@ Conventions
     producer's backward adds while it applies the activation derivative.
 """
 import ctypes as C
+import os
 
 import torch
 
 from .. import _lib as L
+
+
+# BP_EPILOGUE_STATS=0: batch-norm sums by separate streaming passes (bp_channel_sums / bp_act_backward) everywhere;
+# "fwd" / "bwd": only the forward statistics / only the backward sums from the convolution epilogues
+_ES = os.environ.get("BP_EPILOGUE_STATS", "fwd")
+EPILOGUE_STATS = _ES != "0"
+EPILOGUE_FWD, EPILOGUE_BWD = _ES in ("1", "fwd"), _ES in ("1", "bwd")
 
 
 def _stream():
@@ -315,6 +323,19 @@ class ConvUnit:
         self.dgrad_slice = None        # (c0, c1): only these input channels need a gradient
         self._sub = None
         plan.need_ws(lib.bp_channel_sums_workspace(C.byref(self.out.view)))
+        # Batch-norm statistics out of the convolution's own epilogue (bp_conv_forward_stats) instead of a streaming
+        # pass over the tensor it just wrote; the same for the two sums of a producer's batch-norm backward, taken
+        # in this layer's data-gradient epilogue (bp_conv_backward_data_stats, decided at the first backward).
+        self.out.producer = self
+        self.fwd_stats = False
+        self._fused_producer = None          # None: undecided; False: separate pass; a ConvUnit: fused
+        self._sums_ready = False             # a consumer's data gradient has already filled self.sums
+        if EPILOGUE_FWD and bn is not None and not self.bf16 and holder.bias is None and self.out.dt == L.F32 \
+                and self._impl("fwd") in (L.IMPL_AUTO, L.IMPL_MFMA):
+            nb = lib.bp_conv_stats_workspace(C.byref(cv), L.PACK_FWD, C.byref(inp.view), C.byref(self.out.view))
+            if nb > 0:
+                self.fwd_stats = True
+                plan.need_ws(nb)
 
     def restrict_dgrad(self, c0, c1):
         """Only input channels [c0, c1) carry a gradient (the rest of a concatenated input is data): the data
@@ -411,11 +432,17 @@ class ConvUnit:
         plan, lib, st = self.plan, self.plan.lib, _stream()
         self.maybe_pack()
         hold = self.holder
+        fused = training and self.fwd_stats
         t0 = plan.prof_begin()
-        L.check(lib.bp_conv_forward(C.byref(self.cv), C.byref(self.inp.view), self.inp.pw_struct(),
-                                    L.ptr(self.packed_fwd), L.ptr(hold.weight), L.ptr(hold.bias),
-                                    C.byref(self.out.view), self._impl("fwd"), st),
-                f"{self.name} forward")
+        if fused:
+            L.check(lib.bp_conv_forward_stats(C.byref(self.cv), C.byref(self.inp.view), self.inp.pw_struct(),
+                                              L.ptr(self.packed_fwd), C.byref(self.out.view), L.ptr(self.sums),
+                                              L.ptr(self._ws()), plan.ws_bytes, st), f"{self.name} forward + bn stats")
+        else:
+            L.check(lib.bp_conv_forward(C.byref(self.cv), C.byref(self.inp.view), self.inp.pw_struct(),
+                                        L.ptr(self.packed_fwd), L.ptr(hold.weight), L.ptr(hold.bias),
+                                        C.byref(self.out.view), self._impl("fwd"), st),
+                    f"{self.name} forward")
         plan.prof_end(t0, self, "forward")
         c = self.cv.cout
         if self.act == "prelu":
@@ -424,10 +451,11 @@ class ConvUnit:
         if bn is None:
             return
         if training:
-            t0 = plan.prof_begin()
-            L.check(lib.bp_channel_sums(C.byref(self.out.view), L.ptr(self.sums), L.ptr(self._ws()), plan.ws_bytes,
-                                        st), f"{self.name} bn stats")
-            plan.prof_end(t0, self, "bn_stats")
+            if not fused:
+                t0 = plan.prof_begin()
+                L.check(lib.bp_channel_sums(C.byref(self.out.view), L.ptr(self.sums), L.ptr(self._ws()),
+                                            plan.ws_bytes, st), f"{self.name} bn stats")
+                plan.prof_end(t0, self, "bn_stats")
             count = float(self.out.n * self.out.h * self.out.w)
             if plan.sync is not None and plan.sync.sync_bn:
                 yield self.sums[:2 * c]
@@ -451,6 +479,9 @@ class ConvUnit:
         self.plan.need_ws(lib.bp_conv_backward_weight_workspace(C.byref(self.cv), C.byref(self.inp.view),
                                                                 C.byref(self.out.view)))
         self.dx = self.inp.claim_grad() if self.need_dgrad else None
+        if self.dx is not None and self._sub is None and EPILOGUE_BWD and not self.bf16 and self.inp.dt == L.F32:
+            self.plan.need_ws(lib.bp_conv_stats_workspace(C.byref(self.cv), L.PACK_BWD, C.byref(self.inp.view),
+                                                          C.byref(self.out.view)))
         if self.dx is not None and self._sub is not None:
             c0, c1 = self.dgrad_slice
             full = self.dx
@@ -486,11 +517,16 @@ class ConvUnit:
         aout = None if act_out is None else C.byref(act_out)
         d2 = None if dout2 is None else C.byref(dout2)
         nstreams = 2 + (dout2 is not None) + (act_out is not None)       # tensors this pass and the apply pass read
-        t0 = plan.prof_begin()
-        L.check(lib.bp_act_backward(C.byref(dout), d2, C.byref(self.out.view), pw, aout,
-                                    None if g_out is None else C.byref(g_out), L.ptr(self.sums), L.ptr(self._ws()),
-                                    plan.ws_bytes, st), f"{self.name} act backward")
-        plan.prof_end(t0, self, "act_backward", nstreams + (g_out is not None))
+        if self._sums_ready and g_out is None and dout2 is None and act_out is None:
+            self._sums_ready = False         # the consumer's data gradient left {sum g, sum g*raw} in self.sums
+        else:
+            if self._sums_ready:
+                raise RuntimeError(f"{self.name}: fused statistics do not match this activation backward")
+            t0 = plan.prof_begin()
+            L.check(lib.bp_act_backward(C.byref(dout), d2, C.byref(self.out.view), pw, aout,
+                                        None if g_out is None else C.byref(g_out), L.ptr(self.sums),
+                                        L.ptr(self._ws()), plan.ws_bytes, st), f"{self.name} act backward")
+            plan.prof_end(t0, self, "act_backward", nstreams + (g_out is not None))
         if self.act == "prelu":
             L.check(lib.bp_prelu_slope_grad(L.ptr(self.sums), c, L.ptr(grads[id(self.act_holder.weight)]), st),
                     f"{self.name} prelu grad")
@@ -515,6 +551,24 @@ class ConvUnit:
                 plan.prof_end(t0, self, "bn_apply", 3)
             return True
         return False
+
+    def _producer_to_fuse(self):
+        """The unit whose batch-norm backward sums this layer's data gradient can take in its epilogue: the only
+        producer of ``inp`` when this layer is its only consumer (then d/d(activated inp) is exactly what this
+        kernel writes) and its activation is a fixed-slope one.  Decided once, after every consumer has claimed."""
+        if self._fused_producer is None:
+            self._fused_producer = False
+            p = getattr(self.inp, "producer", None)
+            if EPILOGUE_BWD and isinstance(p, ConvUnit) and p.out is self.inp and p.bn is not None \
+                    and p.act in (None, "relu", "leaky relu") and p.plan is self.plan and p.ws_name == self.ws_name \
+                    and self.inp.n_consumers == 1 and self.inp.grad2 is None and self.inp.dt == L.F32 \
+                    and self._sub is None and not self.bf16 and self.packed_bwd is not None \
+                    and self._impl("dgrad") in (L.IMPL_AUTO, L.IMPL_MFMA):
+                nb = self.plan.lib.bp_conv_stats_workspace(C.byref(self.cv), L.PACK_BWD, C.byref(self.inp.view),
+                                                           C.byref(self.out.view))
+                if 0 < nb <= self.plan.ws_bytes:
+                    self._fused_producer = p
+        return self._fused_producer
 
     def conv_backward(self, grads):
         """Weight gradient and data gradient of this layer from d_raw (``out.grad``).
@@ -545,8 +599,16 @@ class ConvUnit:
             with torch.cuda.stream(side):
                 wgrad(plan.ws2)
         if self.dx is not None:
+            prod = self._producer_to_fuse()
             t0 = plan.prof_begin()
-            if self._sub is not None:
+            if prod:
+                L.check(lib.bp_conv_backward_data_stats(C.byref(self.cv), C.byref(g), L.ptr(self.packed_bwd),
+                                                        C.byref(self.dx), C.byref(self.inp.view),
+                                                        self.inp.pw_struct(), L.ptr(prod.sums), L.ptr(self._ws()),
+                                                        plan.ws_bytes, st),
+                        f"{self.name} backward_data + {prod.name} activation sums")
+                prod._sums_ready = True
+            elif self._sub is not None:
                 sub = self._sub
                 L.check(lib.bp_conv_backward_data(C.byref(sub["cv"]), C.byref(g), L.ptr(sub["packed"]),
                                                   L.ptr(sub["w"]), C.byref(sub["dx"]), self._impl("dgrad"), st),

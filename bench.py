@@ -58,6 +58,8 @@ def kernel_name(kind, unit, lib):
     if kind == "backward_weight":
         cv = unit.cv
         cx, cy = (cv.cout, cv.cin) if cv.transposed else (cv.cin, cv.cout)
+        if (cv.transposed, cv.cin, cv.cout, cv.k, cv.stride, cv.pad) == (0, 3, 16, 5, 1, 2):
+            return "stem_wgrad_kernel"
         if cx <= 16 and cy <= 16 and not (cx == 16 and cy == 16) and (cv.k, cv.stride) in ((3, 1), (5, 1), (7, 1), (4, 2), (8, 4)):
             return "wgrad_small_kernel[k%ds%d %d,%d]" % (cv.k, cv.stride, cx, cy)
         return "wgrad_tiles_kernel[k%ds%d %s]" % (cv.k, cv.stride, "wide" if (cx > 16 and cy > 16) else "thin")
@@ -65,6 +67,11 @@ def kernel_name(kind, unit, lib):
     if kind == "backward_data" and getattr(unit, "_sub", None) is not None:
         cv = unit._sub["cv"]           # data gradient restricted to a channel slice
     kid = lib.bp_conv_kernel_id(C.byref(cv), L.PACK_FWD if kind == "forward" else L.PACK_BWD)
+    if kid == 700000:
+        return "stem_forward_kernel"
+    if 800000 <= kid < 900000:
+        return "tiny_%s_kernel<%d,%d,%d,%d>" % ("transposed" if kid % 10 else "gather", kid // 10000 % 10, kid // 1000 % 10,
+                                                kid // 100 % 10, kid // 10 % 10)
     if kid >= 900000:
         return "small_conv_kernel<%d,%d,%d>" % (kid // 1000 % 100, kid // 10 % 100, kid % 10)
     dma, kid = divmod(kid, 100000)

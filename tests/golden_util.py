@@ -103,3 +103,10 @@ def distance(prefix, arr, gold):
     e1 = abs(np.sqrt((flat ** 2).sum()) - gl2) / max(gl2, 1e-30)
     e2 = np.abs(flat[sample_indices(flat.size)] - gs).max() / max(np.abs(gs).max(), rms)
     return max(e1, e2)
+
+
+def distance_arrays(arr, ref):
+    """``distance`` between two arrays in hand: the measure a stored summary of ``ref`` would give."""
+    out = {}
+    summarize("t", ref, out)
+    return distance("t", arr, out)

@@ -245,6 +245,101 @@ def test_small_channel_kernels_ragged_views_and_activation(case):
     assert G.rel_err(G.from_nhwc(dxb, ci, coff=1), dx_ref) < 2e-5
     assert torch.isnan(dxb[..., :1]).all() and torch.isnan(dxb[..., 1 + ci:]).all(), "stores outside the view"
 
+# strided layers with one or two channels on one side, served by the per-pixel kernels of conv_small.hip
+# (transposed, cin, cout, k, stride, pad)
+TINY_CASES = [(0, 1, 8, 4, 2, 1), (0, 2, 8, 4, 2, 1), (1, 1, 1, 8, 4, 2), (1, 1, 1, 4, 2, 1), (0, 1, 1, 8, 4, 2),
+              (0, 1, 1, 4, 2, 1)]
+
+
+@pytest.mark.parametrize("case", TINY_CASES, ids=lambda c: "%s%d_%d_k%ds%d" % ("T" if c[0] else "C", *c[1:5]))
+def test_strided_few_channel_kernels_ragged_views_and_activation(case):
+    """Forward and data gradient of the 512^2 ends of the recognition / prior networks and of the latent up-sampler
+    (cvae.py:26-45 via arch q_x_in / q_y_in / prior_z_y / p_z_in) on views that are channel slices, with a pending
+    activation whose act(0) != 0 and a bias, against the float64 oracle."""
+    lib = L.load()
+    tr, ci, co, k, s, p = case
+    n, h, w = 3, 21, 38
+    rng = np.random.default_rng(ci * 17 + co + k)
+    x = rng.standard_normal((n, ci, h, w)).astype(np.float32)
+    wt = (rng.standard_normal(((ci, co) if tr else (co, ci)) + (k, k)) * 0.2).astype(np.float32)
+    bias = rng.standard_normal(co).astype(np.float32)
+    scale = rng.uniform(0.5, 1.5, ci).astype(np.float32)
+    shift = rng.uniform(0.2, 0.6, ci).astype(np.float32)
+    slope = rng.uniform(0.0, 0.3, ci).astype(np.float32)
+    t = x * scale[None, :, None, None] + shift[None, :, None, None]
+    xa = np.where(t > 0, t, t * slope[None, :, None, None]).astype(np.float64)
+    w64 = wt.astype(np.float64)
+    y_ref = (ops.convT2d_fwd(xa, w64, s, p, 0) if tr else ops.conv2d_fwd(xa, w64, s, p)) + bias[None, :, None, None]
+    cv = L.Conv(tr, ci, co, k, s, p, 0)
+    ids = [lib.bp_conv_kernel_id(C.byref(cv), d) for d in (L.PACK_FWD, L.PACK_BWD)]
+    assert 800000 <= ids[0] < 900000, "case is meant for the per-pixel strided kernels"
+    st = G.stream()
+    xb, xv = G.to_nhwc(x, cstride=ci + 4, coff=3)
+    ho, wo = y_ref.shape[2:]
+    yb, yv = G.empty_nhwc(n, ho, wo, co, cstride=co + 4, coff=4)
+    keep, pw = G.pointwise(scale, shift, slope)
+    wd, bd = G.dev(wt), G.dev(bias)
+    pf = torch.zeros(lib.bp_conv_packed_floats(C.byref(cv), L.PACK_FWD), device="cuda")
+    pb = torch.zeros(lib.bp_conv_packed_floats(C.byref(cv), L.PACK_BWD), device="cuda")
+    L.check(lib.bp_conv_pack(C.byref(cv), L.PACK_FWD, L.ptr(wd), L.ptr(pf), st))
+    L.check(lib.bp_conv_pack(C.byref(cv), L.PACK_BWD, L.ptr(wd), L.ptr(pb), st))
+    L.check(lib.bp_conv_forward(C.byref(cv), C.byref(xv), C.byref(pw), L.ptr(pf), L.ptr(wd), L.ptr(bd), C.byref(yv),
+                                L.IMPL_MFMA, st), "forward")
+    assert G.rel_err(G.from_nhwc(yb, co, coff=4), y_ref) < 2e-5
+    assert torch.isnan(yb[..., :4]).all() and torch.isnan(yb[..., 4 + co:]).all(), "stores outside the view"
+    dy = rng.standard_normal(y_ref.shape).astype(np.float32)
+    dy64 = dy.astype(np.float64)
+    dyb, dyv = G.to_nhwc(dy, cstride=co + 1, coff=1)
+    dxb, dxv = G.empty_nhwc(n, h, w, ci, cstride=ci + 2, coff=1)
+    L.check(lib.bp_conv_backward_data(C.byref(cv), C.byref(dyv), L.ptr(pb), L.ptr(wd), C.byref(dxv), L.IMPL_MFMA,
+                                      st), "backward_data")
+    dx_ref = ops.convT2d_bwd_data(dy64, w64, s, p) if tr else ops.conv2d_bwd_data(dy64, w64, s, p, h, w)
+    assert G.rel_err(G.from_nhwc(dxb, ci, coff=1), dx_ref) < 2e-5
+    assert torch.isnan(dxb[..., :1]).all() and torch.isnan(dxb[..., 1 + ci:]).all(), "stores outside the view"
+
+
+def test_stem_kernel_padded_slot_bias_and_activation():
+    """Conv2d 3 -> 16 k5 (arch p_y_z_in.0) through conv_stem.hip: input as the model holds it (3 channels in a
+    4-float pixel: 16-byte loads) and as a ragged slice (scalar loads), pending activation, bias, enough tiles that
+    workgroups walk several of them (grid stride + double-buffered staging)."""
+    lib = L.load()
+    rng = np.random.default_rng(316)
+    cv = L.Conv(0, 3, 16, 5, 1, 2, 0)
+    assert lib.bp_conv_kernel_id(C.byref(cv), L.PACK_FWD) == 700000
+    wt = (rng.standard_normal((16, 3, 5, 5)) * 0.2).astype(np.float32)
+    bias = rng.standard_normal(16).astype(np.float32)
+    scale = rng.uniform(0.5, 1.5, 3).astype(np.float32)
+    shift = rng.uniform(0.2, 0.6, 3).astype(np.float32)
+    slope = rng.uniform(0.0, 0.3, 3).astype(np.float32)
+    st = G.stream()
+    wd, bd = G.dev(wt), G.dev(bias)
+    keep, pw = G.pointwise(scale, shift, slope)
+    pf = torch.zeros(lib.bp_conv_packed_floats(C.byref(cv), L.PACK_FWD), device="cuda")
+    L.check(lib.bp_conv_pack(C.byref(cv), L.PACK_FWD, L.ptr(wd), L.ptr(pf), st))
+    for (n, h, w), (cs, co_) in (((2, 19, 150), (4, 0)), ((3, 37, 70), (7, 2)), ((40, 130, 200), (4, 0))):
+        x = rng.standard_normal((n, 3, h, w)).astype(np.float32)
+        t = x * scale[None, :, None, None] + shift[None, :, None, None]
+        xa = np.where(t > 0, t, t * slope[None, :, None, None]).astype(np.float64)
+        y_ref = ops.conv2d_fwd(xa, wt.astype(np.float64), 1, 2) + bias[None, :, None, None]
+        xb, xv = G.to_nhwc(x, cstride=cs, coff=co_)
+        yb, yv = G.empty_nhwc(n, h, w, 16, cstride=20, coff=4)
+        L.check(lib.bp_conv_forward(C.byref(cv), C.byref(xv), C.byref(pw), L.ptr(pf), L.ptr(wd), L.ptr(bd),
+                                    C.byref(yv), L.IMPL_MFMA, st), "stem forward")
+        assert G.rel_err(G.from_nhwc(yb, 16, coff=4), y_ref) < 2e-5
+        assert torch.isnan(yb[..., :4]).all(), "stores outside the view"
+        # weight gradient (stem_wgrad_kernel): sees the activated input, dy as a channel slice
+        dy = rng.standard_normal(y_ref.shape).astype(np.float32)
+        dyb, dyv = G.to_nhwc(dy, cstride=20, coff=4)
+        ws_bytes = lib.bp_conv_backward_weight_workspace(C.byref(cv), C.byref(xv), C.byref(dyv))
+        ws = torch.full((ws_bytes // 8 + 8,), float("nan"), dtype=torch.float64, device="cuda")
+        dw = torch.full(wt.shape, float("nan"), device="cuda")
+        db = torch.full((16,), float("nan"), device="cuda")
+        L.check(lib.bp_conv_backward_weight(C.byref(cv), C.byref(xv), C.byref(pw), C.byref(dyv), L.ptr(dw), L.ptr(db),
+                                            L.ptr(ws), ws.numel() * 8, L.IMPL_MFMA, st), "stem backward_weight")
+        dw_ref = ops.conv2d_bwd_weight(xa, dy.astype(np.float64), 1, 2, 5, 5)
+        assert G.rel_err(dw.cpu().numpy(), dw_ref) < 1e-4
+        assert G.rel_err(db.cpu().numpy(), dy.astype(np.float64).sum(axis=(0, 2, 3))) < 1e-5
+
 
 def test_conv_rejects_bad_shapes():
     lib = L.load()

@@ -177,3 +177,28 @@ def test_torch_cpu_restatement_matches_reference(tag, size, n, two, alpha, golde
         from golden_util import crop_rel_l2
         assert crop_rel_l2(f"{tag}/x_mu", m.x_mu.detach().numpy(), golden_model) <= 1e-6
         assert crop_rel_l2(f"{tag}/sample_P_eval_zfix", s, golden_model) <= 1e-6
+
+
+def test_conditioning_fixture_is_what_its_script_makes():
+    """tests/golden/cond.npz (the float32 noise floor the GPU gradient tests use) against a fresh evaluation of one
+    draw at 128^2 by tests/golden/make_goldens_cond.py: the fixture is data of the committed script, and the true
+    gradient of this case really jumps by ~1e-2 under an 8-ulp perturbation (a latent-level ReLU sits at zero)."""
+    import os
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.join(here, "golden"))
+    import make_goldens_cond as mc
+    from golden_util import distance_arrays
+    cond = np.load(os.path.join(here, "golden", "cond.npz"))
+    assert float(cond["delta"]) == mc.DELTA and int(cond["draws"]) == mc.DRAWS
+    for tag, _, _ in mc.CASES:
+        assert cond[f"{tag}/grad_cond_dist"].shape[0] == mc.DRAWS
+    arch = syn.scaled_architecture(A.fiducial_architecture(512), 128)
+    g0 = mc.gradient(arch, 2, 128, 0.0, 0)
+    g1 = mc.gradient(arch, 2, 128, mc.DELTA, 1)
+    names = str(cond["fid128_n2/grad_cond_params"]).split(",")
+    assert names == list(g0)
+    fresh = np.array([distance_arrays(g1[k], g0[k]) for k in names])
+    stored = cond["fid128_n2/grad_cond_dist"][1]
+    assert np.allclose(fresh, stored, rtol=1e-3, atol=1e-7)
+    assert 1e-3 < stored.max() < 1e-1

@@ -7,6 +7,7 @@ from baryon_painter_amd import _lib as L
 import gpu_util as G
 lib = L.load()
 st = G.stream()
+IMPL = L.IMPL_DIRECT if os.environ.get('BENCH_IMPL') == 'direct' else L.IMPL_MFMA
 for spec in sys.argv[1:]:
     tr, ci, co, k, s, p, n, h, w = map(int, spec.split(","))
     cv = L.Conv(tr, ci, co, k, s, p, 0)
@@ -28,11 +29,11 @@ for spec in sys.argv[1:]:
     flop = 2.0 * dense * k * k * ci * co
     def run(kind):
         if kind == "fwd":
-            L.check(lib.bp_conv_forward(C.byref(cv), C.byref(xv), C.byref(pw), L.ptr(pf), L.ptr(wd), None, C.byref(yv), L.IMPL_MFMA, st))
+            L.check(lib.bp_conv_forward(C.byref(cv), C.byref(xv), C.byref(pw), L.ptr(pf), L.ptr(wd), None, C.byref(yv), IMPL, st))
         elif kind == "dgrad":
-            L.check(lib.bp_conv_backward_data(C.byref(cv), C.byref(yv), L.ptr(pb), L.ptr(wd), C.byref(dxv), L.IMPL_MFMA, st))
+            L.check(lib.bp_conv_backward_data(C.byref(cv), C.byref(yv), L.ptr(pb), L.ptr(wd), C.byref(dxv), IMPL, st))
         else:
-            L.check(lib.bp_conv_backward_weight(C.byref(cv), C.byref(xv), C.byref(pw), C.byref(yv), L.ptr(dw), None, L.ptr(ws), ws.numel() * 8, L.IMPL_MFMA, st))
+            L.check(lib.bp_conv_backward_weight(C.byref(cv), C.byref(xv), C.byref(pw), C.byref(yv), L.ptr(dw), None, L.ptr(ws), ws.numel() * 8, IMPL, st))
     out = []
     for kind in ("fwd", "dgrad", "wgrad"):
         for _ in range(2):
