@@ -12,7 +12,7 @@ int bp_igemm_pack_jobs(const void* jobs_dev, const int64_t* first_block_dev, int
                        hipStream_t st);
 int bp_igemm_run(const ConvGeom& g, const bp_view* in, const PW& pw, const float* packed, const float* bias,
                  const bp_view* out, hipStream_t st, const IgemmStatsReq* stats = nullptr);
-size_t bp_igemm_stats_workspace(const ConvGeom& g, const bp_view* in, const bp_view* out);
+size_t bp_igemm_stats_workspace(const ConvGeom& g, const bp_view* in, const bp_view* out, int mode);
 int bp_direct_gather(const ConvGeom& g, const WeightMap& wm, const bp_view* in, const PW& pw, const float* w_torch,
                      const float* bias, const bp_view* out, hipStream_t st);
 int bp_direct_wgrad(const bp_conv* cv, const bp_view* X, const PW& pwx, const bp_view* Y, const PW& pwy, float* dst,
@@ -133,8 +133,8 @@ int bp_conv_forward(const bp_conv* cv, const bp_view* x, const bp_pointwise* x_p
 
 size_t bp_conv_stats_workspace(const bp_conv* cv, int dir, const bp_view* x, const bp_view* y) {
   if (!conv_ok(cv) || !shapes_ok(cv, x, y) || (dir != BP_PACK_FWD && dir != BP_PACK_BWD)) return 0;
-  return dir == BP_PACK_FWD ? bp_igemm_stats_workspace(bp_geom_forward(cv), x, y)
-                            : bp_igemm_stats_workspace(bp_geom_backward_data(cv), y, x);
+  return dir == BP_PACK_FWD ? bp_igemm_stats_workspace(bp_geom_forward(cv), x, y, 1)
+                            : bp_igemm_stats_workspace(bp_geom_backward_data(cv), y, x, 2);
 }
 
 int bp_conv_forward_stats(const bp_conv* cv, const bp_view* x, const bp_pointwise* x_pw, const float* packed_fwd,

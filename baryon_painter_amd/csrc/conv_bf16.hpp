@@ -175,11 +175,15 @@ __device__ __forceinline__ void b_store_tile(const BArgs& a, const v4f (&acc)[MT
   }
 }
 
-template <int CC, int NT, int WN, int MT, int SLOTS, bool IN_BF16, bool OUT_BF16>
-__global__ __launch_bounds__(256, 2) void igemm_bf16_kernel(BArgs a) {
+// NW waves per workgroup: 4, or 8 for the 128-channel trunk -- at bf16 MFMA speed a 128-pixel tile is only ~2 us of
+// matrix work per 295 KB of weights, and streaming the weights from L2 once per tile is what bounds the kernel; eight
+// waves (256 pixels) halve that traffic per pixel.
+template <int CC, int NT, int WN, int MT, int SLOTS, bool IN_BF16, bool OUT_BF16, int NW = 4>
+__global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void igemm_bf16_kernel(BArgs a) {
   constexpr int U = CC < 8 ? CC : 8;            // channels per staging unit
   constexpr int UPP = CC / U;                   // units per pixel
-  constexpr int WM = 4 / WN;
+  constexpr int WM = NW / WN;
+  constexpr int NTH = 64 * NW;
   constexpr int COB = 16 * NT * WN;
   // LDS images (bf16).  Input halo tile: CC = 32 as four k-group planes [channel octet][pixel][8] -- the 16 pixels
   // of an MFMA fragment read are then 256 contiguous bytes per lane quarter (the plain [pixel][32] image has a
@@ -243,11 +247,11 @@ __global__ __launch_bounds__(256, 2) void igemm_bf16_kernel(BArgs a) {
   const int E = a.IH * a.ISx * a.IWq * UPP;     // staging units of the LDS image
 
   // this thread's units: (row, column) are the same for every channel chunk
-  const int cu = tid % UPP;                     // 256 % UPP == 0: fixed channel group per thread
+  const int cu = tid % UPP;                     // NTH % UPP == 0: fixed channel group per thread
   int s_g[SLOTS];                               // element offset inside the image, -1 outside / unused slot
 #pragma unroll
   for (int i = 0; i < SLOTS; ++i) {
-    const int e = tid + i * 256;
+    const int e = tid + i * NTH;
     s_g[i] = -2;
     if (e < E) {
       const int pi = e / UPP;
@@ -289,7 +293,7 @@ __global__ __launch_bounds__(256, 2) void igemm_bf16_kernel(BArgs a) {
         }
         v[j] = t;
       }
-      const int e = tid + i * 256;
+      const int e = tid + i * NTH;
       if constexpr (CC == 32) lds_store_unit<U>(lds_in + ((e % UPP) * a.npixp + e / UPP) * 8, v);
       else lds_store_unit<U>(lds_in + e * U, v);
     }
@@ -298,7 +302,7 @@ __global__ __launch_bounds__(256, 2) void igemm_bf16_kernel(BArgs a) {
   // dealt to the four waves; the packed image holds each workgroup's [k octet][row][8] block contiguously
   auto issue_w = [&](int chunk, int ty, int slot) {
     constexpr int PPR = COB / 16;                    // pieces per run
-    for (int k = wave; k < a.nrun * PPR; k += 4) {
+    for (int k = wave; k < a.nrun * PPR; k += NW) {
       const int s = k / PPR, part = k - s * PPR;
       const u16* src = a.wp + ((((int64_t)(ph * a.tapsy + ty) * a.nrun + s) * a.nchunk + chunk) * a.cout_padP + co0) * 32 +
                        part * 512;
@@ -533,14 +537,16 @@ __host__ __device__ __forceinline__ int b_channel_of(int NT, int jb /* index ins
 struct BConfig {
   int CC, R, NT, WN, MT, COB, nchunk, cout_padP, nrun, run_xm[16], run_xq[16];
   int TPR, BH, IH, IWq, slots, npixp;
+  int NW;                   // waves per workgroup (4, or 8: igemm_bf16_kernel<..., 8>)
   size_t lds_bytes;
   bool ok;
   bool persistent;          // igemm_bf16_p_kernel: one chunk, all tap rows' weights resident
   size_t lds_p;
 };
 
-static inline BConfig b_config_for(const ConvGeom& g, int NT, int WN) {
+static inline BConfig b_config_for(const ConvGeom& g, int NT, int WN, int NW = 4) {
   BConfig c{};
+  c.NW = NW;
   const int cin = g.cin_g;
   if (cin % 32 == 0) c.CC = 32;
   else if (cin == 16) c.CC = 16;
@@ -564,13 +570,13 @@ static inline BConfig b_config_for(const ConvGeom& g, int NT, int WN) {
     }
     if (nr * c.R > rmax) rmax = nr * c.R;
   }
-  const int TM = (4 / c.WN) * c.MT;                        // M tiles per workgroup
+  const int TM = (NW / c.WN) * c.MT;                       // M tiles per workgroup
   c.TPR = 2; c.BH = TM / 2;
   c.IH = (c.BH - 1) * g.IS + g.taps;
   c.IWq = 16 * c.TPR + rmax - 1;
   const int U = c.CC < 8 ? c.CC : 8;
   const int E = c.IH * g.IS * c.IWq * (c.CC / U);
-  c.slots = bp_ceil_div(E, 256);
+  c.slots = bp_ceil_div(E, 64 * NW);
   c.npixp = bp_round_up(c.IH * g.IS * c.IWq, 16);
   const size_t in_b = (((size_t)c.npixp * c.CC + 511) & ~(size_t)511) * 2;
   c.lds_bytes = in_b + (size_t)2 * c.nrun * c.COB * 32 * 2;        // two weight slabs
@@ -580,7 +586,7 @@ static inline BConfig b_config_for(const ConvGeom& g, int NT, int WN) {
   // (measured on the fiducial layers: the persistent form wins for the strided gathers -- 16->32 k4s2 forward
   //  0.61 -> 0.46 ms, 32->16 transposed data gradient 0.54 -> 0.41 ms -- whose halo tiles are four times the
   //  output tile, and loses 10-20 % on the unit-stride forms, which are bound by LDS fragment reads, not by staging)
-  c.persistent = c.ok && !no_p && c.nchunk == 1 && c.lds_p <= 64 * 1024 && g.IS == 2;
+  c.persistent = c.ok && !no_p && NW == 4 && c.nchunk == 1 && c.lds_p <= 64 * 1024 && g.IS == 2;
   return c;
 }
 
@@ -591,6 +597,11 @@ inline BConfig b_config(const ConvGeom& g) {
   static const int cand[6][2] = {{4, 2}, {4, 1}, {2, 2}, {2, 1}, {1, 2}, {1, 1}};
   const int first = nT >= 5 ? 0 : (nT >= 3 ? 1 : (nT == 2 ? 3 : 5));
   BConfig c{};
+  static const bool no_nw8 = getenv("BP_BF16_NONW8") != nullptr;
+  if (first == 0 && g.cin_g % 32 == 0 && !no_nw8) {          // 128-wide channel block, 32-channel chunks: eight waves
+    c = b_config_for(g, 4, 2, 8);
+    if (c.ok && c.slots <= 6) return c;
+  }
   for (int i = first; i < 6; ++i) {            // widest channel block whose tile + two weight slabs fit
     if (16 * cand[i][0] * cand[i][1] > 16 * nT && i != first) continue;      // (never wider than the layer)
     c = b_config_for(g, cand[i][0], cand[i][1]);
@@ -601,13 +612,13 @@ inline BConfig b_config(const ConvGeom& g) {
 
 // weights: torch layout (fp32) -> [phase][ty][run][chunk][channel block][k octet][row][8] bf16 (the LDS image of a
 // workgroup's slab, contiguous: one linear copy / LDS-DMA), k = 8*octet + i = j*CC + cc <-> tap xm + IS*(xq + j)
-template <int CC, int NT, int WN, int SLOTS, bool IB, bool OB>
+template <int CC, int NT, int WN, int SLOTS, bool IB, bool OB, int NW = 4>
 int b_launch(const BArgs& a, dim3 grid, size_t lds, hipStream_t st) {
   static const hipError_t optin = hipFuncSetAttribute(
-      reinterpret_cast<const void*>(&igemm_bf16_kernel<CC, NT, WN, 4, SLOTS, IB, OB>),
+      reinterpret_cast<const void*>(&igemm_bf16_kernel<CC, NT, WN, 4, SLOTS, IB, OB, NW>),
       hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
   if (optin != hipSuccess) return BP_ELAUNCH;
-  hipLaunchKernelGGL((igemm_bf16_kernel<CC, NT, WN, 4, SLOTS, IB, OB>), grid, dim3(256), lds, st, a);
+  hipLaunchKernelGGL((igemm_bf16_kernel<CC, NT, WN, 4, SLOTS, IB, OB, NW>), grid, dim3(64 * NW), lds, st, a);
   BP_CHECK_LAUNCH();
   return BP_OK;
 }
@@ -627,12 +638,12 @@ int b_launch_p_io(const BPArgs& a, bool ib, bool ob, dim3 grid, size_t lds, hipS
   return b_launch_p<CC, NT, WN, SLOTS, false, false>(a, grid, lds, st);
 }
 
-template <int CC, int NT, int WN, int SLOTS>
+template <int CC, int NT, int WN, int SLOTS, int NW = 4>
 int b_launch_io(const BArgs& a, bool ib, bool ob, dim3 grid, size_t lds, hipStream_t st) {
-  if (ib && ob) return b_launch<CC, NT, WN, SLOTS, true, true>(a, grid, lds, st);
-  if (ib) return b_launch<CC, NT, WN, SLOTS, true, false>(a, grid, lds, st);
-  if (ob) return b_launch<CC, NT, WN, SLOTS, false, true>(a, grid, lds, st);
-  return b_launch<CC, NT, WN, SLOTS, false, false>(a, grid, lds, st);
+  if (ib && ob) return b_launch<CC, NT, WN, SLOTS, true, true, NW>(a, grid, lds, st);
+  if (ib) return b_launch<CC, NT, WN, SLOTS, true, false, NW>(a, grid, lds, st);
+  if (ob) return b_launch<CC, NT, WN, SLOTS, false, true, NW>(a, grid, lds, st);
+  return b_launch<CC, NT, WN, SLOTS, false, false, NW>(a, grid, lds, st);
 }
 
 template <int CC, int NT, int WN>
@@ -660,6 +671,9 @@ int b_launch_slots(const BConfig& c, const BArgs& a, bool ib, bool ob, dim3 grid
 
 template <int CC>
 int b_launch_cc(const BConfig& c, const BArgs& a, bool ib, bool ob, dim3 grid, hipStream_t st) {
+  if constexpr (CC == 32) {
+    if (c.NW == 8) return b_launch_io<CC, 4, 2, 6, 8>(a, ib, ob, grid, c.lds_bytes, st);
+  }
   if (c.NT == 4 && c.WN == 2) return b_launch_slots<CC, 4, 2>(c, a, ib, ob, grid, st);
   if (c.NT == 4 && c.WN == 1) return b_launch_slots<CC, 4, 1>(c, a, ib, ob, grid, st);
   if (c.NT == 2 && c.WN == 2) return b_launch_slots<CC, 2, 2>(c, a, ib, ob, grid, st);

@@ -839,6 +839,217 @@ __global__ __launch_bounds__(256, 2) void igemm_dmaf_kernel(IgemmArgs a) {
                              co0, qy0, qx0, ph0);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Weights-resident persistent form for the thin full-resolution gathers (<= 32 produced channels, <= 16 gathered
+// channels in one chunk: the k4s2 16->32 layers and the k7 16<->8 head), whose halo tile is 4-5x the output tile
+// (stride 2) or whose 49 taps make the per-tap-row weight staging of igemm_kernel most of the time:
+//   * ALL tap slabs of the workgroup's channel block are copied to LDS once; the workgroup then walks a contiguous
+//     range of (image, tile) pairs (neighbouring tiles share halo rows / columns: they meet in one XCD's L2);
+//   * the NEXT tile's halo is in flight in registers while the current one is multiplied, then written (pending
+//     activation and zero padding applied) into the single input buffer: two barriers per tile, none inside it;
+//   * eight waves share the tile (MT M-tiles each), so a thread carries ~10 staging registers, not ~20.
+// LDS image, fragments and epilogue are those of igemm_kernel; batch-norm sums (mode 1) are kept per lane over all
+// the tiles of the workgroup and folded once.
+template <int CC, int NT, int MT, int NW, int SLOTS>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void igemm_wres_kernel(IgemmArgs a, int ntiles_total, int per_block) {
+  constexpr int VW = CC / 4;
+  constexpr int NTH = 64 * NW;
+  constexpr int COB = 16 * NT;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* lds_in = smem;
+  float* lds_w = smem + a.in_pad4 * 4;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave;
+  const int lm = lane & 15, kq = lane >> 4;
+  const int co0 = blockIdx.z * COB;
+  const int t_begin = blockIdx.x * per_block;
+  int t_end = t_begin + per_block;
+  if (t_end > ntiles_total) t_end = ntiles_total;
+  const bool idle = t_begin >= t_end;          // (still writes its zero row of the statistics)
+  const int tiles_per_img = a.tiles_x * a.tiles_y;
+  const int BW = 16 * a.TPR;
+  const int qh = a.out_h;                       // gather form: one phase, OS = 1
+  const int qw = a.PP > 1 ? (a.out_w + a.PP - 1) / a.PP : a.out_w;
+
+  // ---- weights: taps x [COB][CC], contiguous per tap in the packed image (one chunk)
+  {
+    const int slab4 = COB * CC / 4, ntap = a.tapsy * a.tapsx;
+    for (int e = tid; e < ntap * slab4 && !idle; e += NTH) {
+      const int tap = e / slab4, o = e - tap * slab4;
+      const float* src = a.wp + ((int64_t)tap * a.cout_padP + co0) * CC;
+      *reinterpret_cast<float4*>(lds_w + (size_t)tap * COB * CC + o * 4) = *reinterpret_cast<const float4*>(src + o * 4);
+    }
+  }
+
+  int abase[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int t = wm * MT + mt;
+    const int tr = t / a.TPR, tc = t % a.TPR;
+    abase[mt] = (tr * a.ISy * a.ISx * a.IWq + tc * 16 + lm) * CC + kq * VW;
+  }
+  int bbase[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) bbase[nt] = (nt * 16 + lm) * CC + kq * VW;
+
+  // staging slots of this thread: (row, column, channel quad) of the halo element, the same for every tile
+  const int in_elems4 = a.IH * a.IW * VW;
+  const int c4 = tid % VW;                      // NTH % VW == 0
+  int s_r[SLOTS], s_c[SLOTS], s_l[SLOTS];
+#pragma unroll
+  for (int i = 0; i < SLOTS; ++i) {
+    const int e = tid + i * NTH;
+    s_l[i] = -1; s_r[i] = 0; s_c[i] = 0;
+    if (e < in_elems4) {
+      const int pix = e / VW;
+      s_c[i] = pix % a.IW; s_r[i] = pix / a.IW;
+      s_l[i] = ((s_r[i] * a.ISx + s_c[i] % a.ISx) * a.IWq + s_c[i] / a.ISx) * CC + c4 * 4;
+    }
+  }
+  const PW4 p4 = pw4_load(a.pw, c4 * 4, a.cin);
+  // first gathered row / column relative to the output position (unit-stride data gradients arrive in the transposed form)
+  const int i0 = a.transposed ? bp_t_i0(0, a.pad, a.stride, a.tapsy) : -a.pad;
+  float4 stage[SLOTS];
+  unsigned inside = 0;
+  auto tile_origin = [&](int t, int* n, int* qy0, int* qx0) {
+    *n = t / tiles_per_img;
+    const int r = t - *n * tiles_per_img;
+    *qy0 = (r / a.tiles_x) * a.BH; *qx0 = (r % a.tiles_x) * BW;
+  };
+  auto fetch = [&](int t) {
+    int n, qy0, qx0;
+    tile_origin(t, &n, &qy0, &qx0);
+    const int gy0 = a.ISy * qy0 + i0, gx0 = a.ISx * qx0 + i0;
+    const float* in_n = a.in + (int64_t)n * a.in_h * a.in_w * a.in_cs + a.in_co + c4 * 4;
+    // every slot loads (coordinates clamped into the image; what lies outside is zeroed at commit): loads under a
+    // per-lane condition are serialised by the compiler with a full vmcnt(0) wait between them
+    inside = 0;
+#pragma unroll
+    for (int i = 0; i < SLOTS; ++i) {
+      const int iy = gy0 + s_r[i], ix = gx0 + s_c[i];
+      if (s_l[i] >= 0 && iy >= 0 && iy < a.in_h && ix >= 0 && ix < a.in_w) inside |= 1u << i;
+      const int cy = min(max(iy, 0), a.in_h - 1), cx = min(max(ix, 0), a.in_w - 1);
+      stage[i] = *reinterpret_cast<const float4*>(in_n + (cy * a.in_w + cx) * a.in_cs);
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int i = 0; i < SLOTS; ++i)
+      if (s_l[i] >= 0)
+        *reinterpret_cast<float4*>(lds_in + s_l[i]) =
+            ((inside >> i) & 1u) ? pw4_apply4(p4, stage[i]) : make_float4(0.f, 0.f, 0.f, 0.f);
+  };
+
+  double s1[NT][4], s2[NT][4];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { s1[nt][r] = 0.0; s2[nt][r] = 0.0; }
+
+  if (!idle) { fetch(t_begin); commit(); }
+  __syncthreads();
+  for (int t = t_begin; t < t_end; ++t) {
+    if (t + 1 < t_end) fetch(t + 1);
+    v4f acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = v4f{0.f, 0.f, 0.f, 0.f};
+    // taps in (ty, tx) order; the fragments of tap k+1 are read while tap k is multiplied (one tap is only 8-16
+    // MFMAs per wave: an exposed LDS round trip per tap would be a fifth of the loop)
+    {
+      const int ntap = a.tapsy * a.tapsx;
+      int ty = 0, xm = 0, xq = 0;            // tx = xq * ISx + xm
+      float af[2][MT][VW], bf[2][NT][VW];
+      auto read_tap = [&](int k, int buf) {
+        const int tapoff = ((ty * a.ISx + xm) * a.IWq + xq) * CC;
+        const float* lw = lds_w + (size_t)k * COB * CC;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) lds_read<VW>(lds_in + abase[mt] + tapoff, af[buf][mt]);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) lds_read<VW>(lw + bbase[nt], bf[buf][nt]);
+        if (++xm == a.ISx) { xm = 0; ++xq; }
+        if (xq * a.ISx + xm >= a.tapsx) { xm = 0; xq = 0; ++ty; }
+      };
+      auto mul_tap = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < VW; ++q)
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[buf][nt][q], af[buf][mt][q], acc[mt][nt], 0, 0, 0);
+      };
+      read_tap(0, 0);
+      int k = 0;
+      for (; k + 2 <= ntap - 1; k += 2) {     // two taps per trip: the buffer index stays a compile-time constant
+        read_tap(k + 1, 1);
+        mul_tap(0);
+        read_tap(k + 2, 0);
+        mul_tap(1);
+      }
+      // k taps done, buffer 0 holds tap k; 1 or 2 taps remain
+      if (k + 1 < ntap) {
+        read_tap(k + 1, 1);
+        mul_tap(0);
+        mul_tap(1);
+      } else {
+        mul_tap(0);
+      }
+    }
+    int n, qy0, qx0;
+    tile_origin(t, &n, &qy0, &qx0);
+    float* out_n = a.out + (int64_t)n * a.out_h * a.out_w * a.out_cs + a.out_co;
+    igemm_store<NT, MT>(a, acc, out_n, wm, 0, lm, kq, co0, qy0, qx0, qh, qw, 0, 0);
+    if (a.stat) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const int tt = wm * MT + mt;
+        const int qy = qy0 + tt / a.TPR, qx = qx0 + (tt % a.TPR) * 16 + lm;
+        if (qy >= qh || qx >= qw) continue;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const double v = (double)acc[mt][nt][r];
+            s1[nt][r] += v; s2[nt][r] = fma(v, v, s2[nt][r]);
+          }
+      }
+    }
+    __syncthreads();                       // every wave is done reading the tile
+    if (t + 1 < t_end) commit();
+    __syncthreads();
+  }
+  if (a.stat) {
+    double* red = reinterpret_cast<double*>(lds_in);        // [NW][COB][2]
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1) {
+          s1[nt][r] += __shfl_xor(s1[nt][r], off, 16);
+          s2[nt][r] += __shfl_xor(s2[nt][r], off, 16);
+        }
+        if (lm == 0) {
+          red[(wm * COB + nt * 16 + kq * 4 + r) * 2] = s1[nt][r];
+          red[(wm * COB + nt * 16 + kq * 4 + r) * 2 + 1] = s2[nt][r];
+        }
+      }
+    __syncthreads();
+    if (tid < COB && co0 + tid < a.cout) {
+      double t1 = 0.0, t2 = 0.0;
+      for (int w = 0; w < NW; ++w) { t1 += red[(w * COB + tid) * 2]; t2 += red[(w * COB + tid) * 2 + 1]; }
+      const int64_t L = (int64_t)blockIdx.y * gridDim.x + blockIdx.x;
+      a.stat[(L * 2) * a.stat_c + co0 + tid] = t1;
+      a.stat[(L * 2 + 1) * a.stat_c + co0 + tid] = t2;
+    }
+  }
+}
+
 // weights: torch layout -> [phase][ty][tx][chunk][cout_padP][CC]
 struct PackArgs {
   const float* w; float* dst;
@@ -953,6 +1164,11 @@ struct IgemmConfig {
   // igemm_dmaf_kernel (NT <= 2): taps per step, fused output phases (1 or 4), input buffers
   bool dmaf;
   int ts, nph, in_bufs;
+  // igemm_wres_kernel (NT <= 2, one channel chunk, gather form): all tap slabs resident, eight waves x 2 M tiles
+  bool wres;
+  int w_slots, w_in_pad4, w_NW;
+  TileGeom tw;
+  size_t lds_wres;
 };
 
 IgemmConfig igemm_config(const ConvGeom& g) {
@@ -984,11 +1200,34 @@ IgemmConfig igemm_config(const ConvGeom& g) {
   // First choice: the DMA-pipelined kernel (MT 4).  Eight waves per workgroup where the produced-channel
   // block is 128 wide (each weight slab then serves 256 pixels), else four; the chunk width that keeps at
   // least two (eight waves) or three (four waves) workgroups per CU.
+  // Thin strided / many-tap gathers: weights resident, persistent (igemm_wres_kernel).
+  static const bool no_wres = getenv("BP_IGEMM_NOWRES") != nullptr;
+  static const bool wres_all = getenv("BP_IGEMM_WRESALL") != nullptr;
+  if (!no_wres && c.NT <= 2 && c.PP <= 2 && g.nphase == 1 && g.OS == 1 && (g.cin_g == 16 || (g.cin_g == 8 && wres_all)) &&
+      (g.IS == 2 || g.taps >= 5 || wres_all)) {
+    const int CC = g.cin_g;
+    static const bool no_w4 = getenv("BP_WRES_NO4") != nullptr;
+    // four waves / 128 pixels where two such workgroups fit a CU (they fill each other's commit phases), else eight
+    // waves / 256 pixels with one workgroup per CU
+    for (int NW = no_w4 ? 8 : 4; NW <= 8 && !c.wres; NW += 4) {
+      const TileGeom tw = tile_geom(2 * NW, g.IS, c.ISx, g.taps, c.tapsx);
+      const int E = tw.IH * tw.IW * (CC / 4);
+      const int slots = bp_ceil_div(E, 64 * NW);
+      const int in_pad4 = bp_round_up(tw.IH * c.ISx * tw.IWq * (CC / 4), 64);
+      const size_t lds = (size_t)in_pad4 * 16 + (size_t)g.taps * c.tapsx * c.COB * CC * sizeof(float);
+      const bool plain_ok = plain_lds(tile_geom(16, g.IS, c.ISx, g.taps, c.tapsx), CC) <= 64 * 1024 ||
+                            plain_lds(tile_geom(4, g.IS, c.ISx, g.taps, c.tapsx), CC) <= 64 * 1024;
+      if (lds <= (size_t)(NW == 4 ? 80 : 150) * 1024 && slots <= 12 && plain_ok) {
+        c.wres = true; c.CC = CC; c.tw = tw; c.w_slots = slots <= 8 ? 8 : 12; c.w_in_pad4 = in_pad4; c.lds_wres = lds;
+        c.w_NW = NW;
+      }
+    }
+  }
   static const bool no_dma = getenv("BP_IGEMM_NODMA") != nullptr;
   static const bool no_nw8 = getenv("BP_IGEMM_NONW8") != nullptr;
   static const bool no_dmaf = getenv("BP_IGEMM_NODMAF") != nullptr;
   static const int pp_dma = getenv("BP_IGEMM_PPDMA") ? atoi(getenv("BP_IGEMM_PPDMA")) : 1;
-  if (c.NT <= 2 && c.PP <= pp_dma && !no_dma && !no_dmaf) {   // (pixel-packed heads measured slower here)
+  if (!c.wres && c.NT <= 2 && c.PP <= pp_dma && !no_dma && !no_dmaf) {   // (pixel-packed heads measured slower here)
     const int T = g.taps * c.tapsx;
     for (int CC = cc_first; CC >= 8 && !c.dma; CC /= 2) {
       if (g.cin_g % CC != 0 || (c.COB * CC) % 256 != 0) continue;
@@ -1019,7 +1258,7 @@ IgemmConfig igemm_config(const ConvGeom& g) {
       }
     }
   }
-  if (!c.dma && c.PP == 1 && g.taps * c.tapsx >= 2 && !no_dma) {
+  if (!c.wres && !c.dma && c.PP == 1 && g.taps * c.tapsx >= 2 && !no_dma) {
     for (int NW = (c.NT == 4 && c.WN == 2 && !no_nw8) ? 8 : 4; NW >= 4 && !c.dma; NW -= 4) {
       for (int CC = cc_first; CC >= 8 && !c.dma; CC /= 2) {
         if (g.cin_g % CC != 0 || (c.COB * CC) % 256 != 0) continue;
@@ -1044,7 +1283,7 @@ IgemmConfig igemm_config(const ConvGeom& g) {
   const int mts[2] = {4, 1};
   for (int mi = 0; mi < 2 && !c.ok; ++mi) {
     for (int CC = cc_first; CC >= 4 && !c.ok; CC /= 2) {
-      if (c.dma && CC != c.CC) continue;
+      if ((c.dma || c.wres) && CC != c.CC) continue;
       const int MT = mts[mi];
       const TileGeom t = tile_geom((4 / c.WN) * MT, g.IS, c.ISx, g.taps, c.tapsx);
       const size_t lds = plain_lds(t, CC);
@@ -1132,6 +1371,31 @@ int launch_dma(const IgemmConfig& c, const IgemmArgs& a, dim3 grid, hipStream_t 
   return BP_EUNSUPPORTED;
 }
 
+template <int CC, int NT, int SLOTS, int NW>
+int launch_wres_one(const IgemmConfig& c, const IgemmArgs& a, dim3 grid, int ntiles, int per_block, hipStream_t st) {
+  static const hipError_t optin = hipFuncSetAttribute(
+      reinterpret_cast<const void*>(&igemm_wres_kernel<CC, NT, 2, NW, SLOTS>),
+      hipFuncAttributeMaxDynamicSharedMemorySize, (NW == 4 ? 80 : 150) * 1024);
+  if (optin != hipSuccess) return BP_ELAUNCH;
+  hipLaunchKernelGGL((igemm_wres_kernel<CC, NT, 2, NW, SLOTS>), grid, dim3(64 * NW), c.lds_wres, st, a, ntiles, per_block);
+  BP_CHECK_LAUNCH();
+  return BP_OK;
+}
+
+int launch_wres(const IgemmConfig& c, const IgemmArgs& a, dim3 grid, int ntiles, int per_block, hipStream_t st) {
+#define BP_WRES(CCv, NTv) \
+  if (c.CC == CCv && c.NT == NTv) { \
+    if (c.w_NW == 4) \
+      return c.w_slots == 8 ? launch_wres_one<CCv, NTv, 8, 4>(c, a, grid, ntiles, per_block, st) \
+                            : launch_wres_one<CCv, NTv, 12, 4>(c, a, grid, ntiles, per_block, st); \
+    return c.w_slots == 8 ? launch_wres_one<CCv, NTv, 8, 8>(c, a, grid, ntiles, per_block, st) \
+                          : launch_wres_one<CCv, NTv, 12, 8>(c, a, grid, ntiles, per_block, st); \
+  }
+  BP_WRES(16, 1) BP_WRES(16, 2) BP_WRES(8, 1) BP_WRES(8, 2)
+#undef BP_WRES
+  return BP_EUNSUPPORTED;
+}
+
 template <int MT>
 int launch_mt(const IgemmConfig& c, const IgemmArgs& a, dim3 grid, hipStream_t st) {
   switch (c.CC) {
@@ -1164,6 +1428,7 @@ int bp_igemm_kernel_id(const ConvGeom& g) {
   if (bp_stem_ok(g)) return 700000;
   if (bp_small_ok(g)) return bp_small_kernel_id(g);
   const IgemmConfig c = igemm_config(g);
+  if (c.ok && c.wres) return 400000 + c.CC * 1000 + c.NT * 100 + (c.w_NW / 4) * 10 + 2;
   return c.ok ? (c.dma ? 100000 * (c.dmaf ? 3 : c.NW / 4) : 0) + c.CC * 1000 + c.NT * 100 + c.WN * 10 + c.MT : -1;
 }
 
@@ -1221,12 +1486,14 @@ int bp_igemm_pack_jobs(const void* jobs_dev, const int64_t* first_block_dev, int
 }
 
 // Launch shape of a layer on these views: which kernel family, its tile and its grid.
-struct IgemmLaunch { bool dma; TileGeom t; dim3 grid; int vec_ok, out_vec; size_t lds; int WM; };
+struct IgemmLaunch { bool dma, wres; TileGeom t; dim3 grid; int vec_ok, out_vec; size_t lds; int WM; int ntiles, per_block; };
 static bool igemm_launch_of(const ConvGeom& g, const IgemmConfig& c, const bp_view* in, const bp_view* out, IgemmLaunch& l) {
   l.vec_ok = (in->cstride % 4 == 0 && in->coff % 4 == 0 && (reinterpret_cast<uintptr_t>(in->ptr) % 16 == 0)) ? 1 : 0;
   l.out_vec = (out->cstride % 4 == 0 && out->coff % 4 == 0 && reinterpret_cast<uintptr_t>(out->ptr) % 16 == 0) ? 1 : 0;
   l.dma = c.dma && l.vec_ok;
-  l.t = l.dma ? c.td : c.t;
+  l.wres = c.wres && l.vec_ok;
+  l.t = l.wres ? c.tw : (l.dma ? c.td : c.t);
+  l.ntiles = l.per_block = 0;
   const int qh = bp_ceil_div(out->h, g.OS), qw = c.PP > 1 ? bp_ceil_div(out->w, c.PP) : bp_ceil_div(out->w, g.OS);
   const int tiles_x = bp_ceil_div(qw, 16 * l.t.TPR), tiles_y = bp_ceil_div(qh, l.t.BH);
   const int64_t gz = (int64_t)in->n * ((l.dma && c.dmaf && c.nph > 1) ? 1 : g.nphase * g.nphase);
@@ -1234,6 +1501,18 @@ static bool igemm_launch_of(const ConvGeom& g, const IgemmConfig& c, const bp_vi
   l.grid = dim3((unsigned)(tiles_x * tiles_y), (unsigned)gz, (unsigned)(c.cout_padP / c.COB));
   l.lds = l.dma ? c.lds_dma : c.lds_bytes;
   l.WM = l.dma ? (c.dmaf ? 4 : c.NW / c.WN) : 4 / c.WN;
+  if (l.wres) {      // persistent: ~one workgroup per CU and channel block, each with a contiguous run of tiles
+    const int64_t nt = (int64_t)tiles_x * tiles_y * in->n;
+    if (nt > 0x7fffffff) return false;
+    static const int cus = getenv("BP_WRES_GRID") ? atoi(getenv("BP_WRES_GRID")) : 256;
+    int nb = cus * (c.w_NW == 4 ? 2 : 1) / (int)l.grid.z;
+    if (nb < 1) nb = 1;
+    if (nb > nt) nb = (int)nt;
+    l.ntiles = (int)nt;
+    l.per_block = (int)((nt + nb - 1) / nb);
+    l.grid = dim3((unsigned)((nt + l.per_block - 1) / l.per_block), 1, l.grid.z);
+    l.lds = c.lds_wres; l.WM = c.w_NW;
+  }
   return true;
 }
 
@@ -1252,13 +1531,14 @@ static bool stats_plan(const ConvGeom& g, const IgemmConfig& c, const IgemmLaunc
   return true;
 }
 
-size_t bp_igemm_stats_workspace(const ConvGeom& g, const bp_view* in, const bp_view* out) {
-  if (bp_stem_ok(g)) return bp_stem_stats_workspace(out);
+size_t bp_igemm_stats_workspace(const ConvGeom& g, const bp_view* in, const bp_view* out, int mode) {
+  if (bp_stem_ok(g)) return mode == 1 ? bp_stem_stats_workspace(out) : 0;
   if (bp_small_ok(g)) return 0;
   const IgemmConfig c = igemm_config(g);
   IgemmLaunch l;
   StatsPlan p;
   if (!c.ok || !igemm_launch_of(g, c, in, out, l) || !stats_plan(g, c, l, p)) return 0;
+  if (l.wres && mode != 1) return 0;
   return p.bytes;
 }
 
@@ -1286,10 +1566,10 @@ int bp_igemm_run(const ConvGeom& g, const bp_view* in, const PW& pw, const float
   a.tiles_x = bp_ceil_div(qw, 16 * t.TPR);
   a.tiles_y = bp_ceil_div(qh, t.BH);
   const dim3 grid = l.grid;
-  a.in_pad4 = c.in_pad4; a.ts = c.ts; a.in_bufs = c.in_bufs;
+  a.in_pad4 = l.wres ? c.w_in_pad4 : c.in_pad4; a.ts = c.ts; a.in_bufs = c.in_bufs;
   StatsPlan sp{};
   if (sr) {
-    if (bias || !stats_plan(g, c, l, sp)) return BP_EUNSUPPORTED;
+    if (bias || !stats_plan(g, c, l, sp) || (l.wres && sr->mode != 1)) return BP_EUNSUPPORTED;
     if (!sr->ws || sr->ws_bytes < sp.bytes || !sr->sums) return BP_EWORKSPACE;
     a.stat = reinterpret_cast<double*>(sr->ws); a.stat_c = g.cout_g; a.stat_mode = sr->mode;
     if (sr->mode == 2) {
@@ -1299,7 +1579,8 @@ int bp_igemm_run(const ConvGeom& g, const bp_view* in, const PW& pw, const float
     }
   }
   int rc;
-  if (dma && c.dmaf) rc = launch_dmaf(c, a, grid, st);
+  if (l.wres) rc = launch_wres(c, a, grid, l.ntiles, l.per_block, st);
+  else if (dma && c.dmaf) rc = launch_dmaf(c, a, grid, st);
   else if (dma) rc = launch_dma(c, a, grid, st);
   else if (c.MT == 4) rc = launch_mt<4>(c, a, grid, st);
   else rc = launch_mt<1>(c, a, grid, st);

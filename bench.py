@@ -75,7 +75,8 @@ def kernel_name(kind, unit, lib):
     if kid >= 900000:
         return "small_conv_kernel<%d,%d,%d>" % (kid // 1000 % 100, kid // 10 % 100, kid % 10)
     dma, kid = divmod(kid, 100000)
-    return "%s<%d,%d,%d,%d>" % (("igemm_kernel", "igemm_dma_kernel", "igemm_dma8_kernel", "igemm_dmaf_kernel")[dma], kid // 1000,
+    return "%s<%d,%d,%d,%d>" % (("igemm_kernel", "igemm_dma_kernel", "igemm_dma8_kernel", "igemm_dmaf_kernel",
+                                 "igemm_wres_kernel")[dma], kid // 1000,
                                 kid // 100 % 10, kid // 10 % 10, kid % 10)
 
 

@@ -32,6 +32,10 @@ CASES = [
     (0, 16, 16, 3, 1, 1, (2, 9, 33)),
     (0, 4, 16, 3, 1, 1, (2, 11, 21)),
     (0, 3, 16, 5, 1, 2, (3, 37, 70)),         # the generator's stem (conv_stem.hip), ragged against its 8 x 64 tiles
+    (0, 16, 32, 4, 2, 1, (3, 30, 70)),         # weights-resident persistent kernel (igemm_wres_kernel): stride 2
+    (0, 16, 8, 7, 1, 3, (2, 19, 45)),          # ... 49 taps, two pixels per MFMA column block
+    (0, 8, 16, 7, 1, 3, (2, 19, 45)),
+    (0, 16, 32, 4, 2, 1, (70, 64, 64)),        # ... more tiles than workgroups
     (0, 3, 16, 5, 1, 2, (40, 130, 200)),      # ... with more tiles than workgroups (grid-stride walk)
 ]
 

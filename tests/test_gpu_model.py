@@ -212,25 +212,34 @@ def test_adam_step_matches_reference(golden_model):
 
 
 def test_flat_adam_equals_torch_adam():
+    """FlatAdam (one fused kernel over the flat parameter buffer) against torch.optim.Adam on the same gradients:
+    after ONE step from the same state the parameters agree to float32 rounding (the arithmetic is the same); over
+    three steps with a decaying learning rate the two trajectories stay together to a fraction of a step (they are
+    not bitwise comparable: a last-bit difference after step one moves the next gradient through the ReLU masks,
+    see ``conditioning``, and Adam normalises every gradient to a step of order lr)."""
     from baryon_painter_amd.optim import FlatAdam
     arch = A.fiducial_architecture(64)
     x, y, aux = syn.synthetic_batch(2, 64, 64, seed=3)
     eps = syn.synthetic_eps((1, 2, *arch["dim_z"]), seed=4)
-    finals = []
+    finals, first = [], []
     for kind in ("torch", "flat"):
         m, _ = _model(arch)
         m._eps_override = eps
         opt = torch.optim.Adam(m.parameters(), lr=1e-3) if kind == "torch" else FlatAdam(m, lr=1e-3)
         sched = torch.optim.lr_scheduler.LambdaLR(opt, lambda e: 0.5 ** e)
-        for _ in range(3):
+        for it in range(3):
             elbo = m(torch.from_numpy(x), torch.from_numpy(y), torch.from_numpy(aux))
             opt.zero_grad()
             (-elbo).backward()
             opt.step()
             sched.step()
+            if it == 0:
+                first.append((float(elbo.detach()), m._flat_params.clone()))
         finals.append((float(elbo.detach()), m._flat_params.clone()))
-    assert abs(finals[0][0] - finals[1][0]) <= 1e-5 * abs(finals[0][0])
-    assert G.rel_err(finals[1][1].cpu().numpy(), finals[0][1].cpu().numpy()) < 1e-5
+    assert first[0][0] == first[1][0]
+    assert G.rel_err(first[1][1].cpu().numpy(), first[0][1].cpu().numpy()) < 1e-6
+    assert abs(finals[0][0] - finals[1][0]) <= 1e-4 * abs(finals[0][0])
+    assert (finals[1][1] - finals[0][1]).abs().max().item() < 0.5e-3       # half of the first (largest) step
 
 
 def test_forward_is_deterministic_and_shape_checked():
@@ -305,5 +314,20 @@ def test_batch_sizes_L_and_eval_mode_against_oracle(n, L, train):
         return
     (-elbo).backward()
     g = ora.backward(seed=-1.0)
-    errs = sorted(((G.rel_err(p.grad.cpu().numpy(), g[k]), k) for k, p in m.named_parameters()), reverse=True)
-    assert errs[0][0] < 5e-3, errs[:4]
+    # float32 noise floor of these gradients: how far the TRUE gradient moves when the parameters are perturbed by
+    # 2^-20 relative -- the size of the difference between any float32 forward pass and the float64 one (activations
+    # agree to ~1e-6 of their scale).  At batch 1 a single ReLU unit at zero moves these gradients by percents (see
+    # ``conditioning``); which side of it a float32 evaluation lands on changes with the summation order of any kernel.
+    floor = {k: 0.0 for k in g}
+    rng = np.random.default_rng(7)
+    for _ in range(4):
+        pert = CVAEOracle(arch, dtype=np.float64)
+        pert.load_params({k: np.asarray(v, np.float64) * (1.0 + 2.0 ** -20 * rng.uniform(-1, 1, np.shape(v)))
+                          for k, v in P.items()})
+        pert.forward(x, y, aux, eps)
+        gp = pert.backward(seed=-1.0)
+        for k in g:
+            floor[k] = max(floor[k], G.rel_err(gp[k], g[k]))
+    errs = sorted(((G.rel_err(p.grad.cpu().numpy(), g[k]) / max(4 * floor[k], 5e-3), k) for k, p in m.named_parameters()),
+                  reverse=True)
+    assert errs[0][0] < 1.0, errs[:4]
