@@ -850,7 +850,7 @@ __global__ __launch_bounds__(256, 2) void igemm_dmaf_kernel(IgemmArgs a) {
 //   * eight waves share the tile (MT M-tiles each), so a thread carries ~10 staging registers, not ~20.
 // LDS image, fragments and epilogue are those of igemm_kernel; batch-norm sums (mode 1) are kept per lane over all
 // the tiles of the workgroup and folded once.
-template <int CC, int NT, int MT, int NW, int SLOTS>
+template <int CC, int NT, int MT, int NW, int SLOTS, bool STATS>
 __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void igemm_wres_kernel(IgemmArgs a, int ntiles_total, int per_block) {
   constexpr int VW = CC / 4;
   constexpr int NTH = 64 * NW;
@@ -898,15 +898,16 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void igemm_wres_kernel(Ig
   // staging slots of this thread: (row, column, channel quad) of the halo element, the same for every tile
   const int in_elems4 = a.IH * a.IW * VW;
   const int c4 = tid % VW;                      // NTH % VW == 0
-  int s_r[SLOTS], s_c[SLOTS], s_l[SLOTS];
+  int s_rc[SLOTS], s_l[SLOTS];                  // (row << 16 | column) of the halo element, its LDS offset (-1: unused)
 #pragma unroll
   for (int i = 0; i < SLOTS; ++i) {
     const int e = tid + i * NTH;
-    s_l[i] = -1; s_r[i] = 0; s_c[i] = 0;
+    s_l[i] = -1; s_rc[i] = 0;
     if (e < in_elems4) {
       const int pix = e / VW;
-      s_c[i] = pix % a.IW; s_r[i] = pix / a.IW;
-      s_l[i] = ((s_r[i] * a.ISx + s_c[i] % a.ISx) * a.IWq + s_c[i] / a.ISx) * CC + c4 * 4;
+      const int c = pix % a.IW, r = pix / a.IW;
+      s_rc[i] = (r << 16) | c;
+      s_l[i] = ((r * a.ISx + c % a.ISx) * a.IWq + c / a.ISx) * CC + c4 * 4;
     }
   }
   const PW4 p4 = pw4_load(a.pw, c4 * 4, a.cin);
@@ -929,7 +930,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void igemm_wres_kernel(Ig
     inside = 0;
 #pragma unroll
     for (int i = 0; i < SLOTS; ++i) {
-      const int iy = gy0 + s_r[i], ix = gx0 + s_c[i];
+      const int iy = gy0 + (s_rc[i] >> 16), ix = gx0 + (s_rc[i] & 0xffff);
       if (s_l[i] >= 0 && iy >= 0 && iy < a.in_h && ix >= 0 && ix < a.in_w) inside |= 1u << i;
       const int cy = min(max(iy, 0), a.in_h - 1), cx = min(max(ix, 0), a.in_w - 1);
       stage[i] = *reinterpret_cast<const float4*>(in_n + (cy * a.in_w + cx) * a.in_cs);
@@ -943,9 +944,10 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void igemm_wres_kernel(Ig
             ((inside >> i) & 1u) ? pw4_apply4(p4, stage[i]) : make_float4(0.f, 0.f, 0.f, 0.f);
   };
 
-  double s1[NT][4], s2[NT][4];
+  constexpr int SN = STATS ? NT : 1;            // (the sums cost 16 * NT registers: only the batch-norm layers' variant has them)
+  double s1[SN][4], s2[SN][4];
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt)
+  for (int nt = 0; nt < SN; ++nt)
 #pragma unroll
     for (int r = 0; r < 4; ++r) { s1[nt][r] = 0.0; s2[nt][r] = 0.0; }
 
@@ -1004,7 +1006,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void igemm_wres_kernel(Ig
     tile_origin(t, &n, &qy0, &qx0);
     float* out_n = a.out + (int64_t)n * a.out_h * a.out_w * a.out_cs + a.out_co;
     igemm_store<NT, MT>(a, acc, out_n, wm, 0, lm, kq, co0, qy0, qx0, qh, qw, 0, 0);
-    if (a.stat) {
+    if constexpr (STATS) {
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
         const int tt = wm * MT + mt;
@@ -1023,7 +1025,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void igemm_wres_kernel(Ig
     if (t + 1 < t_end) commit();
     __syncthreads();
   }
-  if (a.stat) {
+  if constexpr (STATS) {
     double* red = reinterpret_cast<double*>(lds_in);        // [NW][COB][2]
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
@@ -1203,7 +1205,7 @@ IgemmConfig igemm_config(const ConvGeom& g) {
   // Thin strided / many-tap gathers: weights resident, persistent (igemm_wres_kernel).
   static const bool no_wres = getenv("BP_IGEMM_NOWRES") != nullptr;
   static const bool wres_all = getenv("BP_IGEMM_WRESALL") != nullptr;
-  if (!no_wres && c.NT <= 2 && c.PP <= 2 && g.nphase == 1 && g.OS == 1 && (g.cin_g == 16 || (g.cin_g == 8 && wres_all)) &&
+  if (!no_wres && c.NT <= 2 && c.PP <= 2 && g.nphase == 1 && g.OS == 1 && g.cin_g == 16 &&
       (g.IS == 2 || g.taps >= 5 || wres_all)) {
     const int CC = g.cin_g;
     static const bool no_w4 = getenv("BP_WRES_NO4") != nullptr;
@@ -1218,7 +1220,7 @@ IgemmConfig igemm_config(const ConvGeom& g) {
       const bool plain_ok = plain_lds(tile_geom(16, g.IS, c.ISx, g.taps, c.tapsx), CC) <= 64 * 1024 ||
                             plain_lds(tile_geom(4, g.IS, c.ISx, g.taps, c.tapsx), CC) <= 64 * 1024;
       if (lds <= (size_t)(NW == 4 ? 80 : 150) * 1024 && slots <= 12 && plain_ok) {
-        c.wres = true; c.CC = CC; c.tw = tw; c.w_slots = slots <= 8 ? 8 : 12; c.w_in_pad4 = in_pad4; c.lds_wres = lds;
+        c.wres = true; c.CC = CC; c.tw = tw; c.w_slots = slots <= 8 ? 8 : (slots <= 10 ? 10 : 12); c.w_in_pad4 = in_pad4; c.lds_wres = lds;
         c.w_NW = NW;
       }
     }
@@ -1371,27 +1373,37 @@ int launch_dma(const IgemmConfig& c, const IgemmArgs& a, dim3 grid, hipStream_t 
   return BP_EUNSUPPORTED;
 }
 
-template <int CC, int NT, int SLOTS, int NW>
-int launch_wres_one(const IgemmConfig& c, const IgemmArgs& a, dim3 grid, int ntiles, int per_block, hipStream_t st) {
+template <int CC, int NT, int SLOTS, int NW, bool STATS>
+int launch_wres_st(const IgemmConfig& c, const IgemmArgs& a, dim3 grid, int ntiles, int per_block, hipStream_t st) {
   static const hipError_t optin = hipFuncSetAttribute(
-      reinterpret_cast<const void*>(&igemm_wres_kernel<CC, NT, 2, NW, SLOTS>),
+      reinterpret_cast<const void*>(&igemm_wres_kernel<CC, NT, 2, NW, SLOTS, STATS>),
       hipFuncAttributeMaxDynamicSharedMemorySize, (NW == 4 ? 80 : 150) * 1024);
   if (optin != hipSuccess) return BP_ELAUNCH;
-  hipLaunchKernelGGL((igemm_wres_kernel<CC, NT, 2, NW, SLOTS>), grid, dim3(64 * NW), c.lds_wres, st, a, ntiles, per_block);
+  hipLaunchKernelGGL((igemm_wres_kernel<CC, NT, 2, NW, SLOTS, STATS>), grid, dim3(64 * NW), c.lds_wres, st, a, ntiles,
+                     per_block);
   BP_CHECK_LAUNCH();
   return BP_OK;
+}
+
+template <int CC, int NT, int SLOTS, int NW>
+int launch_wres_one(const IgemmConfig& c, const IgemmArgs& a, dim3 grid, int ntiles, int per_block, hipStream_t st) {
+  if (a.stat) return launch_wres_st<CC, NT, SLOTS, NW, true>(c, a, grid, ntiles, per_block, st);
+  return launch_wres_st<CC, NT, SLOTS, NW, false>(c, a, grid, ntiles, per_block, st);
 }
 
 int launch_wres(const IgemmConfig& c, const IgemmArgs& a, dim3 grid, int ntiles, int per_block, hipStream_t st) {
 #define BP_WRES(CCv, NTv) \
   if (c.CC == CCv && c.NT == NTv) { \
-    if (c.w_NW == 4) \
-      return c.w_slots == 8 ? launch_wres_one<CCv, NTv, 8, 4>(c, a, grid, ntiles, per_block, st) \
-                            : launch_wres_one<CCv, NTv, 12, 4>(c, a, grid, ntiles, per_block, st); \
-    return c.w_slots == 8 ? launch_wres_one<CCv, NTv, 8, 8>(c, a, grid, ntiles, per_block, st) \
-                          : launch_wres_one<CCv, NTv, 12, 8>(c, a, grid, ntiles, per_block, st); \
+    if (c.w_NW == 4) { \
+      if (c.w_slots == 8) return launch_wres_one<CCv, NTv, 8, 4>(c, a, grid, ntiles, per_block, st); \
+      if (c.w_slots == 10) return launch_wres_one<CCv, NTv, 10, 4>(c, a, grid, ntiles, per_block, st); \
+      return launch_wres_one<CCv, NTv, 12, 4>(c, a, grid, ntiles, per_block, st); \
+    } \
+    if (c.w_slots == 8) return launch_wres_one<CCv, NTv, 8, 8>(c, a, grid, ntiles, per_block, st); \
+    if (c.w_slots == 10) return launch_wres_one<CCv, NTv, 10, 8>(c, a, grid, ntiles, per_block, st); \
+    return launch_wres_one<CCv, NTv, 12, 8>(c, a, grid, ntiles, per_block, st); \
   }
-  BP_WRES(16, 1) BP_WRES(16, 2) BP_WRES(8, 1) BP_WRES(8, 2)
+  BP_WRES(16, 1) BP_WRES(16, 2)
 #undef BP_WRES
   return BP_EUNSUPPORTED;
 }
