@@ -297,6 +297,11 @@ bool bp_stem_wgrad_ok(const bp_conv* cv, const bp_view* X, const bp_view* Y, con
 size_t bp_stem_wgrad_workspace(const bp_view* X);
 int bp_stem_wgrad(const bp_view* X, const PW& pwx, const bp_view* Y, float* dst, void* workspace, size_t workspace_bytes,
                   hipStream_t st);
+// conv_wgrad_flat.hip: weight gradient of the 16 -> 8 k7 head layer
+bool bp_wgrad_flat_ok(const bp_conv* cv, const bp_view* X, const bp_view* Y, const PW& pwy);
+size_t bp_wgrad_flat_workspace(const bp_view* X);
+int bp_wgrad_flat(const bp_view* X, const PW& pwx, const bp_view* Y, float* dst, void* workspace, size_t workspace_bytes,
+                  hipStream_t st);
 static size_t wgrad_general_workspace(const bp_conv* cv, const bp_view* X, const bp_view* Y);
 
 size_t bp_wgrad_mfma_workspace(const bp_conv* cv, const bp_view* X, const bp_view* Y) {
@@ -304,6 +309,10 @@ size_t bp_wgrad_mfma_workspace(const bp_conv* cv, const bp_view* X, const bp_vie
   if (bp_stem_wgrad_ok(cv, X, Y, PW{nullptr, nullptr, nullptr}, nullptr)) {
     const size_t stem = bp_stem_wgrad_workspace(X);
     return stem > general ? stem : general;
+  }
+  if (bp_wgrad_flat_ok(cv, X, Y, PW{nullptr, nullptr, nullptr})) {
+    const size_t flat = bp_wgrad_flat_workspace(X);
+    return flat > general ? flat : general;
   }
   return general;
 }
@@ -324,6 +333,7 @@ static size_t wgrad_general_workspace(const bp_conv* cv, const bp_view* X, const
 int bp_wgrad_mfma(const bp_conv* cv, const bp_view* X, const PW& pwx, const bp_view* Y, const PW& pwy,
                   float* dst, void* workspace, size_t workspace_bytes, hipStream_t st) {
   if (bp_stem_wgrad_ok(cv, X, Y, pwy, nullptr)) return bp_stem_wgrad(X, pwx, Y, dst, workspace, workspace_bytes, st);
+  if (bp_wgrad_flat_ok(cv, X, Y, pwy)) return bp_wgrad_flat(X, pwx, Y, dst, workspace, workspace_bytes, st);
   {
     bool on_x = false;
     if (wide_side_chunks(cv, X, Y, &on_x)) {

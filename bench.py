@@ -60,6 +60,8 @@ def kernel_name(kind, unit, lib):
         cx, cy = (cv.cout, cv.cin) if cv.transposed else (cv.cin, cv.cout)
         if (cv.transposed, cv.cin, cv.cout, cv.k, cv.stride, cv.pad) == (0, 3, 16, 5, 1, 2):
             return "stem_wgrad_kernel"
+        if (cv.transposed, cv.cin, cv.cout, cv.k, cv.stride, cv.pad) == (0, 16, 8, 7, 1, 3):
+            return "wgrad_flat_kernel"
         if cx <= 16 and cy <= 16 and not (cx == 16 and cy == 16) and (cv.k, cv.stride) in ((3, 1), (5, 1), (7, 1), (4, 2), (8, 4)):
             return "wgrad_small_kernel[k%ds%d %d,%d]" % (cv.k, cv.stride, cx, cy)
         return "wgrad_tiles_kernel[k%ds%d %s]" % (cv.k, cv.stride, "wide" if (cx > 16 and cy > 16) else "thin")

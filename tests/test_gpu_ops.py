@@ -143,6 +143,9 @@ DMA_CASES = [
     (0, 64, 128, 4, 2, 1, (2, 10, 38)),
     (1, 64, 32, 4, 2, 1, (3, 5, 9)),
     (1, 128, 64, 4, 2, 1, (2, 7, 18)),
+    (0, 16, 32, 4, 2, 1, (3, 30, 70)),        # weights-resident persistent igemm (stride-2 gather)
+    (0, 16, 8, 7, 1, 3, (3, 21, 45)),         # ... 49 taps; weight gradient: conv_wgrad_flat.hip
+    (0, 16, 8, 7, 1, 3, (9, 64, 250)),        # ... more tiles than workgroups (grid-stride walk)
 ]
 
 
