@@ -89,6 +89,36 @@ __device__ __forceinline__ void load_unit(const void* base, int64_t elem_off, fl
   }
 }
 
+// The same unit as raw 16-byte words (conversion deferred): a prefetch must not touch the loaded registers, or the
+// wait for the data lands right behind the load instead of after the MFMAs the load was meant to overlap.
+template <int U, bool IN_BF16> struct RawUnit { uint4 q[IN_BF16 ? 1 : U / 4]; };
+template <int U, bool IN_BF16>
+__device__ __forceinline__ void load_unit_raw(const void* base, int64_t elem_off, RawUnit<U, IN_BF16>& r) {
+  if constexpr (IN_BF16) {
+    const u16* p = reinterpret_cast<const u16*>(base) + elem_off;
+    if constexpr (U == 8) r.q[0] = *reinterpret_cast<const uint4*>(p);
+    else { const uint2 t = *reinterpret_cast<const uint2*>(p); r.q[0] = make_uint4(t.x, t.y, 0u, 0u); }
+  } else {
+    const float* p = reinterpret_cast<const float*>(base) + elem_off;
+#pragma unroll
+    for (int j = 0; j < U / 4; ++j) r.q[j] = *reinterpret_cast<const uint4*>(p + 4 * j);
+  }
+}
+template <int U, bool IN_BF16>
+__device__ __forceinline__ void unpack_unit(const RawUnit<U, IN_BF16>& r, float (&v)[U]) {
+  if constexpr (IN_BF16) {
+    const unsigned w[4] = {r.q[0].x, r.q[0].y, r.q[0].z, r.q[0].w};
+#pragma unroll
+    for (int j = 0; j < U / 2; ++j) { v[2 * j] = bf2f((u16)(w[j] & 0xffffu)); v[2 * j + 1] = bf2f((u16)(w[j] >> 16)); }
+  } else {
+#pragma unroll
+    for (int j = 0; j < U / 4; ++j) {
+      v[4 * j] = __builtin_bit_cast(float, r.q[j].x); v[4 * j + 1] = __builtin_bit_cast(float, r.q[j].y);
+      v[4 * j + 2] = __builtin_bit_cast(float, r.q[j].z); v[4 * j + 3] = __builtin_bit_cast(float, r.q[j].w);
+    }
+  }
+}
+
 template <int U>
 __device__ __forceinline__ void lds_store_unit(u16* dst, const float (&v)[U]) {
   if constexpr (U == 8) {
@@ -179,7 +209,7 @@ __device__ __forceinline__ void b_store_tile(const BArgs& a, const v4f (&acc)[MT
 // matrix work per 295 KB of weights, and streaming the weights from L2 once per tile is what bounds the kernel; eight
 // waves (256 pixels) halve that traffic per pixel.
 template <int CC, int NT, int WN, int MT, int SLOTS, bool IN_BF16, bool OUT_BF16, int NW = 4>
-__global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void igemm_bf16_kernel(BArgs a) {
+__global__ __launch_bounds__(64 * NW, 2) void igemm_bf16_kernel(BArgs a) {
   constexpr int U = CC < 8 ? CC : 8;            // channels per staging unit
   constexpr int UPP = CC / U;                   // units per pixel
   constexpr int WM = NW / WN;
@@ -263,32 +293,45 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void igemm_bf16_kernel(BA
     }
   }
 
-  float stage[SLOTS][U];
+  RawUnit<U, IN_BF16> stage[SLOTS];
+  // Every slot loads (slots outside the image / unused fetch the image's first pixel and are zeroed when stored):
+  // a load under a per-lane condition is followed by a full vmcnt(0) wait by the compiler, which serialises the
+  // slots of a chunk -- one HBM round trip each -- instead of having them all in flight.
   auto load_chunk = [&](int chunk) {
 #pragma unroll
     for (int i = 0; i < SLOTS; ++i)
-      if (s_g[i] >= 0) load_unit<U, IN_BF16>(a.in, in_img + s_g[i] + chunk * CC, stage[i]);
+      load_unit_raw<U, IN_BF16>(a.in, in_img + (s_g[i] >= 0 ? s_g[i] : 0) + chunk * CC, stage[i]);
   };
+  // the pending activation's parameters live in LDS ([scale | shift | slope][nchunk * CC], identity past cin): read
+  // per chunk from global memory they are 3 * U dependent loads, each waited for, in front of every chunk
+  float* lpw = reinterpret_cast<float*>(lds_w + 2 * slab_t);
+  const int cpad = a.nchunk * CC;
+  const bool on = a.pw.scale != nullptr;
+  if (on) {
+    for (int i = tid; i < cpad; i += NTH) {
+      const bool ok = i < a.cin;
+      lpw[i] = ok ? a.pw.scale[i] : 1.f; lpw[cpad + i] = ok ? a.pw.shift[i] : 0.f; lpw[2 * cpad + i] = ok ? a.pw.slope[i] : 1.f;
+    }
+  }
   auto store_chunk = [&](int chunk) {
     const int ch = chunk * CC + cu * U;
     float sc[U], sf[U], sl[U];
-    const bool on = a.pw.scale != nullptr;
 #pragma unroll
     for (int j = 0; j < U; ++j) {
-      const bool ok = on && ch + j < a.cin;
-      sc[j] = ok ? a.pw.scale[ch + j] : 1.f;
-      sf[j] = ok ? a.pw.shift[ch + j] : 0.f;
-      sl[j] = ok ? a.pw.slope[ch + j] : 1.f;
+      sc[j] = on ? lpw[ch + j] : 1.f;
+      sf[j] = on ? lpw[cpad + ch + j] : 0.f;
+      sl[j] = on ? lpw[2 * cpad + ch + j] : 1.f;
     }
 #pragma unroll
     for (int i = 0; i < SLOTS; ++i) {
       if (s_g[i] == -2) continue;
-      float v[U];
+      float v[U], raw[U];
+      unpack_unit<U, IN_BF16>(stage[i], raw);
 #pragma unroll
       for (int j = 0; j < U; ++j) {
         float t = 0.f;
         if (s_g[i] >= 0 && ch + j < a.cin) {
-          t = stage[i][j];
+          t = raw[j];
           if (on) { t = fmaf(t, sc[j], sf[j]); t = t > 0.f ? t : t * sl[j]; }
         }
         v[j] = t;
@@ -439,7 +482,7 @@ __global__ __launch_bounds__(256, 2) void igemm_bf16_p_kernel(BPArgs pa) {
     sl[j] = ok ? a.pw.slope[cu * U + j] : 1.f;
   }
 
-  float stage[SLOTS][U];
+  RawUnit<U, IN_BF16> stage[SLOTS];
   unsigned inside = 0;
   auto tile_coords = [&](int t, int* n, int* qy0, int* qx0) {
     *n = t / tiles_per_img;
@@ -452,26 +495,27 @@ __global__ __launch_bounds__(256, 2) void igemm_bf16_p_kernel(BPArgs pa) {
     tile_coords(t, &n, &qy0, &qx0);
     const int gy0 = a.ISy * qy0 + iy0, gx0 = a.ISx * qx0 + ix0;
     const int64_t img = (int64_t)n * a.in_h * a.in_w * a.in_cs + a.in_co + cu * U;
+    // every slot loads, coordinates clamped into the image (see igemm_bf16_kernel::load_chunk)
     inside = 0;
 #pragma unroll
     for (int i = 0; i < SLOTS; ++i) {
       const int iy = gy0 + s_r[i], ix = gx0 + s_c[i];
-      if (s_r[i] >= 0 && iy >= 0 && iy < a.in_h && ix >= 0 && ix < a.in_w) {
-        inside |= 1u << i;
-        load_unit<U, IN_BF16>(a.in, img + ((int64_t)iy * a.in_w + ix) * a.in_cs, stage[i]);
-      }
+      if (s_r[i] >= 0 && iy >= 0 && iy < a.in_h && ix >= 0 && ix < a.in_w) inside |= 1u << i;
+      const int cy = min(max(iy, 0), a.in_h - 1), cx = min(max(ix, 0), a.in_w - 1);
+      load_unit_raw<U, IN_BF16>(a.in, img + ((int64_t)cy * a.in_w + cx) * a.in_cs, stage[i]);
     }
   };
   auto store_tile = [&]() {
 #pragma unroll
     for (int i = 0; i < SLOTS; ++i) {
       if (s_r[i] < 0) continue;
-      float v[U];
+      float v[U], raw[U];
+      unpack_unit<U, IN_BF16>(stage[i], raw);
 #pragma unroll
       for (int j = 0; j < U; ++j) {
         float t = 0.f;
         if (((inside >> i) & 1u) && cu * U + j < a.cin) {
-          t = stage[i][j];
+          t = raw[j];
           if (on) { t = fmaf(t, sc[j], sf[j]); t = t > 0.f ? t : t * sl[j]; }
         }
         v[j] = t;
@@ -579,14 +623,17 @@ static inline BConfig b_config_for(const ConvGeom& g, int NT, int WN, int NW = 4
   c.slots = bp_ceil_div(E, 64 * NW);
   c.npixp = bp_round_up(c.IH * g.IS * c.IWq, 16);
   const size_t in_b = (((size_t)c.npixp * c.CC + 511) & ~(size_t)511) * 2;
-  c.lds_bytes = in_b + (size_t)2 * c.nrun * c.COB * 32 * 2;        // two weight slabs
+  c.lds_bytes = in_b + (size_t)2 * c.nrun * c.COB * 32 * 2          // two weight slabs
+                + (size_t)3 * c.nchunk * c.CC * sizeof(float);       // + the pending activation's parameters
   c.ok = c.lds_bytes <= 80 * 1024 && c.slots <= 12;       // two workgroups per CU
   c.lds_p = in_b + (size_t)g.taps * c.nrun * c.COB * 32 * 2;
   static const bool no_p = getenv("BP_BF16_NOPERSIST") != nullptr;
   // (measured on the fiducial layers: the persistent form wins for the strided gathers -- 16->32 k4s2 forward
-  //  0.61 -> 0.46 ms, 32->16 transposed data gradient 0.54 -> 0.41 ms -- whose halo tiles are four times the
-  //  output tile, and loses 10-20 % on the unit-stride forms, which are bound by LDS fragment reads, not by staging)
-  c.persistent = c.ok && !no_p && NW == 4 && c.nchunk == 1 && c.lds_p <= 64 * 1024 && g.IS == 2;
+  //  0.61 -> 0.28 ms, 32->16 transposed data gradient 0.54 -> 0.27 ms -- whose halo tiles are four times the
+  //  output tile, and for the four-phase transposed forms -- 32->16 forward 0.71 -> 0.61 ms; the unit-stride k7 head
+  //  is the same either way)
+  static const bool p_all = getenv("BP_BF16_PALL") != nullptr;
+  c.persistent = c.ok && !no_p && NW == 4 && c.nchunk == 1 && c.lds_p <= 64 * 1024 && (g.IS == 2 || g.nphase > 1 || p_all);
   return c;
 }
 

@@ -36,7 +36,9 @@ struct WbCfg {
   static constexpr int TAPS = KHB * KW;
   static constexpr size_t LDS_MAIN = (size_t)(CXC / 16 * XT + CYC / 16 * YT) * 2;
   static constexpr size_t LDS_RED = WK > 1 ? (size_t)WK * NTX * NTY * 64 * 4 * 4 : 0;
-  static constexpr size_t LDS = LDS_MAIN > LDS_RED ? LDS_MAIN : LDS_RED;
+  static constexpr size_t LDS_TILES = LDS_MAIN > LDS_RED ? LDS_MAIN : LDS_RED;
+  static constexpr size_t LDS_PW = (size_t)3 * (CXC + CYC) * sizeof(float);     // pending activations of both sides
+  static constexpr size_t LDS = LDS_TILES + LDS_PW;
 };
 
 __device__ __forceinline__ s4 lds_tr(const u16* p) {
@@ -129,6 +131,129 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(WbArgs a) {
 
   const int tiles_per_img = a.tiles_x * a.tiles_y;
   const int ntiles = a.n * tiles_per_img;
+  auto multiply = [&]() {
+    // ---- this wave's rows of the tile
+#pragma unroll 1
+    for (int r = wk; r < BH; r += WK) {
+      bf8 yf[NTY];
+#pragma unroll
+      for (int j = 0; j < NTY; ++j) {
+        const u16* p = ys + (wy * NTY + j) * YT + r * 32 * 16 + trl;
+        yf[j] = frag_of(lds_tr(p), lds_tr(p + 16 * 16));
+      }
+#pragma unroll
+      for (int kyl = 0; kyl < KHB; ++kyl)
+#pragma unroll
+        for (int kx = 0; kx < KW; ++kx) {
+          const int toff = (((r * S + kyl) * S + kx % S) * IWq + kx / S) * 16;
+#pragma unroll
+          for (int i = 0; i < NTX; ++i) {
+            const u16* p = xs + (wx * NTX + i) * XT + toff + trl;
+            const bf8 xf = frag_of(lds_tr(p), lds_tr(p + 16 * 16));
+#pragma unroll
+            for (int j = 0; j < NTY; ++j)
+              acc[kyl * KW + kx][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf, yf[j], acc[kyl * KW + kx][i][j], 0, 0, 0);
+          }
+        }
+    }
+  };
+  // Staging, pipelined form (channel counts that are multiples of 8: 16-byte units).  A thread's units of the NEXT tile
+  // are fetched -- all of them back to back, as raw 16-byte words, coordinates clamped into the image -- before this
+  // tile is multiplied, and activated / rounded / written to LDS after it.  (Loading under a per-lane condition, or
+  // converting right behind the load, makes the compiler wait for every load in turn: one HBM round trip per unit.)
+  constexpr int NXS = (XR * S * IWq * XU + 255) / 256, NYS = (BH * 32 * YU + 255) / 256;
+  if (xvec && yvec) {
+    // the activation parameters of this thread's channel groups, parked in LDS (48 registers otherwise)
+    float* lpw = reinterpret_cast<float*>(reinterpret_cast<char*>(smem) + Cfg::LDS_TILES);
+    if (tid < XU) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { lpw[tid * 8 + j] = xsc[j]; lpw[CXC + tid * 8 + j] = xsf[j]; lpw[2 * CXC + tid * 8 + j] = xsl[j]; }
+    }
+    if (tid < YU) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        lpw[3 * CXC + tid * 8 + j] = ysc[j]; lpw[3 * CXC + CYC + tid * 8 + j] = ysf[j]; lpw[3 * CXC + 2 * CYC + tid * 8 + j] = ysl[j];
+      }
+    }
+    RawUnit<8, XB> xr[NXS];
+    RawUnit<8, YB> yr[NYS];
+    unsigned xin = 0, yin = 0;
+    const int xch = cx0 + xcu * 8, ych = cy0 + ycu * 8;
+    auto fetch = [&](int tile) {
+      const int n = tile / tiles_per_img;
+      const int trem = tile - n * tiles_per_img;
+      const int ty_ = trem / a.tiles_x, tx_ = trem - ty_ * a.tiles_x;
+      const int qy0 = ty_ * BH, qx0 = tx_ * 32;
+      const int gy0 = qy0 * S + ky0 - a.pad, gx0 = qx0 * S - a.pad;
+      const int64_t ximg = (int64_t)n * a.xh * a.xw * a.xcs + a.xco + (xch < a.cx ? xch : 0);
+      const int64_t yimg = (int64_t)n * a.yh * a.yw * a.ycs + a.yco + (ych < a.cy ? ych : 0);
+      xin = 0; yin = 0;
+#pragma unroll
+      for (int i = 0; i < NXS; ++i) {
+        const int e = tid + i * 256;
+        const int pi = e / XU;
+        const int xq = pi % IWq;
+        const int t = pi / IWq;
+        const int xm = t % S, r = t / S;
+        const int iy = gy0 + r, ix = gx0 + xq * S + xm;
+        if (e < XR * S * IWq * XU && iy >= 0 && iy < a.xh && ix >= 0 && ix < a.xw && xch < a.cx) xin |= 1u << i;
+        const int cy = min(max(iy, 0), a.xh - 1), cx = min(max(ix, 0), a.xw - 1);
+        load_unit_raw<8, XB>(a.X, ximg + ((int64_t)cy * a.xw + cx) * a.xcs, xr[i]);
+      }
+#pragma unroll
+      for (int i = 0; i < NYS; ++i) {
+        const int e = tid + i * 256;
+        const int pi = e / YU;
+        const int c = pi & 31, r = pi >> 5;
+        const int qy = qy0 + r, qx = qx0 + c;
+        if (e < BH * 32 * YU && qy < a.yh && qx < a.yw && ych < a.cy) yin |= 1u << i;
+        const int cy = min(qy, a.yh - 1), cx = min(qx, a.yw - 1);
+        load_unit_raw<8, YB>(a.Y, yimg + ((int64_t)cy * a.yw + cx) * a.ycs, yr[i]);
+      }
+    };
+    auto commit = [&]() {
+#pragma unroll
+      for (int i = 0; i < NXS; ++i) {
+        const int e = tid + i * 256;
+        if (e >= XR * S * IWq * XU) continue;
+        float v[8], raw[8];
+        unpack_unit<8, XB>(xr[i], raw);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          float u = raw[j];
+          if (xon) { u = fmaf(u, lpw[xcu * 8 + j], lpw[CXC + xcu * 8 + j]); u = u > 0.f ? u : u * lpw[2 * CXC + xcu * 8 + j]; }
+          v[j] = ((xin >> i) & 1u) ? u : 0.f;
+        }
+        lds_store_unit<8>(xs + (xcu >> 1) * XT + (e / XU) * 16 + (xcu & 1) * 8, v);
+      }
+#pragma unroll
+      for (int i = 0; i < NYS; ++i) {
+        const int e = tid + i * 256;
+        if (e >= BH * 32 * YU) continue;
+        float v[8], raw[8];
+        unpack_unit<8, YB>(yr[i], raw);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          float u = raw[j];
+          if (yon) {
+            u = fmaf(u, lpw[3 * CXC + ycu * 8 + j], lpw[3 * CXC + CYC + ycu * 8 + j]);
+            u = u > 0.f ? u : u * lpw[3 * CXC + 2 * CYC + ycu * 8 + j];
+          }
+          v[j] = ((yin >> i) & 1u) ? u : 0.f;
+        }
+        lds_store_unit<8>(ys + (ycu >> 1) * YT + (e / YU) * 16 + (ycu & 1) * 8, v);
+      }
+    };
+    int tile = split;
+    if (tile < ntiles) fetch(tile);
+    for (; tile < ntiles; tile += a.nsplit) {
+      __syncthreads();                // the previous tile's readers are done
+      commit();
+      __syncthreads();
+      if (tile + a.nsplit < ntiles) fetch(tile + a.nsplit);
+      multiply();
+    }
+  } else
   for (int tile = split; tile < ntiles; tile += a.nsplit) {
     const int n = tile / tiles_per_img;
     const int trem = tile - n * tiles_per_img;
@@ -185,30 +310,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(WbArgs a) {
       }
     }
     __syncthreads();
-    // ---- this wave's rows of the tile
-#pragma unroll 1
-    for (int r = wk; r < BH; r += WK) {
-      bf8 yf[NTY];
-#pragma unroll
-      for (int j = 0; j < NTY; ++j) {
-        const u16* p = ys + (wy * NTY + j) * YT + r * 32 * 16 + trl;
-        yf[j] = frag_of(lds_tr(p), lds_tr(p + 16 * 16));
-      }
-#pragma unroll
-      for (int kyl = 0; kyl < KHB; ++kyl)
-#pragma unroll
-        for (int kx = 0; kx < KW; ++kx) {
-          const int toff = (((r * S + kyl) * S + kx % S) * IWq + kx / S) * 16;
-#pragma unroll
-          for (int i = 0; i < NTX; ++i) {
-            const u16* p = xs + (wx * NTX + i) * XT + toff + trl;
-            const bf8 xf = frag_of(lds_tr(p), lds_tr(p + 16 * 16));
-#pragma unroll
-            for (int j = 0; j < NTY; ++j)
-              acc[kyl * KW + kx][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf, yf[j], acc[kyl * KW + kx][i][j], 0, 0, 0);
-          }
-        }
-    }
+    multiply();
   }
 
   // ---- partial tiles of this split: D[row = 4*kq + r : X channel][col = li : Y channel]
