@@ -306,10 +306,10 @@ __global__ __launch_bounds__(256, (MT == 4 && NT == 4) ? 4 : 1) void igemm_kerne
 
   // Staging slots of this thread: the (row, column) of each halo element it copies is the same for every
   // channel chunk, so the global offset (or -1 outside the image) and the LDS offset are computed once.
-  constexpr int SLOTS = NT == 4 ? 3 : (NT == 2 ? 8 : 1);   // NT 1: few channels, occupancy matters more
+  constexpr int SLOTS = NT == 4 ? 3 : (NT == 2 ? 8 : 6);   // (NT 1 used to take the element-by-element path: every load waited for)
   constexpr int SG = SLOTS < 4 ? SLOTS : 4;                // loads in flight per thread
   const int c4 = tid % VW;                                 // 256 % VW == 0: fixed channel quad per thread
-  const bool slots_ok = NT > 1 && in_elems4 <= SLOTS * 256;
+  const bool slots_ok = in_elems4 <= SLOTS * 256;
   int s_g[SLOTS], s_l[SLOTS];
 #pragma unroll
   for (int i = 0; i < SLOTS; ++i) {
@@ -336,8 +336,8 @@ __global__ __launch_bounds__(256, (MT == 4 && NT == 4) ? 4 : 1) void igemm_kerne
         for (int i0 = 0; i0 < SLOTS; i0 += SG) {
           float4 v[SG];
 #pragma unroll
-          for (int i = 0; i < SG; ++i)
-            if (s_g[i0 + i] >= 0) v[i] = *reinterpret_cast<const float4*>(in_n + s_g[i0 + i] + ch);
+          for (int i = 0; i < SG; ++i)       // (unconditional: a load under a per-lane condition may be waited for on the spot)
+            v[i] = *reinterpret_cast<const float4*>(in_n + (s_g[i0 + i] >= 0 ? s_g[i0 + i] : 0) + ch);
 #pragma unroll
           for (int i = 0; i < SG; ++i)
             if (s_l[i0 + i] >= 0)

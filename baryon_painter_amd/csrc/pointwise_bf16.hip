@@ -74,11 +74,25 @@ __global__ __launch_bounds__(RB) void channel_sums_bf16_kernel(const uint4* __re
   double acc[2][8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) { acc[0][j] = 0.0; acc[1][j] = 0.0; }
-  for (int64_t i = b0 + threadIdx.x; i < b1; i += RB) {
-    float v[8];
-    unpack8(x[i], v);
+  // four elements per trip: their loads are in flight together, their sums are taken in fp32 (the elements carry 8
+  // mantissa bits) and added to the double accumulators once per trip -- a quarter of the double-rate instructions
+  for (int64_t i = b0 + threadIdx.x; i < b1; i += 4 * RB) {
+    uint4 q[4];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { acc[0][j] += v[j]; acc[1][j] += (double)v[j] * v[j]; }
+    for (int u = 0; u < 4; ++u) q[u] = x[i + u * RB < b1 ? i + u * RB : i];
+    float p0[8], p1[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { p0[j] = 0.f; p1[j] = 0.f; }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (i + u * RB >= b1) break;
+      float v[8];
+      unpack8(q[u], v);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { p0[j] += v[j]; p1[j] = fmaf(v[j], v[j], p1[j]); }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { acc[0][j] += (double)p0[j]; acc[1][j] += (double)p1[j]; }
   }
   block_reduce_store8<2>(acc, c, partial + (int64_t)blockIdx.x * 2 * c, sh);
 }
@@ -98,27 +112,46 @@ __global__ __launch_bounds__(RB) void act_backward_bf16_kernel(ActBwd8 a) {
   double acc[3][8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) { acc[0][j] = 0.0; acc[1][j] = 0.0; acc[2][j] = 0.0; }
-  for (int64_t i = b0 + threadIdx.x; i < b1; i += RB) {
-    float d[8], r[8], so[8], g[8];
-    unpack8(a.dout[i], d);
-    if (a.dout2) {
-      float e[8];
-      unpack8(a.dout2[i], e);
+  // two elements per trip (loads in flight together), fp32 partial sums added to the double accumulators per trip
+  for (int64_t i0 = b0 + threadIdx.x; i0 < b1; i0 += 2 * RB) {
+    uint4 qd[2], qr[2], q2[2], qa[2];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) d[j] += e[j];
+    for (int u = 0; u < 2; ++u) {
+      const int64_t i = i0 + u * RB < b1 ? i0 + u * RB : i0;
+      qd[u] = a.dout[i]; qr[u] = a.raw[i];
+      if (a.dout2) q2[u] = a.dout2[i];
+      if (a.aout) qa[u] = a.aout[i];
     }
-    unpack8(a.raw[i], r);
-    if (a.aout) unpack8(a.aout[i], so);
+    float p0[8], p1[8], p2[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const float t = fmaf(r[j], p.sc[j], p.sf[j]);
-      const bool pos = (a.aout ? so[j] : t) > 0.f;
-      g[j] = pos ? d[j] : d[j] * p.sl[j];
-      acc[0][j] += g[j];
-      acc[1][j] += (double)g[j] * r[j];
-      if (!pos) acc[2][j] += (double)d[j] * t;
+    for (int j = 0; j < 8; ++j) { p0[j] = 0.f; p1[j] = 0.f; p2[j] = 0.f; }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int64_t i = i0 + u * RB;
+      if (i >= b1) break;
+      float d[8], r[8], so[8], g[8];
+      unpack8(qd[u], d);
+      if (a.dout2) {
+        float e[8];
+        unpack8(q2[u], e);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) d[j] += e[j];
+      }
+      unpack8(qr[u], r);
+      if (a.aout) unpack8(qa[u], so);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float t = fmaf(r[j], p.sc[j], p.sf[j]);
+        const bool pos = (a.aout ? so[j] : t) > 0.f;
+        g[j] = pos ? d[j] : d[j] * p.sl[j];
+        p0[j] += g[j];
+        p1[j] = fmaf(g[j], r[j], p1[j]);
+        if (!pos) p2[j] = fmaf(d[j], t, p2[j]);
+      }
+      if (a.g) a.g[i] = pack8(g);
     }
-    if (a.g) a.g[i] = pack8(g);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { acc[0][j] += (double)p0[j]; acc[1][j] += (double)p1[j]; acc[2][j] += (double)p2[j]; }
   }
   block_reduce_store8<3>(acc, a.c, a.partial + (int64_t)blockIdx.x * 3 * a.c, sh);
 }
