@@ -60,8 +60,8 @@ SIGNATURES = {
     "bp_conv_bf16_supported": (C.c_int, [_CP, C.c_int, _VP, _VP]),
     "bp_conv_forward": (C.c_int, [_CP, _VP, _PWP, _P, _P, _P, _VP, C.c_int, _P]),
     "bp_conv_backward_data": (C.c_int, [_CP, _VP, _P, _P, _VP, C.c_int, _P]),
-    "bp_conv_stats_workspace": (C.c_size_t, [_CP, C.c_int, _VP, _VP]),
-    "bp_conv_forward_stats": (C.c_int, [_CP, _VP, _PWP, _P, _VP, _P, _P, C.c_size_t, _P]),
+    "bp_conv_stats_workspace": (C.c_size_t, [_CP, C.c_int, _VP, _VP, C.c_int]),
+    "bp_conv_forward_stats": (C.c_int, [_CP, _VP, _PWP, _P, _VP, _P, _P, C.c_size_t, C.c_int, _P]),
     "bp_conv_backward_data_stats": (C.c_int, [_CP, _VP, _P, _VP, _VP, _PWP, _P, _P, C.c_size_t, _P]),
     "bp_conv_backward_weight_workspace": (C.c_size_t, [_CP, _VP, _VP]),
     "bp_conv_backward_weight": (C.c_int, [_CP, _VP, _PWP, _VP, _P, _P, _P, C.c_size_t, C.c_int, _P]),

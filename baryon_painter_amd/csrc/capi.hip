@@ -26,7 +26,8 @@ bool bp_bf16_igemm_ok(const ConvGeom& g, const bp_view* in, const bp_view* out);
 int64_t bp_bf16_packed_elems(const ConvGeom& g);
 int bp_bf16_pack(const ConvGeom& g, const WeightMap& wm, const float* w_torch, void* packed, hipStream_t st);
 int bp_bf16_igemm_run(const ConvGeom& g, const bp_view* in, const PW& pw, const void* packed, const float* bias,
-                      const bp_view* out, hipStream_t st);
+                      const bp_view* out, hipStream_t st, const IgemmStatsReq* stats = nullptr);
+size_t bp_bf16_stats_workspace(const ConvGeom& g, const bp_view* in, const bp_view* out);
 size_t bp_wgrad_bf16_workspace(const bp_conv* cv, const bp_view* X, const bp_view* Y);
 int bp_wgrad_bf16_run(const bp_conv* cv, const bp_view* X, const PW& pwx, const bp_view* Y, const PW& pwy, float* dst,
                       void* workspace, size_t workspace_bytes, hipStream_t st);
@@ -131,16 +132,20 @@ int bp_conv_forward(const bp_conv* cv, const bp_view* x, const bp_pointwise* x_p
   return bp_direct_gather(g, bp_wmap(cv, BP_PACK_FWD), x, bp_pw(x_pw), w_torch, bias, y, bp_stream(stream));
 }
 
-size_t bp_conv_stats_workspace(const bp_conv* cv, int dir, const bp_view* x, const bp_view* y) {
-  if (!conv_ok(cv) || !shapes_ok(cv, x, y) || (dir != BP_PACK_FWD && dir != BP_PACK_BWD)) return 0;
+size_t bp_conv_stats_workspace(const bp_conv* cv, int dir, const bp_view* x, const bp_view* y, int impl) {
+  if (!conv_ok(cv) || !shapes_ok(cv, x, y, impl == BP_IMPL_BF16) || (dir != BP_PACK_FWD && dir != BP_PACK_BWD)) return 0;
+  if (impl == BP_IMPL_BF16) return dir == BP_PACK_FWD ? bp_bf16_stats_workspace(bp_geom_forward(cv), x, y) : 0;
   return dir == BP_PACK_FWD ? bp_igemm_stats_workspace(bp_geom_forward(cv), x, y, 1)
                             : bp_igemm_stats_workspace(bp_geom_backward_data(cv), y, x, 2);
 }
 
 int bp_conv_forward_stats(const bp_conv* cv, const bp_view* x, const bp_pointwise* x_pw, const float* packed_fwd,
-                          const bp_view* y, double* sums, void* workspace, size_t workspace_bytes, void* stream) {
-  if (!conv_ok(cv) || !shapes_ok(cv, x, y) || !packed_fwd || !sums) return BP_EINVAL;
+                          const bp_view* y, double* sums, void* workspace, size_t workspace_bytes, int impl,
+                          void* stream) {
+  if (!conv_ok(cv) || !shapes_ok(cv, x, y, impl == BP_IMPL_BF16) || !packed_fwd || !sums) return BP_EINVAL;
   const IgemmStatsReq sr{1, nullptr, PW{nullptr, nullptr, nullptr}, sums, workspace, workspace_bytes};
+  if (impl == BP_IMPL_BF16)
+    return bp_bf16_igemm_run(bp_geom_forward(cv), x, bp_pw(x_pw), packed_fwd, nullptr, y, bp_stream(stream), &sr);
   return bp_igemm_run(bp_geom_forward(cv), x, bp_pw(x_pw), packed_fwd, nullptr, y, bp_stream(stream), &sr);
 }
 

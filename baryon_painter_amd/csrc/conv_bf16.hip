@@ -94,8 +94,24 @@ int bp_bf16_pack(const ConvGeom& g, const WeightMap& wm, const float* w_torch, v
   return BP_OK;
 }
 
+// conv_igemm.hip: partial rows of epilogue statistics -> sums
+size_t bp_stats_rows_bytes(int64_t rows, int C);
+int bp_stats_rows_finish(double* ws, int64_t rows, int C, double* sums, hipStream_t st);
+
+static int64_t bf16_stat_rows(const ConvGeom& g, const BConfig& c, const bp_view* in, const bp_view* out) {
+  const int qh = bp_ceil_div(out->h, g.OS), qw = bp_ceil_div(out->w, g.OS);
+  return (int64_t)bp_ceil_div(qw, 16 * c.TPR) * bp_ceil_div(qh, c.BH) * in->n * g.nphase * g.nphase;
+}
+
+// workspace for bp_bf16_igemm_run with statistics (0: not available for this layer / these views)
+size_t bp_bf16_stats_workspace(const ConvGeom& g, const bp_view* in, const bp_view* out) {
+  const BConfig c = b_config(g);
+  if (!c.ok || !bp_bf16_igemm_ok(g, in, out)) return 0;
+  return bp_stats_rows_bytes(bf16_stat_rows(g, c, in, out), g.cout_g);
+}
+
 int bp_bf16_igemm_run(const ConvGeom& g, const bp_view* in, const PW& pw, const void* packed, const float* bias,
-                      const bp_view* out, hipStream_t st) {
+                      const bp_view* out, hipStream_t st, const IgemmStatsReq* sr) {
   const BConfig c = b_config(g);
   if (!c.ok || !bp_bf16_igemm_ok(g, in, out)) return BP_EUNSUPPORTED;
   BArgs a{};
@@ -115,12 +131,21 @@ int bp_bf16_igemm_run(const ConvGeom& g, const bp_view* in, const PW& pw, const 
   if (gz > 65535 || c.cout_padP / c.COB > 65535) return BP_EUNSUPPORTED;
   dim3 grid((unsigned)(a.tiles_x * a.tiles_y), (unsigned)gz, (unsigned)(c.cout_padP / c.COB));
   const bool ib = in->dtype == BP_BF16, ob = out->dtype == BP_BF16;
-  switch (c.CC) {
-    case 32: return bp_bf16_launch_cc32(c, a, ib, ob, grid, st);
-    case 16: return bp_bf16_launch_cc16(c, a, ib, ob, grid, st);
-    case 8: return bp_bf16_launch_cc8(c, a, ib, ob, grid, st);
-    case 4: return bp_bf16_launch_cc4(c, a, ib, ob, grid, st);
+  const int64_t rows = (int64_t)grid.x * grid.y;
+  if (sr) {
+    const size_t need = bp_stats_rows_bytes(rows, g.cout_g);
+    if (bias || sr->mode != 1 || !need) return BP_EUNSUPPORTED;
+    if (!sr->ws || sr->ws_bytes < need || !sr->sums) return BP_EWORKSPACE;
+    a.stat = reinterpret_cast<double*>(sr->ws); a.stat_c = g.cout_g;
   }
-  return BP_EUNSUPPORTED;
+  int rc = BP_EUNSUPPORTED;
+  switch (c.CC) {
+    case 32: rc = bp_bf16_launch_cc32(c, a, ib, ob, grid, st); break;
+    case 16: rc = bp_bf16_launch_cc16(c, a, ib, ob, grid, st); break;
+    case 8: rc = bp_bf16_launch_cc8(c, a, ib, ob, grid, st); break;
+    case 4: rc = bp_bf16_launch_cc4(c, a, ib, ob, grid, st); break;
+  }
+  if (rc != BP_OK || !sr) return rc;
+  return bp_stats_rows_finish(a.stat, rows, g.cout_g, sr->sums, st);
 }
 

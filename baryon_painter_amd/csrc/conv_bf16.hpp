@@ -52,6 +52,7 @@ struct BArgs {
   int nchunk, cout_padP;
   int IH, IWq;
   int npixp;                // pixels of the LDS halo image, padded to 16 (plane stride of the CC = 32 layout)
+  double* stat; int stat_c; // batch-norm sums from the epilogue: rows [tile x image x phase][2][stat_c], or nullptr
 };
 
 __device__ __forceinline__ void b_tile_of_block(int* tile, int* by) {
@@ -205,6 +206,68 @@ __device__ __forceinline__ void b_store_tile(const BArgs& a, const v4f (&acc)[MT
   }
 }
 
+// Training-mode batch-norm sums {sum y, sum y^2} of the tile just produced, from the accumulators (y = the value as
+// STORED: rounded to bf16 where the output is bf16, so the statistics are those of the tensor the next layer reads).
+// One N tile at a time: a lane's 4 channels over its MT pixels in double, the 16 lanes that share them (lm) by a
+// halving exchange, the waves that share them (wm) through LDS; one row per (tile, image, phase), fixed order.
+template <int NT, int MT, bool OUT_BF16, int WMN>
+__device__ __forceinline__ void b_stats_tile(const BArgs& a, const v4f (&acc)[MT][NT], double* red, int64_t row, int qy0,
+                                             int qx0, int qh, int qw, int co0, int wm, int wn, int lm, int kq, int COB) {
+  const int tid = threadIdx.x;
+  __syncthreads();                           // the LDS image is read out
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};     // <= 256 terms of 8-bit-mantissa values
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int t = wm * MT + mt;
+      const int qy = qy0 + t / a.TPR, qx = qx0 + (t % a.TPR) * 16 + lm;
+      if (qy >= qh || qx >= qw) continue;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v = acc[mt][nt][r];
+        if constexpr (OUT_BF16) v = bf2f(f2bf(v));
+        s1[r] += v; s2[r] = fmaf(v, v, s2[r]);
+      }
+    }
+    float h4[4], h2[2], h1;
+    {
+      const bool up = lm & 8;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float send = up ? s1[i] : s2[i], keep = up ? s2[i] : s1[i];
+        h4[i] = keep + __shfl_xor(send, 8, 16);
+      }
+    }
+    {
+      const bool up = lm & 4;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const float send = up ? h4[i] : h4[2 + i], keep = up ? h4[2 + i] : h4[i];
+        h2[i] = keep + __shfl_xor(send, 4, 16);
+      }
+    }
+    {
+      const bool up = lm & 2;
+      const float send = up ? h2[0] : h2[1], keep = up ? h2[1] : h2[0];
+      h1 = keep + __shfl_xor(send, 2, 16);
+    }
+    h1 += __shfl_xor(h1, 1, 16);
+    if ((lm & 1) == 0) {
+      const int idx = lm >> 1, r = idx & 3;   // value index = 4 * s + r
+      const int jl = NT == 1 ? wn * 16 + kq * 4 + r : (wn * NT / 2 + nt / 2) * 32 + kq * 8 + (nt & 1) * 4 + r;
+      red[(wm * COB + jl) * 2 + (idx >> 2)] = (double)h1;
+    }
+  }
+  __syncthreads();
+  if (tid < COB && co0 + tid < a.cout) {
+    double t1 = 0.0, t2 = 0.0;
+    for (int w = 0; w < WMN; ++w) { t1 += red[(w * COB + tid) * 2]; t2 += red[(w * COB + tid) * 2 + 1]; }
+    a.stat[(row * 2) * a.stat_c + co0 + tid] = t1;
+    a.stat[(row * 2 + 1) * a.stat_c + co0 + tid] = t2;
+  }
+}
+
 // NW waves per workgroup: 4, or 8 for the 128-channel trunk -- at bf16 MFMA speed a 128-pixel tile is only ~2 us of
 // matrix work per 295 KB of weights, and streaming the weights from L2 once per tile is what bounds the kernel; eight
 // waves (256 pixels) halve that traffic per pixel.
@@ -244,7 +307,14 @@ __global__ __launch_bounds__(64 * NW, 2) void igemm_bf16_kernel(BArgs a) {
   const int qy0 = tile_y * a.BH, qx0 = tile_x * BW;
   const int qh = (a.out_h - py + a.OS - 1) / a.OS;
   const int qw = (a.out_w - px + a.OS - 1) / a.OS;
-  if (qy0 >= qh || qx0 >= qw) return;  // uniform per block
+  const int64_t stat_row = (int64_t)blockIdx.y * gridDim.x + blockIdx.x;
+  if (qy0 >= qh || qx0 >= qw) {        // uniform per block
+    if (a.stat && tid < COB && co0 + tid < a.cout) {
+      a.stat[(stat_row * 2) * a.stat_c + co0 + tid] = 0.0;
+      a.stat[(stat_row * 2 + 1) * a.stat_c + co0 + tid] = 0.0;
+    }
+    return;
+  }
 
   int iy0, ix0;
   if (a.transposed) {
@@ -389,6 +459,9 @@ __global__ __launch_bounds__(64 * NW, 2) void igemm_bf16_kernel(BArgs a) {
   }
 
   b_store_tile<NT, MT, OUT_BF16>(a, acc, n, py, px, qy0, qx0, qh, qw, co0, wm, wn, lm, kq);
+  if (a.stat)
+    b_stats_tile<NT, MT, OUT_BF16, WM>(a, acc, reinterpret_cast<double*>(smem), stat_row, qy0, qx0, qh, qw, co0, wm, wn, lm,
+                                      kq, COB);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -422,7 +495,6 @@ __global__ __launch_bounds__(256, 2) void igemm_bf16_p_kernel(BPArgs pa) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
   const int lm = lane & 15, kq = lane >> 4;
-  (void)WM;
 
   const int ph = blockIdx.y;
   const int py = ph / a.nphase, px = ph % a.nphase;
@@ -568,6 +640,9 @@ __global__ __launch_bounds__(256, 2) void igemm_bf16_p_kernel(BPArgs pa) {
     int n, qy0, qx0;
     tile_coords(t, &n, &qy0, &qx0);
     b_store_tile<NT, MT, OUT_BF16>(a, acc, n, py, px, qy0, qx0, qh, qw, co0, wm, wn, lm, kq);
+    if (a.stat)
+      b_stats_tile<NT, MT, OUT_BF16, WM>(a, acc, reinterpret_cast<double*>(smem), (int64_t)ph * pa.ntiles_total + t, qy0, qx0,
+                                        qh, qw, co0, wm, wn, lm, kq, COB);
   }
 }
 

@@ -1530,17 +1530,47 @@ static bool igemm_launch_of(const ConvGeom& g, const IgemmConfig& c, const bp_vi
 
 // Epilogue statistics (IgemmArgs::stat): partial rows, their first fold, and whether this layer's kernel has them.
 struct StatsPlan { int64_t rows; int n; int nfold; int64_t R; size_t bytes; };
+static void stats_fold_plan(StatsPlan& p) {
+  p.nfold = p.rows <= 128 ? 0 : (int)(p.rows / 32 < 256 ? (p.rows + 31) / 32 : 256);
+  p.R = p.nfold ? (p.rows + p.nfold - 1) / p.nfold : 0;
+  if (p.nfold) p.nfold = (int)((p.rows + p.R - 1) / p.R);
+  p.bytes = (size_t)(p.rows + p.nfold) * p.n * sizeof(double);
+}
 static bool stats_plan(const ConvGeom& g, const IgemmConfig& c, const IgemmLaunch& l, StatsPlan& p) {
   const int C = g.cout_g;
   if (c.PP != 1 || C <= 0 || (C & (C - 1)) != 0 || C > 512) return false;
   if ((size_t)l.WM * c.COB * 2 * sizeof(double) > l.lds) return false;
   p.rows = (int64_t)l.grid.x * l.grid.y;
   p.n = 2 * C;
-  p.nfold = p.rows <= 128 ? 0 : (int)(p.rows / 32 < 256 ? (p.rows + 31) / 32 : 256);
-  p.R = p.nfold ? (p.rows + p.nfold - 1) / p.nfold : 0;
-  if (p.nfold) p.nfold = (int)((p.rows + p.R - 1) / p.R);
-  p.bytes = (size_t)(p.rows + p.nfold) * p.n * sizeof(double);
+  stats_fold_plan(p);
   return true;
+}
+static int stats_finish(const StatsPlan& sp, double* ws, double* sums, hipStream_t st) {
+  const double* rows = ws;
+  int64_t nrows = sp.rows;
+  if (sp.nfold) {
+    double* folded = ws + sp.rows * sp.n;
+    hipLaunchKernelGGL(stats_fold_kernel, dim3((unsigned)sp.nfold), dim3(256), 0, st, rows, sp.rows, sp.R, sp.n, folded);
+    BP_CHECK_LAUNCH();
+    rows = folded; nrows = sp.nfold;
+  }
+  return bp_sum_partials(rows, (int)nrows, sp.n, sums, st);
+}
+
+// Partial rows [rows][2*C] written by some kernel's epilogue -> sums[2*C] (used by the bf16 kernels too):
+// bytes of workspace for the rows and their first fold, and the fold itself.
+size_t bp_stats_rows_bytes(int64_t rows, int C) {
+  if (C <= 0 || (C & (C - 1)) != 0 || C > 512) return 0;
+  StatsPlan p{};
+  p.rows = rows; p.n = 2 * C;
+  stats_fold_plan(p);
+  return p.bytes;
+}
+int bp_stats_rows_finish(double* ws, int64_t rows, int C, double* sums, hipStream_t st) {
+  StatsPlan p{};
+  p.rows = rows; p.n = 2 * C;
+  stats_fold_plan(p);
+  return stats_finish(p, ws, sums, st);
 }
 
 size_t bp_igemm_stats_workspace(const ConvGeom& g, const bp_view* in, const bp_view* out, int mode) {
@@ -1597,13 +1627,5 @@ int bp_igemm_run(const ConvGeom& g, const bp_view* in, const PW& pw, const float
   else if (c.MT == 4) rc = launch_mt<4>(c, a, grid, st);
   else rc = launch_mt<1>(c, a, grid, st);
   if (rc != BP_OK || !sr) return rc;
-  const double* rows = a.stat;
-  int64_t nrows = sp.rows;
-  if (sp.nfold) {
-    double* folded = a.stat + sp.rows * sp.n;
-    hipLaunchKernelGGL(stats_fold_kernel, dim3((unsigned)sp.nfold), dim3(256), 0, st, rows, sp.rows, sp.R, sp.n, folded);
-    BP_CHECK_LAUNCH();
-    rows = folded; nrows = sp.nfold;
-  }
-  return bp_sum_partials(rows, (int)nrows, sp.n, sr->sums, st);
+  return stats_finish(sp, a.stat, sr->sums, st);
 }

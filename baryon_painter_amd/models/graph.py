@@ -330,9 +330,11 @@ class ConvUnit:
         self.fwd_stats = False
         self._fused_producer = None          # None: undecided; False: separate pass; a ConvUnit: fused
         self._sums_ready = False             # a consumer's data gradient has already filled self.sums
-        if EPILOGUE_FWD and bn is not None and not self.bf16 and holder.bias is None and self.out.dt == L.F32 \
-                and self._impl("fwd") in (L.IMPL_AUTO, L.IMPL_MFMA):
-            nb = lib.bp_conv_stats_workspace(C.byref(cv), L.PACK_FWD, C.byref(inp.view), C.byref(self.out.view))
+        self._stats_impl = L.IMPL_BF16 if self.bf16 else L.IMPL_MFMA
+        if EPILOGUE_FWD and bn is not None and holder.bias is None \
+                and (self.bf16 or (self.out.dt == L.F32 and self._impl("fwd") in (L.IMPL_AUTO, L.IMPL_MFMA))):
+            nb = lib.bp_conv_stats_workspace(C.byref(cv), L.PACK_FWD, C.byref(inp.view), C.byref(self.out.view),
+                                             self._stats_impl)
             if nb > 0:
                 self.fwd_stats = True
                 plan.need_ws(nb)
@@ -437,7 +439,8 @@ class ConvUnit:
         if fused:
             L.check(lib.bp_conv_forward_stats(C.byref(self.cv), C.byref(self.inp.view), self.inp.pw_struct(),
                                               L.ptr(self.packed_fwd), C.byref(self.out.view), L.ptr(self.sums),
-                                              L.ptr(self._ws()), plan.ws_bytes, st), f"{self.name} forward + bn stats")
+                                              L.ptr(self._ws()), plan.ws_bytes, self._stats_impl, st),
+                    f"{self.name} forward + bn stats")
         else:
             L.check(lib.bp_conv_forward(C.byref(self.cv), C.byref(self.inp.view), self.inp.pw_struct(),
                                         L.ptr(self.packed_fwd), L.ptr(hold.weight), L.ptr(hold.bias),
@@ -481,7 +484,7 @@ class ConvUnit:
         self.dx = self.inp.claim_grad() if self.need_dgrad else None
         if self.dx is not None and self._sub is None and EPILOGUE_BWD and not self.bf16 and self.inp.dt == L.F32:
             self.plan.need_ws(lib.bp_conv_stats_workspace(C.byref(self.cv), L.PACK_BWD, C.byref(self.inp.view),
-                                                          C.byref(self.out.view)))
+                                                          C.byref(self.out.view), L.IMPL_MFMA))
         if self.dx is not None and self._sub is not None:
             c0, c1 = self.dgrad_slice
             full = self.dx
@@ -565,7 +568,7 @@ class ConvUnit:
                     and self._sub is None and not self.bf16 and self.packed_bwd is not None \
                     and self._impl("dgrad") in (L.IMPL_AUTO, L.IMPL_MFMA):
                 nb = self.plan.lib.bp_conv_stats_workspace(C.byref(self.cv), L.PACK_BWD, C.byref(self.inp.view),
-                                                           C.byref(self.out.view))
+                                                           C.byref(self.out.view), L.IMPL_MFMA)
                 if 0 < nb <= self.plan.ws_bytes:
                     self._fused_producer = p
         return self._fused_producer

@@ -122,16 +122,19 @@ int bp_conv_backward_data(const bp_conv* cv, const bp_view* dy, const float* pac
 /* Convolution + per-channel sums in one launch (fp32 matrix-core kernels only): the sums are taken from the
  * accumulators in the kernel's epilogue, so the streaming pass of bp_channel_sums / bp_act_backward over the
  * produced tensor is not needed (batch-norm statistics of utils.py:146-147 and the two reductions of its backward).
- *   bp_conv_stats_workspace(cv, dir, x, y)  bytes of workspace for layer `cv` on module input x / output y
+ *   impl: BP_IMPL_MFMA (fp32 views) or BP_IMPL_BF16 (bf16 packed image, views of either type; forward only: the sums
+ *       are those of the tensor as stored, i.e. of the bf16-rounded values where y is bf16).
+ *   bp_conv_stats_workspace(cv, dir, x, y, impl)  bytes of workspace for layer `cv` on module input x / output y
  *       (BP_PACK_FWD: bp_conv_forward_stats, BP_PACK_BWD: bp_conv_backward_data_stats); 0 = this layer's kernel
  *       has no statistics epilogue (bias, pixel-packed or vector-ALU kernels, channel count not a power of two):
  *       use the separate passes.
  *   bp_conv_forward_stats        y_raw = conv(act(x)); sums[2*cout] = {sum y, sum y^2} as bp_channel_sums(y).
  *   bp_conv_backward_data_stats  dx = d(loss)/d(act(x)) as bp_conv_backward_data; sums[2*cin] = {sum g, sum g*x_raw},
  *       g = dx * act'(x_pw(x_raw)): the first two sums of bp_act_backward(dx, NULL, x_raw, x_pw, ...). */
-size_t bp_conv_stats_workspace(const bp_conv* cv, int dir, const bp_view* x, const bp_view* y);
+size_t bp_conv_stats_workspace(const bp_conv* cv, int dir, const bp_view* x, const bp_view* y, int impl);
 int bp_conv_forward_stats(const bp_conv* cv, const bp_view* x, const bp_pointwise* x_pw, const float* packed_fwd,
-                          const bp_view* y, double* sums, void* workspace, size_t workspace_bytes, void* stream);
+                          const bp_view* y, double* sums, void* workspace, size_t workspace_bytes, int impl,
+                          void* stream);
 int bp_conv_backward_data_stats(const bp_conv* cv, const bp_view* dy, const float* packed_bwd, const bp_view* dx,
                                 const bp_view* x_raw, const bp_pointwise* x_pw, double* sums, void* workspace,
                                 size_t workspace_bytes, void* stream);

@@ -98,6 +98,25 @@ def test_bf16_convolution_forward_dgrad_wgrad(case, io):
     raw = yb.to(torch.float32)
     assert torch.isnan(raw[..., :8]).all(), "stores outside the view"
 
+    # ---- the same forward with the batch-norm sums taken in the epilogue: the sums of the tensor AS STORED
+    nb = lib.bp_conv_stats_workspace(C.byref(cv), L.PACK_FWD, C.byref(xv), C.byref(yv), L.IMPL_BF16)
+    if co & (co - 1) == 0:
+        assert nb > 0
+        yb2, yv2 = empty_view(n, ho, wo, co, out_bf, cstride=co + 8, coff=8)
+        sums = torch.full((2 * co,), float("nan"), dtype=torch.float64, device="cuda")
+        wss = torch.full((nb // 8 + 8,), float("nan"), dtype=torch.float64, device="cuda")
+        L.check(lib.bp_conv_forward_stats(C.byref(cv), C.byref(xv), C.byref(pw), L.ptr(pf), C.byref(yv2), L.ptr(sums),
+                                          L.ptr(wss), nb, L.IMPL_BF16, st), "forward + statistics")
+        got2 = from_view(yb2, co, coff=8)
+        assert np.array_equal(got2, got), "the statistics epilogue must not change the output"
+        g64 = got.astype(np.float64)
+        sm = sums.cpu().numpy()
+        # (a lane's <= 256 terms are summed in fp32 before the double reductions: 1e-6 of the sum of magnitudes)
+        assert (np.abs(sm[:co] - g64.sum(axis=(0, 2, 3))) <= 1e-6 * np.abs(g64).sum(axis=(0, 2, 3)) + 1e-12).all()
+        assert np.allclose(sm[co:], (g64 ** 2).sum(axis=(0, 2, 3)), rtol=1e-6, atol=1e-12)
+    else:
+        assert nb == 0
+
     # ---- data gradient (no pending activation on dy)
     dy = rng.standard_normal(y_ref.shape).astype(np.float32)
     dyin = bf16_round(dy) if in_bf else dy

@@ -72,11 +72,11 @@ def test_forward_statistics_from_the_epilogue(case):
     wd = G.dev(wt)
     pf = torch.zeros(lib.bp_conv_packed_floats(C.byref(cv), L.PACK_FWD), device="cuda")
     L.check(lib.bp_conv_pack(C.byref(cv), L.PACK_FWD, L.ptr(wd), L.ptr(pf), st))
-    nb = lib.bp_conv_stats_workspace(C.byref(cv), L.PACK_FWD, C.byref(xv), C.byref(yv))
+    nb = lib.bp_conv_stats_workspace(C.byref(cv), L.PACK_FWD, C.byref(xv), C.byref(yv), L.IMPL_MFMA)
     sums = torch.full((2 * co,), float("nan"), dtype=torch.float64, device="cuda")
     ws = torch.full((nb // 8 + 8,), float("nan"), dtype=torch.float64, device="cuda")
     rc = lib.bp_conv_forward_stats(C.byref(cv), C.byref(xv), C.byref(pw), L.ptr(pf), C.byref(yv), L.ptr(sums),
-                                   L.ptr(ws), nb, st)
+                                   L.ptr(ws), nb, L.IMPL_MFMA, st)
     if nb == 0:
         assert rc == -2
         return
@@ -96,7 +96,7 @@ def test_forward_statistics_from_the_epilogue(case):
     assert _close(got[co:], ref[co:], ref[co:], 1e-6)
     # too small a workspace is refused, not overrun
     assert lib.bp_conv_forward_stats(C.byref(cv), C.byref(xv), C.byref(pw), L.ptr(pf), C.byref(yv), L.ptr(sums),
-                                     L.ptr(ws), nb - 8, st) == -4
+                                     L.ptr(ws), nb - 8, L.IMPL_MFMA, st) == -4
 
 
 @pytest.mark.parametrize("case", CASES, ids=_ids)
@@ -127,7 +127,7 @@ def test_activation_backward_sums_from_the_data_gradient_epilogue(case):
     wd = G.dev(wt)
     pb = torch.zeros(lib.bp_conv_packed_floats(C.byref(cv), L.PACK_BWD), device="cuda")
     L.check(lib.bp_conv_pack(C.byref(cv), L.PACK_BWD, L.ptr(wd), L.ptr(pb), st))
-    nb = lib.bp_conv_stats_workspace(C.byref(cv), L.PACK_BWD, C.byref(dxv), C.byref(dyv))
+    nb = lib.bp_conv_stats_workspace(C.byref(cv), L.PACK_BWD, C.byref(dxv), C.byref(dyv), L.IMPL_MFMA)
     sums = torch.full((3 * ci,), float("nan"), dtype=torch.float64, device="cuda")
     ws = torch.full((nb // 8 + 8,), float("nan"), dtype=torch.float64, device="cuda")
     rc = lib.bp_conv_backward_data_stats(C.byref(cv), C.byref(dyv), L.ptr(pb), C.byref(dxv), C.byref(rv),
@@ -159,4 +159,4 @@ def test_statistics_are_refused_where_the_kernel_has_none():
                           (L.Conv(0, 16, 24, 3, 1, 1, 0), (2, 9, 33))):
         xb, xv = G.empty_nhwc(n, h, w, cv.cin)
         yb, yv = G.empty_nhwc(n, h, w, cv.cout)
-        assert lib.bp_conv_stats_workspace(C.byref(cv), L.PACK_FWD, C.byref(xv), C.byref(yv)) == 0
+        assert lib.bp_conv_stats_workspace(C.byref(cv), L.PACK_FWD, C.byref(xv), C.byref(yv), L.IMPL_MFMA) == 0
