@@ -898,16 +898,22 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void igemm_wres_kernel(Ig
   // staging slots of this thread: (row, column, channel quad) of the halo element, the same for every tile
   const int in_elems4 = a.IH * a.IW * VW;
   const int c4 = tid % VW;                      // NTH % VW == 0
-  int s_rc[SLOTS], s_l[SLOTS];                  // (row << 16 | column) of the halo element, its LDS offset (-1: unused)
+  // (row << 16 | column) of the halo element, its LDS offset, its offset from the tile's first element in the tensor.
+  // Unused slots (past the end of the tile) write to a spare 16 bytes behind the weights: no branch in the commit.
+  int s_rc[SLOTS], s_l[SLOTS], s_off[SLOTS];
+  unsigned valid = 0;
+  const int dummy = a.in_pad4 * 4 + a.tapsy * a.tapsx * COB * CC;
 #pragma unroll
   for (int i = 0; i < SLOTS; ++i) {
     const int e = tid + i * NTH;
-    s_l[i] = -1; s_rc[i] = 0;
+    s_l[i] = dummy; s_rc[i] = 0; s_off[i] = 0;
     if (e < in_elems4) {
       const int pix = e / VW;
       const int c = pix % a.IW, r = pix / a.IW;
       s_rc[i] = (r << 16) | c;
       s_l[i] = ((r * a.ISx + c % a.ISx) * a.IWq + c / a.ISx) * CC + c4 * 4;
+      s_off[i] = (r * a.in_w + c) * a.in_cs;
+      valid |= 1u << i;
     }
   }
   const PW4 p4 = pw4_load(a.pw, c4 * 4, a.cin);
@@ -920,28 +926,37 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void igemm_wres_kernel(Ig
     const int r = t - *n * tiles_per_img;
     *qy0 = (r / a.tiles_x) * a.BH; *qx0 = (r % a.tiles_x) * BW;
   };
+  // Tiles whose halo lies inside the image (all but the border ring) take one pointer add per slot; the others clamp
+  // their coordinates (every slot loads either way: a load under a per-lane condition is waited for on the spot).
   auto fetch = [&](int t) {
     int n, qy0, qx0;
     tile_origin(t, &n, &qy0, &qx0);
     const int gy0 = a.ISy * qy0 + i0, gx0 = a.ISx * qx0 + i0;
     const float* in_n = a.in + (int64_t)n * a.in_h * a.in_w * a.in_cs + a.in_co + c4 * 4;
-    // every slot loads (coordinates clamped into the image; what lies outside is zeroed at commit): loads under a
-    // per-lane condition are serialised by the compiler with a full vmcnt(0) wait between them
-    inside = 0;
+    if (gy0 >= 0 && gx0 >= 0 && gy0 + a.IH <= a.in_h && gx0 + a.IW <= a.in_w) {       // uniform
+      const float* base = in_n + ((int64_t)gy0 * a.in_w + gx0) * a.in_cs;
 #pragma unroll
-    for (int i = 0; i < SLOTS; ++i) {
-      const int iy = gy0 + (s_rc[i] >> 16), ix = gx0 + (s_rc[i] & 0xffff);
-      if (s_l[i] >= 0 && iy >= 0 && iy < a.in_h && ix >= 0 && ix < a.in_w) inside |= 1u << i;
-      const int cy = min(max(iy, 0), a.in_h - 1), cx = min(max(ix, 0), a.in_w - 1);
-      stage[i] = *reinterpret_cast<const float4*>(in_n + (cy * a.in_w + cx) * a.in_cs);
+      for (int i = 0; i < SLOTS; ++i) stage[i] = *reinterpret_cast<const float4*>(base + s_off[i]);
+      inside = valid;
+    } else {
+      unsigned in = 0;
+#pragma unroll
+      for (int i = 0; i < SLOTS; ++i) {
+        const int iy = gy0 + (s_rc[i] >> 16), ix = gx0 + (s_rc[i] & 0xffff);
+        if (iy >= 0 && iy < a.in_h && ix >= 0 && ix < a.in_w) in |= 1u << i;
+        const int cy = min(max(iy, 0), a.in_h - 1), cx = min(max(ix, 0), a.in_w - 1);
+        stage[i] = *reinterpret_cast<const float4*>(in_n + (cy * a.in_w + cx) * a.in_cs);
+      }
+      inside = in & valid;
     }
   };
   auto commit = [&]() {
 #pragma unroll
-    for (int i = 0; i < SLOTS; ++i)
-      if (s_l[i] >= 0)
-        *reinterpret_cast<float4*>(lds_in + s_l[i]) =
-            ((inside >> i) & 1u) ? pw4_apply4(p4, stage[i]) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = 0; i < SLOTS; ++i) {
+      const float4 v = pw4_apply4(p4, stage[i]);
+      const bool in = (inside >> i) & 1u;
+      *reinterpret_cast<float4*>(lds_in + s_l[i]) = make_float4(in ? v.x : 0.f, in ? v.y : 0.f, in ? v.z : 0.f, in ? v.w : 0.f);
+    }
   };
 
   constexpr int SN = STATS ? NT : 1;            // (the sums cost 16 * NT registers: only the batch-norm layers' variant has them)
@@ -1216,7 +1231,7 @@ IgemmConfig igemm_config(const ConvGeom& g) {
       const int E = tw.IH * tw.IW * (CC / 4);
       const int slots = bp_ceil_div(E, 64 * NW);
       const int in_pad4 = bp_round_up(tw.IH * c.ISx * tw.IWq * (CC / 4), 64);
-      const size_t lds = (size_t)in_pad4 * 16 + (size_t)g.taps * c.tapsx * c.COB * CC * sizeof(float);
+      const size_t lds = (size_t)in_pad4 * 16 + (size_t)g.taps * c.tapsx * c.COB * CC * sizeof(float) + 16;
       const bool plain_ok = plain_lds(tile_geom(16, g.IS, c.ISx, g.taps, c.tapsx), CC) <= 64 * 1024 ||
                             plain_lds(tile_geom(4, g.IS, c.ISx, g.taps, c.tapsx), CC) <= 64 * 1024;
       if (lds <= (size_t)(NW == 4 ? 80 : 150) * 1024 && slots <= 12 && plain_ok) {

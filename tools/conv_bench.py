@@ -18,6 +18,7 @@ for spec in sys.argv[1:]:
     dxb = torch.empty_like(xb); dxv = L.View(dxb.data_ptr(), n, h, w, ci, ci, 0)
     wd = torch.randn(((ci, co) if tr else (co, ci)) + (k, k), device="cuda") * 0.05
     keep, pw = G.pointwise(np.ones(ci, np.float32), np.zeros(ci, np.float32), np.full(ci, 0.2, np.float32))
+    pwp = None if os.environ.get('BENCH_NOPW') else C.byref(pw)
     pf = torch.zeros(lib.bp_conv_packed_floats(C.byref(cv), L.PACK_FWD), device="cuda")
     pb = torch.zeros(lib.bp_conv_packed_floats(C.byref(cv), L.PACK_BWD), device="cuda")
     L.check(lib.bp_conv_pack(C.byref(cv), L.PACK_FWD, L.ptr(wd), L.ptr(pf), st))
@@ -29,7 +30,7 @@ for spec in sys.argv[1:]:
     flop = 2.0 * dense * k * k * ci * co
     def run(kind):
         if kind == "fwd":
-            L.check(lib.bp_conv_forward(C.byref(cv), C.byref(xv), C.byref(pw), L.ptr(pf), L.ptr(wd), None, C.byref(yv), IMPL, st))
+            L.check(lib.bp_conv_forward(C.byref(cv), C.byref(xv), pwp, L.ptr(pf), L.ptr(wd), None, C.byref(yv), IMPL, st))
         elif kind == "dgrad":
             L.check(lib.bp_conv_backward_data(C.byref(cv), C.byref(yv), L.ptr(pb), L.ptr(wd), C.byref(dxv), IMPL, st))
         else:
