@@ -675,7 +675,8 @@ static inline BConfig b_config_for(const ConvGeom& g, int NT, int WN, int NW = 4
   c.R = 32 / c.CC;
   c.nchunk = c.CC == 32 ? cin / 32 : 1;
   c.NT = NT; c.WN = WN;
-  c.MT = 4;
+  static const bool no_mt8 = getenv("BP_BF16_NOMT8") != nullptr;
+  c.MT = (NW == 8 && !no_mt8) ? 8 : 4;          // eight waves: 128 pixels x 64 channels per wave (12 fragment reads per 32 MFMAs)
   c.COB = 16 * c.NT * c.WN;
   c.cout_padP = bp_round_up(g.cout_g, c.COB);
   // K-steps of one tap row: per parity plane xm (x % IS), runs of R plane-adjacent taps
@@ -700,7 +701,7 @@ static inline BConfig b_config_for(const ConvGeom& g, int NT, int WN, int NW = 4
   const size_t in_b = (((size_t)c.npixp * c.CC + 511) & ~(size_t)511) * 2;
   c.lds_bytes = in_b + (size_t)2 * c.nrun * c.COB * 32 * 2          // two weight slabs
                 + (size_t)3 * c.nchunk * c.CC * sizeof(float);       // + the pending activation's parameters
-  c.ok = c.lds_bytes <= 80 * 1024 && c.slots <= 12;       // two workgroups per CU
+  c.ok = c.lds_bytes <= (size_t)(NW == 8 ? 100 : 80) * 1024 && c.slots <= 12;       // two workgroups per CU (one of eight waves)
   c.lds_p = in_b + (size_t)g.taps * c.nrun * c.COB * 32 * 2;
   static const bool no_p = getenv("BP_BF16_NOPERSIST") != nullptr;
   // (measured on the fiducial layers: the persistent form wins for the strided gathers -- 16->32 k4s2 forward
@@ -734,13 +735,13 @@ inline BConfig b_config(const ConvGeom& g) {
 
 // weights: torch layout (fp32) -> [phase][ty][run][chunk][channel block][k octet][row][8] bf16 (the LDS image of a
 // workgroup's slab, contiguous: one linear copy / LDS-DMA), k = 8*octet + i = j*CC + cc <-> tap xm + IS*(xq + j)
-template <int CC, int NT, int WN, int SLOTS, bool IB, bool OB, int NW = 4>
+template <int CC, int NT, int WN, int SLOTS, bool IB, bool OB, int NW = 4, int MT = 4>
 int b_launch(const BArgs& a, dim3 grid, size_t lds, hipStream_t st) {
   static const hipError_t optin = hipFuncSetAttribute(
-      reinterpret_cast<const void*>(&igemm_bf16_kernel<CC, NT, WN, 4, SLOTS, IB, OB, NW>),
-      hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+      reinterpret_cast<const void*>(&igemm_bf16_kernel<CC, NT, WN, MT, SLOTS, IB, OB, NW>),
+      hipFuncAttributeMaxDynamicSharedMemorySize, (NW == 8 ? 100 : 80) * 1024);
   if (optin != hipSuccess) return BP_ELAUNCH;
-  hipLaunchKernelGGL((igemm_bf16_kernel<CC, NT, WN, 4, SLOTS, IB, OB, NW>), grid, dim3(64 * NW), lds, st, a);
+  hipLaunchKernelGGL((igemm_bf16_kernel<CC, NT, WN, MT, SLOTS, IB, OB, NW>), grid, dim3(64 * NW), lds, st, a);
   BP_CHECK_LAUNCH();
   return BP_OK;
 }
@@ -760,12 +761,12 @@ int b_launch_p_io(const BPArgs& a, bool ib, bool ob, dim3 grid, size_t lds, hipS
   return b_launch_p<CC, NT, WN, SLOTS, false, false>(a, grid, lds, st);
 }
 
-template <int CC, int NT, int WN, int SLOTS, int NW = 4>
+template <int CC, int NT, int WN, int SLOTS, int NW = 4, int MT = 4>
 int b_launch_io(const BArgs& a, bool ib, bool ob, dim3 grid, size_t lds, hipStream_t st) {
-  if (ib && ob) return b_launch<CC, NT, WN, SLOTS, true, true, NW>(a, grid, lds, st);
-  if (ib) return b_launch<CC, NT, WN, SLOTS, true, false, NW>(a, grid, lds, st);
-  if (ob) return b_launch<CC, NT, WN, SLOTS, false, true, NW>(a, grid, lds, st);
-  return b_launch<CC, NT, WN, SLOTS, false, false, NW>(a, grid, lds, st);
+  if (ib && ob) return b_launch<CC, NT, WN, SLOTS, true, true, NW, MT>(a, grid, lds, st);
+  if (ib) return b_launch<CC, NT, WN, SLOTS, true, false, NW, MT>(a, grid, lds, st);
+  if (ob) return b_launch<CC, NT, WN, SLOTS, false, true, NW, MT>(a, grid, lds, st);
+  return b_launch<CC, NT, WN, SLOTS, false, false, NW, MT>(a, grid, lds, st);
 }
 
 template <int CC, int NT, int WN>
@@ -794,6 +795,7 @@ int b_launch_slots(const BConfig& c, const BArgs& a, bool ib, bool ob, dim3 grid
 template <int CC>
 int b_launch_cc(const BConfig& c, const BArgs& a, bool ib, bool ob, dim3 grid, hipStream_t st) {
   if constexpr (CC == 32) {
+    if (c.NW == 8 && c.MT == 8) return b_launch_io<CC, 4, 2, 6, 8, 8>(a, ib, ob, grid, c.lds_bytes, st);
     if (c.NW == 8) return b_launch_io<CC, 4, 2, 6, 8>(a, ib, ob, grid, c.lds_bytes, st);
   }
   if (c.NT == 4 && c.WN == 2) return b_launch_slots<CC, 4, 2>(c, a, ib, ob, grid, st);
