@@ -205,6 +205,11 @@ def main():
     ap.add_argument("--no-paint", action="store_true", help="skip the paint() throughput leg")
     ap.add_argument("--paint-tiles", type=int, default=1024, help="tiles streamed through paint() per rank")
     ap.add_argument("--torch-adam", action="store_true", help="torch.optim.Adam instead of the fused FlatAdam")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the step (forward + backward + Adam, same launches) from one hipGraph "
+                         "(CVAE.make_graphed_train_step; single GPU).  Measured SLOWER than the eager schedule at "
+                         "batch 64 x 512^2 (fp32 48.5 vs 46.2 ms, bf16 24.8 vs 23.6: the graph re-packs every layer's "
+                         "weights and the host is never the bottleneck); it pays at the reference's small minibatches")
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
                     help="f32: the reference's arithmetic (configs[1], the headline); bf16: bf16 activations / gradients "
                          "in the generator trunk, fp32 accumulation, master weights and statistics (configs[3])")
@@ -258,12 +263,19 @@ def main():
     y = torch.from_numpy(np.tile(y, (reps, 1, 1, 1))[:n]).to(dev)
     aux = torch.from_numpy(np.tile(aux, reps)[:n]).to(dev)
 
-    def step():
+    def eager_step():
         elbo = model(x, y, aux)
         opt.zero_grad()
         (-elbo).backward()
         opt.step()
         return elbo
+
+    step = eager_step
+    use_graph = args.graph and world == 1 and not args.torch_adam
+    if use_graph:
+        eager_step()                                  # (sizes workspaces, claims gradient buffers)
+        gstep = model.make_graphed_train_step(opt, n)
+        step = lambda: gstep(x, y, aux)
 
     for _ in range(args.warmup):
         step()
@@ -314,7 +326,7 @@ def main():
     model.overlap_weight_gradients(False)
     plan.prof = []                               # HIP events around every convolution launch
     for _ in range(PROF_STEPS):
-        step()
+        eager_step()                             # (eager: the events are recorded by the launch hooks)
     torch.cuda.synchronize()
     prof_events, plan.prof = plan.prof, None
     model.overlap_weight_gradients(True)
@@ -454,6 +466,7 @@ def main():
                        else ("global (all-reduced statistics)" if world > 1 else "single device"),
                        "optimizer": "torch.optim.Adam(lr=1e-3)" if args.torch_adam else "FlatAdam(lr=1e-3) = torch.optim.Adam arithmetic, fused",
                        "schedule": "weight gradients on a second HIP stream beside the rest of the backward pass"
+                                   + ("; the whole step replayed from one hipGraph" if use_graph else "")
                                    if os.environ.get("BP_SIDE_WGRAD", "1") != "0" else "single stream",
                        "final_elbo": final_elbo},
             "roofline": roofline,
