@@ -478,7 +478,11 @@ struct BPArgs {
   int per_block;        // tiles per workgroup (contiguous)
 };
 
-template <int CC, int NT, int WN, int MT, int SLOTS, bool IN_BF16, bool OUT_BF16>
+// FUSE (transposed forms with stride^2 = 4 output phases): one workgroup computes all four phases of a tile from ONE
+// staged input tile (the union of the phases' halos) with all four phases' weights resident -- the halo is fetched,
+// activated and written to LDS once instead of four times, and the four phases' pixels of an output row are written
+// by the same workgroup back to back.
+template <int CC, int NT, int WN, int MT, int SLOTS, bool IN_BF16, bool OUT_BF16, bool FUSE = false>
 __global__ __launch_bounds__(256, 2) void igemm_bf16_p_kernel(BPArgs pa) {
   const BArgs& a = pa.b;
   constexpr int U = CC < 8 ? CC : 8;
@@ -496,21 +500,20 @@ __global__ __launch_bounds__(256, 2) void igemm_bf16_p_kernel(BPArgs pa) {
   const int wm = wave / WN, wn = wave % WN;
   const int lm = lane & 15, kq = lane >> 4;
 
-  const int ph = blockIdx.y;
-  const int py = ph / a.nphase, px = ph % a.nphase;
+  constexpr int NPH = FUSE ? 4 : 1;
+  const int ph0 = FUSE ? 0 : blockIdx.y;
   const int co0 = blockIdx.z * COB;
   const int t_begin = blockIdx.x * pa.per_block;
   int t_end = t_begin + pa.per_block;
   if (t_end > pa.ntiles_total) t_end = pa.ntiles_total;
   if (t_begin >= t_end) return;          // uniform per block
   const int tiles_per_img = a.tiles_x * a.tiles_y;
-  const int qh = (a.out_h - py + a.OS - 1) / a.OS;
-  const int qw = (a.out_w - px + a.OS - 1) / a.OS;
 
+  // origin of the staged tile: the first gathered row / column of phase ph0 (fused: phase 0, the smallest origin)
   int iy0, ix0;
   if (a.transposed) {
-    iy0 = bp_t_i0(py, a.pad, a.stride, a.tapsy);
-    ix0 = bp_t_i0(px, a.pad, a.stride, a.tapsy);
+    iy0 = bp_t_i0(ph0 / a.nphase, a.pad, a.stride, a.tapsy);
+    ix0 = bp_t_i0(ph0 % a.nphase, a.pad, a.stride, a.tapsy);
   } else {
     iy0 = -a.pad; ix0 = -a.pad;
   }
@@ -601,10 +604,10 @@ __global__ __launch_bounds__(256, 2) void igemm_bf16_p_kernel(BPArgs pa) {
   // weights of every tap row of this phase and channel block: [ty][run][k octet][COB][8]
   {
     constexpr int slab8 = COB * 32 / 8;
-    const int total = a.tapsy * a.nrun * slab8;
+    const int total = NPH * a.tapsy * a.nrun * slab8;
     for (int e = tid; e < total; e += 256) {
-      const int sl_ = e / slab8, o = e % slab8;          // sl_ = ty * nrun + s
-      const u16* src = a.wp + (((int64_t)ph * a.tapsy * a.nrun + sl_) * a.cout_padP + co0) * 32;
+      const int sl_ = e / slab8, o = e % slab8;          // sl_ = (phase * tapsy + ty) * nrun + s
+      const u16* src = a.wp + (((int64_t)ph0 * a.tapsy * a.nrun + sl_) * a.cout_padP + co0) * 32;
       *reinterpret_cast<uint4*>(lds_w + (size_t)sl_ * COB * 32 + o * 8) = *reinterpret_cast<const uint4*>(src + o * 8);
     }
   }
@@ -616,33 +619,43 @@ __global__ __launch_bounds__(256, 2) void igemm_bf16_p_kernel(BPArgs pa) {
     __syncthreads();
     if (t + 1 < t_end) load_tile(t + 1);      // in flight while this tile is multiplied
 
-    v4f acc[MT][NT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = v4f{0.f, 0.f, 0.f, 0.f};
-    for (int ty = 0; ty < a.tapsy; ++ty) {
-      for (int s = 0; s < a.nrun; ++s) {
-        const int tapoff = (ty * a.ISx * a.IWq + a.run_off[s]) * (CC == 32 ? 8 : CC);
-        const u16* lw = lds_w + (ty * a.nrun + s) * COB * 32;
-        bf8 xf[MT], wf[NT];
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) xf[mt] = lds_frag<CC>(lds_in + abase[mt] + tapoff);
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) wf[nt] = lds_frag<32>(lw + bbase[nt]);
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-          for (int nt = 0; nt < NT; ++nt)
-            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], xf[mt], acc[mt][nt], 0, 0, 0);
-      }
-    }
     int n, qy0, qx0;
     tile_coords(t, &n, &qy0, &qx0);
-    b_store_tile<NT, MT, OUT_BF16>(a, acc, n, py, px, qy0, qx0, qh, qw, co0, wm, wn, lm, kq);
-    if (a.stat)
-      b_stats_tile<NT, MT, OUT_BF16, WM>(a, acc, reinterpret_cast<double*>(smem), (int64_t)ph * pa.ntiles_total + t, qy0, qx0,
-                                        qh, qw, co0, wm, wn, lm, kq, COB);
+#pragma unroll 1
+    for (int p = 0; p < NPH; ++p) {
+      const int ph = FUSE ? p : ph0;
+      const int py = ph / a.nphase, px = ph % a.nphase;
+      const int qh = (a.out_h - py + a.OS - 1) / a.OS;
+      const int qw = (a.out_w - px + a.OS - 1) / a.OS;
+      // this phase's first gathered row / column relative to the tile origin
+      const int dy = FUSE ? bp_t_i0(py, a.pad, a.stride, a.tapsy) - iy0 : 0;
+      const int dx = FUSE ? bp_t_i0(px, a.pad, a.stride, a.tapsy) - ix0 : 0;
+      v4f acc[MT][NT];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = v4f{0.f, 0.f, 0.f, 0.f};
+      for (int ty = 0; ty < a.tapsy; ++ty) {
+        for (int s = 0; s < a.nrun; ++s) {
+          const int tapoff = ((ty + dy) * a.ISx * a.IWq + a.run_off[s] + dx) * (CC == 32 ? 8 : CC);
+          const u16* lw = lds_w + ((p * a.tapsy + ty) * a.nrun + s) * COB * 32;
+          bf8 xf[MT], wf[NT];
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) xf[mt] = lds_frag<CC>(lds_in + abase[mt] + tapoff);
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) wf[nt] = lds_frag<32>(lw + bbase[nt]);
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], xf[mt], acc[mt][nt], 0, 0, 0);
+        }
+      }
+      b_store_tile<NT, MT, OUT_BF16>(a, acc, n, py, px, qy0, qx0, qh, qw, co0, wm, wn, lm, kq);
+      if (a.stat)
+        b_stats_tile<NT, MT, OUT_BF16, WM>(a, acc, reinterpret_cast<double*>(lds_w + NPH * a.tapsy * a.nrun * COB * 32),
+                                          (int64_t)ph * pa.ntiles_total + t, qy0, qx0, qh, qw, co0, wm, wn, lm, kq, COB);
+    }
   }
 }
 
@@ -660,6 +673,7 @@ struct BConfig {
   size_t lds_bytes;
   bool ok;
   bool persistent;          // igemm_bf16_p_kernel: one chunk, all tap rows' weights resident
+  bool fuse;                // ... all four phases of a stride-2 transposed form in one workgroup
   size_t lds_p;
 };
 
@@ -702,14 +716,28 @@ static inline BConfig b_config_for(const ConvGeom& g, int NT, int WN, int NW = 4
   c.lds_bytes = in_b + (size_t)2 * c.nrun * c.COB * 32 * 2          // two weight slabs
                 + (size_t)3 * c.nchunk * c.CC * sizeof(float);       // + the pending activation's parameters
   c.ok = c.lds_bytes <= (size_t)(NW == 8 ? 100 : 80) * 1024 && c.slots <= 12;       // two workgroups per CU (one of eight waves)
-  c.lds_p = in_b + (size_t)g.taps * c.nrun * c.COB * 32 * 2;
+  constexpr size_t RED = 4 * 128 * 2 * sizeof(double);              // cross-wave fold of the epilogue statistics
+  c.lds_p = in_b + (size_t)g.taps * c.nrun * c.COB * 32 * 2 + RED;
   static const bool no_p = getenv("BP_BF16_NOPERSIST") != nullptr;
+  static const bool no_fuse = getenv("BP_BF16_NOFUSE") != nullptr;
   // (measured on the fiducial layers: the persistent form wins for the strided gathers -- 16->32 k4s2 forward
   //  0.61 -> 0.28 ms, 32->16 transposed data gradient 0.54 -> 0.27 ms -- whose halo tiles are four times the
   //  output tile, and for the four-phase transposed forms -- 32->16 forward 0.71 -> 0.61 ms; the unit-stride k7 head
   //  is the same either way)
   static const bool p_all = getenv("BP_BF16_PALL") != nullptr;
   c.persistent = c.ok && !no_p && NW == 4 && c.nchunk == 1 && c.lds_p <= 64 * 1024 && (g.IS == 2 || g.nphase > 1 || p_all);
+  if (c.persistent && !no_fuse && g.gather_transposed && g.nphase == 2) {
+    // all four phases from one staged tile: the union of their halos is `spread` rows / columns larger
+    const int spread = bp_t_i0(g.nphase - 1, g.pad, g.stride, g.taps) - bp_t_i0(0, g.pad, g.stride, g.taps);
+    BConfig f = c;
+    f.IH += spread; f.IWq += spread;
+    const int Ef = f.IH * g.IS * f.IWq * (c.CC / U);
+    f.slots = bp_ceil_div(Ef, 256);
+    f.npixp = bp_round_up(f.IH * g.IS * f.IWq, 16);
+    const size_t in_f = (((size_t)f.npixp * c.CC + 511) & ~(size_t)511) * 2;
+    f.lds_p = in_f + (size_t)4 * g.taps * c.nrun * c.COB * 32 * 2 + RED;
+    if (f.lds_p <= 64 * 1024 && f.slots <= 12) { f.fuse = true; c = f; }
+  }
   return c;
 }
 
@@ -746,19 +774,19 @@ int b_launch(const BArgs& a, dim3 grid, size_t lds, hipStream_t st) {
   return BP_OK;
 }
 
-template <int CC, int NT, int WN, int SLOTS, bool IB, bool OB>
+template <int CC, int NT, int WN, int SLOTS, bool IB, bool OB, bool FUSE>
 int b_launch_p(const BPArgs& a, dim3 grid, size_t lds, hipStream_t st) {
-  hipLaunchKernelGGL((igemm_bf16_p_kernel<CC, NT, WN, 4, SLOTS, IB, OB>), grid, dim3(256), lds, st, a);
+  hipLaunchKernelGGL((igemm_bf16_p_kernel<CC, NT, WN, 4, SLOTS, IB, OB, FUSE>), grid, dim3(256), lds, st, a);
   BP_CHECK_LAUNCH();
   return BP_OK;
 }
 
-template <int CC, int NT, int WN, int SLOTS>
+template <int CC, int NT, int WN, int SLOTS, bool FUSE = false>
 int b_launch_p_io(const BPArgs& a, bool ib, bool ob, dim3 grid, size_t lds, hipStream_t st) {
-  if (ib && ob) return b_launch_p<CC, NT, WN, SLOTS, true, true>(a, grid, lds, st);
-  if (ib) return b_launch_p<CC, NT, WN, SLOTS, true, false>(a, grid, lds, st);
-  if (ob) return b_launch_p<CC, NT, WN, SLOTS, false, true>(a, grid, lds, st);
-  return b_launch_p<CC, NT, WN, SLOTS, false, false>(a, grid, lds, st);
+  if (ib && ob) return b_launch_p<CC, NT, WN, SLOTS, true, true, FUSE>(a, grid, lds, st);
+  if (ib) return b_launch_p<CC, NT, WN, SLOTS, true, false, FUSE>(a, grid, lds, st);
+  if (ob) return b_launch_p<CC, NT, WN, SLOTS, false, true, FUSE>(a, grid, lds, st);
+  return b_launch_p<CC, NT, WN, SLOTS, false, false, FUSE>(a, grid, lds, st);
 }
 
 template <int CC, int NT, int WN, int SLOTS, int NW = 4, int MT = 4>
@@ -783,6 +811,15 @@ int b_launch_slots(const BConfig& c, const BArgs& a, bool ib, bool ob, dim3 grid
       int per = bp_ceil_div(pa.ntiles_total, nb);
       if (per < 4) per = 4;
       pa.per_block = per;
+      if (c.fuse) {          // every workgroup does all four phases of its tiles
+        nb = 512 / (int)grid.z;
+        per = bp_ceil_div(pa.ntiles_total, nb);
+        if (per < 2) per = 2;
+        pa.per_block = per;
+        dim3 fg((unsigned)bp_ceil_div(pa.ntiles_total, per), 1, grid.z);
+        if (c.slots <= 6) return b_launch_p_io<CC, NT, WN, 6, true>(pa, ib, ob, fg, c.lds_p, st);
+        return b_launch_p_io<CC, NT, WN, 12, true>(pa, ib, ob, fg, c.lds_p, st);
+      }
       dim3 pg((unsigned)bp_ceil_div(pa.ntiles_total, per), (unsigned)(a.nphase * a.nphase), grid.z);
       if (c.slots <= 6) return b_launch_p_io<CC, NT, WN, 6>(pa, ib, ob, pg, c.lds_p, st);
       return b_launch_p_io<CC, NT, WN, 12>(pa, ib, ob, pg, c.lds_p, st);
