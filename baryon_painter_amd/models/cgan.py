@@ -79,10 +79,19 @@ class _GanPlan:
         return self.impl
 
     def prof_begin(self):
-        return None
+        """HIP events around every launch when ``self.prof`` is a list (bench / tools), as in cvae._Plan."""
+        if self.prof is None:
+            return None
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        return e
 
-    def prof_end(self, *a):
-        pass
+    def prof_end(self, e0, unit, kind, nstreams=1):
+        if e0 is None:
+            return
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        self.prof.append((e0, e1, unit, kind, nstreams))
 
     # ---- forward pieces
     def generate(self, y, zc, training):
