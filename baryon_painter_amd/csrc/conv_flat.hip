@@ -1,0 +1,173 @@
+// Unit-stride k7 convolutions gathering 8 channels into 16 (arch p_y_z_out: the data gradient of the head's first
+// layer Conv2d 16 -> 8, k7; equally the forward of an 8 -> 16 k7 layer): 49 taps x 8 channels is a K of 392 with only
+// 16 x 16 outputs per MFMA tile, so the general igemm -- one weight slab per tap staged through LDS -- spends its time
+// between barriers.  Here, as in conv_stem.hip, the K dimension of the fp32 MFMA walks the FLATTENED (tap column,
+// channel) index of one tap row, kf = 8*v + c: the window of pixel x in an NHWC row is 56 consecutive floats, i.e. 14
+// K-groups of 4 per tap row, 98 MFMAs per 16 pixels with no padding, and all 98 weight fragments live in registers for
+// the whole kernel (one VGPR each): no weight staging, no barrier inside a tile.
+//   D[co][px] = sum_{u, g} W[u][g] (16 co x 4 kf)  x  Xflat[u][g] (4 kf x 16 px)
+// The input tile is staged as two channel-quad planes [quad][row][pixel][4], so the 64 lanes of an operand read
+// (pixel lm, channel kq of quad g % 2, tap column g / 2) touch 256 contiguous bytes.  Workgroups walk the tile
+// sequence with a grid stride, the next tile in flight in registers (unconditional loads from clamped coordinates).
+#include "common.hpp"
+#include <cstdlib>
+
+namespace {
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+constexpr int K = 7, CG = 8, CO = 16;
+constexpr int NQ = CG / 4;                            // channel quads per pixel
+constexpr int NG = K * NQ;                            // K-groups per tap row (14)
+constexpr int TH = 8, TW = 64;                        // output tile of a workgroup: 4 waves x 2 rows x 64 columns
+constexpr int IH = TH + K - 1, IWP = TW + K - 1;      // staged rows / pixels per row (14 x 70)
+constexpr int PLANE = IH * IWP * 4;                   // floats of one quad plane
+constexpr int NU = IH * IWP * NQ;                     // float4 units of the tile (1960)
+constexpr int SL = (NU + 255) / 256;                  // per thread (8)
+
+struct FlatArgs {
+  const float* in; int h, w, in_cs, in_co;
+  float* out; int out_cs, out_co;
+  const float* bias;
+  const float* wp;            // [u][g][kq][co]
+  PW pw;
+  int n, tiles_x, tiles_y, i0, in_vec;
+};
+
+template <bool OUT_VEC>
+__global__ __launch_bounds__(256, 2) void flat_k7_kernel(FlatArgs a) {
+  __shared__ __attribute__((aligned(16))) float tile[NQ * PLANE];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lm = lane & 15, kq = lane >> 4;
+
+  float wreg[K][NG];
+#pragma unroll
+  for (int u = 0; u < K; ++u)
+#pragma unroll
+    for (int g = 0; g < NG; ++g) wreg[u][g] = a.wp[((u * NG + g) * 4 + kq) * CO + lm];
+  v4f b4 = {0.f, 0.f, 0.f, 0.f};
+  if (a.bias) b4 = v4f{a.bias[4 * kq], a.bias[4 * kq + 1], a.bias[4 * kq + 2], a.bias[4 * kq + 3]};
+
+  // staging: unit e = (pixel, quad); a thread always holds the same quad
+  const int q4 = tid % NQ;
+  const PW4 p4 = pw4_load(a.pw, q4 * 4, CG);
+  const int per_img = a.tiles_x * a.tiles_y;
+  const int ntiles = per_img * a.n;
+  float4 stage[SL];
+  unsigned inside = 0;
+  auto fetch = [&](int t) {
+    const int n = t / per_img, r = t % per_img;
+    const int y0 = (r / a.tiles_x) * TH + a.i0, x0 = (r % a.tiles_x) * TW + a.i0;
+    const float* in_n = a.in + (int64_t)n * a.h * a.w * a.in_cs + a.in_co + q4 * 4;
+    unsigned in = 0;
+#pragma unroll
+    for (int i = 0; i < SL; ++i) {
+      const int e = tid + i * 256;
+      const int pix = e / NQ, col = pix % IWP, row = pix / IWP;
+      const int iy = y0 + row, ix = x0 + col;
+      if (e < NU && iy >= 0 && iy < a.h && ix >= 0 && ix < a.w) in |= 1u << i;
+      const int cy = min(max(iy, 0), a.h - 1), cx = min(max(ix, 0), a.w - 1);
+      const float* p = in_n + ((int64_t)cy * a.w + cx) * a.in_cs;
+      stage[i] = a.in_vec ? *reinterpret_cast<const float4*>(p) : make_float4(p[0], p[1], p[2], p[3]);
+    }
+    inside = in;
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int i = 0; i < SL; ++i) {
+      const int e = tid + i * 256;
+      if (e < NU) {
+        const float4 v = pw4_apply4(p4, stage[i]);
+        const bool in = (inside >> i) & 1u;
+        *reinterpret_cast<float4*>(tile + q4 * PLANE + (e / NQ) * 4) =
+            make_float4(in ? v.x : 0.f, in ? v.y : 0.f, in ? v.z : 0.f, in ? v.w : 0.f);
+      }
+    }
+  };
+
+  int t = blockIdx.x;
+  if (t < ntiles) { fetch(t); commit(); }
+  __syncthreads();
+  for (; t < ntiles; t += gridDim.x) {
+    const int tn = t + gridDim.x;
+    if (tn < ntiles) fetch(tn);
+    const int n = t / per_img, r = t % per_img;
+    const int y0 = (r / a.tiles_x) * TH, x0 = (r % a.tiles_x) * TW;
+    float* out_n = a.out + (int64_t)n * a.h * a.w * a.out_cs + a.out_co;
+#pragma unroll 1
+    for (int rr = 0; rr < 2; ++rr) {
+      const int row = wave * 2 + rr;
+#pragma unroll 1
+      for (int ct = 0; ct < TW / 16; ++ct) {
+        v4f acc = b4;
+        const float* base = tile + (row * IWP + ct * 16 + lm) * 4 + kq;
+#pragma unroll
+        for (int u = 0; u < K; ++u)
+#pragma unroll
+          for (int g = 0; g < NG; ++g)        // tap column g / NQ, channel quad g % NQ
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[u][g], base[(g % NQ) * PLANE + (u * IWP + g / NQ) * 4], acc, 0, 0,
+                                                       0);
+        const int Y = y0 + row, X = x0 + ct * 16 + lm;
+        if (Y < a.h && X < a.w) {
+          float* o = out_n + ((int64_t)Y * a.w + X) * a.out_cs + 4 * kq;
+          if constexpr (OUT_VEC) *reinterpret_cast<float4*>(o) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+          else { o[0] = acc[0]; o[1] = acc[1]; o[2] = acc[2]; o[3] = acc[3]; }
+        }
+      }
+    }
+    __syncthreads();                 // every wave is done reading the tile
+    if (tn < ntiles) commit();
+    __syncthreads();
+  }
+}
+
+struct FlatPackArgs { const float* w; float* dst; int64_t sa, sb; int flip; };
+__global__ void flat_pack_kernel(FlatPackArgs a) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;      // ((u*NG + g)*4 + kq)*16 + co
+  if (i >= K * NG * 4 * CO) return;
+  const int co = i % CO, kf = (i / CO) % (NG * 4), u = i / (CO * NG * 4);
+  const int g = kf / 4, kq = kf % 4;
+  const int v = g / NQ, c = (g % NQ) * 4 + kq;               // tap column, gathered channel
+  const int ky = a.flip ? K - 1 - u : u, kx = a.flip ? K - 1 - v : v;
+  a.dst[i] = a.w[c * a.sa + co * a.sb + ky * K + kx];
+}
+
+int flat_grid(int ntiles) {
+  static const int cap = getenv("BP_FLAT_GRID") ? atoi(getenv("BP_FLAT_GRID")) : 512;
+  return ntiles < cap ? ntiles : cap;
+}
+
+}  // namespace
+
+bool bp_flat_ok(const ConvGeom& g) {
+  static const bool off = getenv("BP_NOFLAT") != nullptr;
+  return !off && g.k == K && g.stride == 1 && g.pad == (K - 1) / 2 && g.cin_g == CG && g.cout_g == CO && g.nphase == 1;
+}
+
+int64_t bp_flat_packed_floats() { return (int64_t)K * NG * 4 * CO; }
+
+int bp_flat_pack(const ConvGeom& g, const WeightMap& wm, const float* w_torch, float* packed, hipStream_t st) {
+  FlatPackArgs a{w_torch, packed, wm.sa, wm.sb, g.gather_transposed};
+  hipLaunchKernelGGL(flat_pack_kernel, dim3((K * NG * 4 * CO + 255) / 256), dim3(256), 0, st, a);
+  BP_CHECK_LAUNCH();
+  return BP_OK;
+}
+
+int bp_flat_run(const ConvGeom& g, const bp_view* in, const PW& pw, const float* packed, const float* bias,
+                const bp_view* out, hipStream_t st) {
+  FlatArgs a{};
+  a.in_vec = bp_view_vec4(in) ? 1 : 0;
+  a.in = in->ptr; a.h = in->h; a.w = in->w; a.in_cs = in->cstride; a.in_co = in->coff;
+  a.out = out->ptr; a.out_cs = out->cstride; a.out_co = out->coff;
+  a.wp = packed; a.bias = bias; a.pw = pw; a.n = in->n;
+  a.tiles_x = bp_ceil_div(out->w, TW); a.tiles_y = bp_ceil_div(out->h, TH);
+  a.i0 = g.gather_transposed ? bp_t_i0(0, g.pad, 1, K) : -g.pad;
+  const int64_t ntiles = (int64_t)a.tiles_x * a.tiles_y * a.n;
+  if (ntiles > 0x7fffffff) return BP_EUNSUPPORTED;
+  const int grid = flat_grid((int)ntiles);
+  if (bp_view_vec4(out)) hipLaunchKernelGGL(flat_k7_kernel<true>, dim3(grid), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(flat_k7_kernel<false>, dim3(grid), dim3(256), 0, st, a);
+  BP_CHECK_LAUNCH();
+  return BP_OK;
+}
