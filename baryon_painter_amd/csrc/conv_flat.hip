@@ -171,3 +171,210 @@ int bp_flat_run(const ConvGeom& g, const bp_view* in, const PW& pw, const float*
   BP_CHECK_LAUNCH();
   return BP_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Stride-2 k4 transposed forms gathering 32 channels into 16 (ConvTranspose2d 32 -> 16 k4s2 forward, arch
+// p_y_z_in.22, and the data gradient of Conv2d 16 -> 32 k4s2, p_y_z_in.3): four output phases of 2 x 2 taps each.
+// The same flattened-K scheme per phase: the window of phase-grid pixel x in a tap row is two adjacent input pixels =
+// 64 consecutive floats = 16 K-groups, 32 MFMAs per phase and 16 pixels with no padding; the 4 x 2 x 16 = 128 weight
+// fragments of all four phases stay in registers, the input tile (staged once for all four phases) is eight channel-
+// quad planes, and a wave writes the four phases of its pixels back to back.  Batch-norm sums (forward, mode 1) are
+// kept per lane in double over all the tiles of the workgroup, as in conv_stem.hip.
+namespace {
+
+constexpr int TK = 4, TS = 2, TPAD = 1, TCG = 32, TCO = 16;
+constexpr int TNQ = TCG / 4;                          // 8 quad planes
+constexpr int TT = TK / TS;                           // taps per phase and dimension (2)
+constexpr int TNG = TT * TNQ;                         // K-groups per tap row (16)
+constexpr int TTH = 8, TTW = 16;                      // phase-grid tile of a workgroup: 4 waves x 2 rows x 16 columns
+                                                      // (128 weight registers: the staging set has to stay small)
+constexpr int TIH = TTH + TT, TIW = TTW + TT;         // staged input rows / pixels per row (10 x 34)
+constexpr int TPLANE = TIH * TIW * 4;
+constexpr int TNU = TIH * TIW * TNQ;                  // float4 units (2720)
+constexpr int TSL = (TNU + 255) / 256;                // per thread (11)
+
+struct FlatTArgs {
+  const float* in; int in_h, in_w, in_cs, in_co;
+  float* out; int out_h, out_w, out_cs, out_co;
+  const float* wp;            // [phase][t][g][kq][co]
+  const float* bias;
+  PW pw;
+  int n, tiles_x, tiles_y, in_vec;
+  double* stat;               // partial sums [workgroup][2][16] or nullptr
+};
+
+template <bool STATS>
+__global__ __launch_bounds__(256, 2) void flat_t4_kernel(FlatTArgs a) {
+  __shared__ __attribute__((aligned(16))) float tile[TNQ * TPLANE];
+  __shared__ double red[4][2][TCO];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lm = lane & 15, kq = lane >> 4;
+
+  float wreg[4][TT][TNG];
+#pragma unroll
+  for (int ph = 0; ph < 4; ++ph)
+#pragma unroll
+    for (int t = 0; t < TT; ++t)
+#pragma unroll
+      for (int g = 0; g < TNG; ++g) wreg[ph][t][g] = a.wp[(((ph * TT + t) * TNG + g) * 4 + kq) * TCO + lm];
+
+  v4f b4 = {0.f, 0.f, 0.f, 0.f};
+  if (a.bias) b4 = v4f{a.bias[4 * kq], a.bias[4 * kq + 1], a.bias[4 * kq + 2], a.bias[4 * kq + 3]};
+  const int q8 = tid % TNQ;
+  const PW4 p4 = pw4_load(a.pw, q8 * 4, TCG);
+  const int per_img = a.tiles_x * a.tiles_y;
+  const int ntiles = per_img * a.n;
+  float4 stage[TSL];
+  unsigned inside = 0;
+  // the tile covers phase-grid rows qy0 .. qy0+TTH-1; gathered rows qy0 - 1 .. qy0 + TTH (phase 0 starts at -1, phase 1 at 0)
+  auto fetch = [&](int t) {
+    const int n = t / per_img, r = t % per_img;
+    const int y0 = (r / a.tiles_x) * TTH - 1, x0 = (r % a.tiles_x) * TTW - 1;
+    const float* in_n = a.in + (int64_t)n * a.in_h * a.in_w * a.in_cs + a.in_co + q8 * 4;
+    unsigned in = 0;
+#pragma unroll
+    for (int i = 0; i < TSL; ++i) {
+      const int e = tid + i * 256;
+      const int pix = e / TNQ, col = pix % TIW, row = pix / TIW;
+      const int iy = y0 + row, ix = x0 + col;
+      if (e < TNU && iy >= 0 && iy < a.in_h && ix >= 0 && ix < a.in_w) in |= 1u << i;
+      const int cy = min(max(iy, 0), a.in_h - 1), cx = min(max(ix, 0), a.in_w - 1);
+      const float* p = in_n + ((int64_t)cy * a.in_w + cx) * a.in_cs;
+      stage[i] = a.in_vec ? *reinterpret_cast<const float4*>(p) : make_float4(p[0], p[1], p[2], p[3]);
+    }
+    inside = in;
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int i = 0; i < TSL; ++i) {
+      const int e = tid + i * 256;
+      if (e < TNU) {
+        const float4 v = pw4_apply4(p4, stage[i]);
+        const bool in = (inside >> i) & 1u;
+        *reinterpret_cast<float4*>(tile + q8 * TPLANE + (e / TNQ) * 4) =
+            make_float4(in ? v.x : 0.f, in ? v.y : 0.f, in ? v.z : 0.f, in ? v.w : 0.f);
+      }
+    }
+  };
+
+  double s1[STATS ? 4 : 1] = {}, s2[STATS ? 4 : 1] = {};
+  int t = blockIdx.x;
+  if (t < ntiles) { fetch(t); commit(); }
+  __syncthreads();
+  for (; t < ntiles; t += gridDim.x) {
+    const int tn = t + gridDim.x;
+    if (tn < ntiles) fetch(tn);
+    const int n = t / per_img, r = t % per_img;
+    const int qy0 = (r / a.tiles_x) * TTH, qx0 = (r % a.tiles_x) * TTW;
+    float* out_n = a.out + (int64_t)n * a.out_h * a.out_w * a.out_cs + a.out_co;
+#pragma unroll 1
+    for (int rr = 0; rr < 2; ++rr) {
+      const int row = wave * 2 + rr;
+#pragma unroll 1
+      for (int ct = 0; ct < TTW / 16; ++ct) {
+        const float* base = tile + (row * TIW + ct * 16 + lm) * 4 + kq;
+#pragma unroll
+        for (int ph = 0; ph < 4; ++ph) {
+          const int py = ph >> 1, px = ph & 1;              // staged row of tap t: row + py + t, column: + px + s
+          v4f acc = b4;
+#pragma unroll
+          for (int tt = 0; tt < TT; ++tt)
+#pragma unroll
+            for (int g = 0; g < TNG; ++g)                   // tap column s = g / TNQ, channel quad g % TNQ
+              acc = __builtin_amdgcn_mfma_f32_16x16x4f32(
+                  wreg[ph][tt][g], base[(g % TNQ) * TPLANE + ((py + tt) * TIW + px + g / TNQ) * 4], acc, 0, 0, 0);
+          const int Y = 2 * (qy0 + row) + py, X = 2 * (qx0 + ct * 16 + lm) + px;
+          if (Y < a.out_h && X < a.out_w) {
+            float* o = out_n + ((int64_t)Y * a.out_w + X) * a.out_cs + 4 * kq;
+            *reinterpret_cast<float4*>(o) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+            if constexpr (STATS) {
+#pragma unroll
+              for (int q = 0; q < 4; ++q) { s1[q] += (double)acc[q]; s2[q] = fma((double)acc[q], (double)acc[q], s2[q]); }
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+    if (tn < ntiles) commit();
+    __syncthreads();
+  }
+  if constexpr (STATS) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int off = 8; off > 0; off >>= 1) {
+        s1[q] += __shfl_xor(s1[q], off, 16);
+        s2[q] += __shfl_xor(s2[q], off, 16);
+      }
+    if (lm == 0) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { red[wave][0][4 * kq + q] = s1[q]; red[wave][1][4 * kq + q] = s2[q]; }
+    }
+    __syncthreads();
+    if (tid < 2 * TCO) {
+      const int s = tid / TCO, c = tid % TCO;
+      a.stat[(int64_t)blockIdx.x * 2 * TCO + tid] = red[0][s][c] + red[1][s][c] + red[2][s][c] + red[3][s][c];
+    }
+  }
+}
+
+struct FlatTPackArgs { const float* w; float* dst; int64_t sa, sb; };
+__global__ void flat_t4_pack_kernel(FlatTPackArgs a) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;      // (((ph*TT + t)*TNG + g)*4 + kq)*16 + co
+  if (i >= 4 * TT * TNG * 4 * TCO) return;
+  const int co = i % TCO, kf = (i / TCO) % (TNG * 4), t = (i / (TCO * TNG * 4)) % TT, ph = i / (TCO * TNG * 4 * TT);
+  const int g = kf / 4, kq = kf % 4;
+  const int s = g / TNQ, c = (g % TNQ) * 4 + kq;            // tap column, gathered channel
+  const int ky = bp_t_ky(ph >> 1, TPAD, TS, TT, t), kx = bp_t_ky(ph & 1, TPAD, TS, TT, s);
+  a.dst[i] = a.w[c * a.sa + co * a.sb + ky * TK + kx];
+}
+
+}  // namespace
+
+bool bp_flat_t4_ok(const ConvGeom& g) {
+  static const bool off = getenv("BP_NOFLAT") != nullptr;
+  return !off && g.gather_transposed && g.k == TK && g.stride == TS && g.pad == TPAD && g.cin_g == TCG && g.cout_g == TCO &&
+         g.nphase == 2;
+}
+
+int64_t bp_flat_t4_packed_floats() { return (int64_t)4 * TT * TNG * 4 * TCO; }
+
+int bp_flat_t4_pack(const WeightMap& wm, const float* w_torch, float* packed, hipStream_t st) {
+  FlatTPackArgs a{w_torch, packed, wm.sa, wm.sb};
+  hipLaunchKernelGGL(flat_t4_pack_kernel, dim3((4 * TT * TNG * 4 * TCO + 255) / 256), dim3(256), 0, st, a);
+  BP_CHECK_LAUNCH();
+  return BP_OK;
+}
+
+static int flat_t4_tiles(const bp_view* out) {
+  return bp_ceil_div(bp_ceil_div(out->w, 2), TTW) * bp_ceil_div(bp_ceil_div(out->h, 2), TTH) * out->n;
+}
+
+size_t bp_flat_t4_stats_workspace(const bp_view* out) {
+  return (size_t)flat_grid(flat_t4_tiles(out)) * 2 * TCO * sizeof(double);
+}
+
+int bp_flat_t4_run(const bp_view* in, const PW& pw, const float* packed, const float* bias, const bp_view* out,
+                   hipStream_t st, const IgemmStatsReq* sr) {
+  if ((sr && (bias || sr->mode != 1)) || !bp_view_vec4(out)) return BP_EUNSUPPORTED;
+  FlatTArgs a{};
+  a.bias = bias;
+  a.in = in->ptr; a.in_h = in->h; a.in_w = in->w; a.in_cs = in->cstride; a.in_co = in->coff;
+  a.out = out->ptr; a.out_h = out->h; a.out_w = out->w; a.out_cs = out->cstride; a.out_co = out->coff;
+  a.wp = packed; a.pw = pw; a.n = in->n; a.in_vec = bp_view_vec4(in) ? 1 : 0;
+  a.tiles_x = bp_ceil_div(bp_ceil_div(out->w, 2), TTW); a.tiles_y = bp_ceil_div(bp_ceil_div(out->h, 2), TTH);
+  const int64_t ntiles = (int64_t)a.tiles_x * a.tiles_y * a.n;
+  if (ntiles > 0x7fffffff) return BP_EUNSUPPORTED;
+  const int grid = flat_grid((int)ntiles);
+  if (sr) {
+    if (!sr->ws || sr->ws_bytes < bp_flat_t4_stats_workspace(out) || !sr->sums) return BP_EWORKSPACE;
+    a.stat = reinterpret_cast<double*>(sr->ws);
+  }
+  if (sr) hipLaunchKernelGGL(flat_t4_kernel<true>, dim3(grid), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(flat_t4_kernel<false>, dim3(grid), dim3(256), 0, st, a);
+  BP_CHECK_LAUNCH();
+  if (sr) return bp_sum_partials(a.stat, grid, 2 * TCO, sr->sums, st);
+  return BP_OK;
+}

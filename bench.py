@@ -73,6 +73,8 @@ def kernel_name(kind, unit, lib):
         return "stem_forward_kernel"
     if kid == 710000:
         return "flat_k7_kernel"
+    if kid == 720000:
+        return "flat_t4_kernel"
     if 800000 <= kid < 900000:
         return "tiny_%s_kernel<%d,%d,%d,%d>" % ("transposed" if kid % 10 else "gather", kid // 10000 % 10, kid // 1000 % 10,
                                                 kid // 100 % 10, kid // 10 % 10)

@@ -36,6 +36,8 @@ CASES = [
     (0, 16, 8, 7, 1, 3, (2, 19, 45)),          # ... 49 taps, two pixels per MFMA column block
     (0, 8, 16, 7, 1, 3, (2, 19, 45)),
     (0, 16, 32, 4, 2, 1, (70, 64, 64)),        # ... more tiles than workgroups
+    (1, 32, 16, 4, 2, 1, (3, 9, 11)),          # conv_flat.hip transposed 32 -> 16: sums kept per lane over the tiles
+    (1, 32, 16, 4, 2, 1, (24, 40, 80)),
     (0, 3, 16, 5, 1, 2, (40, 130, 200)),      # ... with more tiles than workgroups (grid-stride walk)
 ]
 

@@ -148,6 +148,8 @@ DMA_CASES = [
     (0, 16, 8, 7, 1, 3, (9, 64, 250)),        # ... more tiles than workgroups (grid-stride walk)
     (0, 8, 16, 7, 1, 3, (3, 21, 45)),         # conv_flat.hip forward (weights in registers); its data gradient: wres
     (0, 16, 8, 7, 1, 3, (40, 64, 130)),       # conv_flat.hip data gradient with more tiles than workgroups
+    (1, 32, 16, 4, 2, 1, (3, 9, 13)),         # conv_flat.hip four-phase transposed form (forward); gather: wres
+    (1, 32, 16, 4, 2, 1, (24, 40, 80)),       # ... more tiles than workgroups
 ]
 
 
