@@ -11,6 +11,7 @@ LIB_PATH = os.path.join(_HERE, "libbp_hip.so")
 
 BP_OK = 0
 IMPL_AUTO, IMPL_DIRECT, IMPL_MFMA, IMPL_BF16 = 0, 1, 2, 3
+IMPL_SHARED = 0x100
 PACK_FWD, PACK_BWD = 0, 1
 F32, BF16 = 0, 1
 

@@ -19,7 +19,7 @@ int bp_direct_wgrad(const bp_conv* cv, const bp_view* X, const PW& pwx, const bp
                     hipStream_t st);
 size_t bp_wgrad_mfma_workspace(const bp_conv* cv, const bp_view* X, const bp_view* Y);
 int bp_wgrad_mfma(const bp_conv* cv, const bp_view* X, const PW& pwx, const bp_view* Y, const PW& pwy, float* dst,
-                  void* workspace, size_t workspace_bytes, hipStream_t st);
+                  void* workspace, size_t workspace_bytes, hipStream_t st, bool shared);
 extern "C" int bp_sums_to_float(const double* sums, int32_t c, float* dst, void* stream);
 // conv_bf16.hip
 bool bp_bf16_igemm_ok(const ConvGeom& g, const bp_view* in, const bp_view* out);
@@ -191,6 +191,8 @@ size_t bp_conv_backward_weight_workspace(const bp_conv* cv, const bp_view* x, co
 int bp_conv_backward_weight(const bp_conv* cv, const bp_view* x, const bp_pointwise* x_pw, const bp_view* dy,
                             float* dw_torch, float* dbias, void* workspace, size_t workspace_bytes, int impl,
                             void* stream) {
+  const bool shared = (impl & BP_IMPL_SHARED) != 0;
+  impl &= ~BP_IMPL_SHARED;
   if (!conv_ok(cv) || !shapes_ok(cv, x, dy, impl == BP_IMPL_BF16) || !dw_torch) return BP_EINVAL;
   const bp_view* X = cv->transposed ? dy : x;
   const bp_view* Y = cv->transposed ? x : dy;
@@ -213,7 +215,7 @@ int bp_conv_backward_weight(const bp_conv* cv, const bp_view* x, const bp_pointw
   int rc;
   if (impl == BP_IMPL_MFMA) {
     if (!ws_main) return BP_EUNSUPPORTED;
-    rc = bp_wgrad_mfma(cv, X, pwx, Y, pwy, dw_torch, workspace, ws_main, st);
+    rc = bp_wgrad_mfma(cv, X, pwx, Y, pwy, dw_torch, workspace, ws_main, st, shared);
   } else {
     rc = bp_direct_wgrad(cv, X, pwx, Y, pwy, dw_torch, st);
   }

@@ -301,7 +301,12 @@ int bp_stem_wgrad(const bp_view* X, const PW& pwx, const bp_view* Y, float* dst,
 bool bp_wgrad_flat_ok(const bp_conv* cv, const bp_view* X, const bp_view* Y, const PW& pwy);
 size_t bp_wgrad_flat_workspace(const bp_view* X);
 int bp_wgrad_flat(const bp_view* X, const PW& pwx, const bp_view* Y, float* dst, void* workspace, size_t workspace_bytes,
-                  hipStream_t st);
+                  hipStream_t st, bool shared);
+// ... and of the thin stride-2 k4 layers (16 channels at full resolution, 32 at half)
+bool bp_wgrad_flat_s2_ok(const bp_conv* cv, const bp_view* X, const bp_view* Y, const PW& pwx, const PW& pwy);
+size_t bp_wgrad_flat_s2_workspace(const bp_view* Y);
+int bp_wgrad_flat_s2(const bp_view* X, const PW& pwx, const bp_view* Y, const PW& pwy, float* dst, void* workspace,
+                     size_t workspace_bytes, hipStream_t st, bool shared);
 static size_t wgrad_general_workspace(const bp_conv* cv, const bp_view* X, const bp_view* Y);
 
 size_t bp_wgrad_mfma_workspace(const bp_conv* cv, const bp_view* X, const bp_view* Y) {
@@ -312,6 +317,10 @@ size_t bp_wgrad_mfma_workspace(const bp_conv* cv, const bp_view* X, const bp_vie
   }
   if (bp_wgrad_flat_ok(cv, X, Y, PW{nullptr, nullptr, nullptr})) {
     const size_t flat = bp_wgrad_flat_workspace(X);
+    return flat > general ? flat : general;
+  }
+  if (bp_wgrad_flat_s2_ok(cv, X, Y, PW{nullptr, nullptr, nullptr}, PW{nullptr, nullptr, nullptr})) {
+    const size_t flat = bp_wgrad_flat_s2_workspace(Y);
     return flat > general ? flat : general;
   }
   return general;
@@ -331,9 +340,11 @@ static size_t wgrad_general_workspace(const bp_conv* cv, const bp_view* X, const
 }
 
 int bp_wgrad_mfma(const bp_conv* cv, const bp_view* X, const PW& pwx, const bp_view* Y, const PW& pwy,
-                  float* dst, void* workspace, size_t workspace_bytes, hipStream_t st) {
+                  float* dst, void* workspace, size_t workspace_bytes, hipStream_t st, bool shared) {
   if (bp_stem_wgrad_ok(cv, X, Y, pwy, nullptr)) return bp_stem_wgrad(X, pwx, Y, dst, workspace, workspace_bytes, st);
-  if (bp_wgrad_flat_ok(cv, X, Y, pwy)) return bp_wgrad_flat(X, pwx, Y, dst, workspace, workspace_bytes, st);
+  if (bp_wgrad_flat_ok(cv, X, Y, pwy)) return bp_wgrad_flat(X, pwx, Y, dst, workspace, workspace_bytes, st, shared);
+  if (bp_wgrad_flat_s2_ok(cv, X, Y, pwx, pwy))
+    return bp_wgrad_flat_s2(X, pwx, Y, pwy, dst, workspace, workspace_bytes, st, shared);
   {
     bool on_x = false;
     if (wide_side_chunks(cv, X, Y, &on_x)) {

@@ -156,7 +156,7 @@ class _Plan:
         # beside that chain's HBM-bound passes.  They get their own workspace.
         self.side = self._side_stream = None
         if with_grad and os.environ.get("BP_SIDE_WGRAD", "1") != "0":
-            self.side = self._side_stream = torch.cuda.Stream(device=dev)
+            self.side = self._side_stream = torch.cuda.Stream(device=dev, priority=int(os.environ.get("BP_SIDE_PRIORITY", "0")))
             self.ws2 = torch.zeros_like(self.ws)
         # q_x_in, q_y_in and the prior network are independent chains of small kernels (none fills the GPU):
         # q_y_in and the prior run on their own streams, each with its own reduction workspace

@@ -589,7 +589,8 @@ class ConvUnit:
             t0 = plan.prof_begin()
             L.check(lib.bp_conv_backward_weight(C.byref(self.cv), C.byref(self.inp.view), self.inp.pw_struct(),
                                                 C.byref(g), L.ptr(grads[id(hold.weight)]), L.ptr(dbias),
-                                                L.ptr(ws), plan.ws_bytes, self._impl("wgrad"), _stream()),
+                                                L.ptr(ws), plan.ws_bytes,
+                                                self._impl("wgrad") | (L.IMPL_SHARED if side is not None else 0), _stream()),
                     f"{self.name} backward_weight")
             plan.prof_end(t0, self, "backward_weight")
 

@@ -62,6 +62,8 @@ def kernel_name(kind, unit, lib):
             return "stem_wgrad_kernel"
         if (cv.transposed, cv.cin, cv.cout, cv.k, cv.stride, cv.pad) == (0, 16, 8, 7, 1, 3):
             return "wgrad_flat_kernel"
+        if (cx, cy, cv.k, cv.stride, cv.pad) == (16, 32, 4, 2, 1):
+            return "wgrad_flat_s2_kernel"
         if cx <= 16 and cy <= 16 and not (cx == 16 and cy == 16) and (cv.k, cv.stride) in ((3, 1), (5, 1), (7, 1), (4, 2), (8, 4)):
             return "wgrad_small_kernel[k%ds%d %d,%d]" % (cv.k, cv.stride, cx, cy)
         return "wgrad_tiles_kernel[k%ds%d %s]" % (cv.k, cv.stride, "wide" if (cx > 16 and cy > 16) else "thin")
@@ -266,6 +268,10 @@ def main():
     x = torch.from_numpy(np.tile(x, (reps, 1, 1, 1))[:n]).to(dev)
     y = torch.from_numpy(np.tile(y, (reps, 1, 1, 1))[:n]).to(dev)
     aux = torch.from_numpy(np.tile(aux, reps)[:n]).to(dev)
+
+    if os.environ.get("BP_MAIN_PRIORITY"):           # experiment: the main chain on a stream of another priority
+        torch.cuda.synchronize()
+        torch.cuda.set_stream(torch.cuda.Stream(device=dev, priority=int(os.environ["BP_MAIN_PRIORITY"])))
 
     def eager_step():
         elbo = model(x, y, aux)

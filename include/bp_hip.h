@@ -65,6 +65,10 @@ typedef struct bp_conv {
 } bp_conv;
 
 enum { BP_IMPL_AUTO = 0, BP_IMPL_DIRECT = 1, BP_IMPL_MFMA = 2, BP_IMPL_BF16 = 3 };
+/* OR-ed into `impl` of bp_conv_backward_weight: the launch shares the GPU with kernels of another stream (the
+ * training step runs weight gradients beside the data-gradient chain), so persistent kernels take one workgroup
+ * per CU instead of two and leave room for the other stream's workgroups.  Same results bit for bit. */
+enum { BP_IMPL_SHARED = 0x100 };
 enum { BP_PACK_FWD = 0, BP_PACK_BWD = 1 };
 
 /* ---- library ------------------------------------------------------------------------------ */

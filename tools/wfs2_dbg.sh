@@ -1,0 +1,2 @@
+#!/bin/bash
+python tools/conv_bench.py 0,16,32,4,2,1,64,512,512 1,32,16,4,2,1,64,256,256 2>&1 | grep -v amdgpu.ids | sed 's/.*dgrad[^|]*| //'
