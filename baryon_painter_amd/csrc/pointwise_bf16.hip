@@ -103,6 +103,7 @@ struct ActBwd8 {
 };
 
 // g = (dout [+ dout2]) * act'(t), sums {sum g, sum g*raw, sum d*t*[t<=0]}  (bp_act_backward's contract)
+template <bool D2, bool AO, bool WG>
 __global__ __launch_bounds__(RB) void act_backward_bf16_kernel(ActBwd8 a) {
   __shared__ double sh[RB * 8];
   const Pw8 p = pw8_load(a.pw, a.c);
@@ -119,8 +120,8 @@ __global__ __launch_bounds__(RB) void act_backward_bf16_kernel(ActBwd8 a) {
     for (int u = 0; u < 2; ++u) {
       const int64_t i = i0 + u * RB < b1 ? i0 + u * RB : i0;
       qd[u] = a.dout[i]; qr[u] = a.raw[i];
-      if (a.dout2) q2[u] = a.dout2[i];
-      if (a.aout) qa[u] = a.aout[i];
+      if constexpr (D2) q2[u] = a.dout2[i];
+      if constexpr (AO) qa[u] = a.aout[i];
     }
     float p0[8], p1[8], p2[8];
 #pragma unroll
@@ -131,24 +132,24 @@ __global__ __launch_bounds__(RB) void act_backward_bf16_kernel(ActBwd8 a) {
       if (i >= b1) break;
       float d[8], r[8], so[8], g[8];
       unpack8(qd[u], d);
-      if (a.dout2) {
+      if constexpr (D2) {
         float e[8];
         unpack8(q2[u], e);
 #pragma unroll
         for (int j = 0; j < 8; ++j) d[j] += e[j];
       }
       unpack8(qr[u], r);
-      if (a.aout) unpack8(qa[u], so);
+      if constexpr (AO) unpack8(qa[u], so);
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const float t = fmaf(r[j], p.sc[j], p.sf[j]);
-        const bool pos = (a.aout ? so[j] : t) > 0.f;
+        const bool pos = (AO ? so[j] : t) > 0.f;
         g[j] = pos ? d[j] : d[j] * p.sl[j];
         p0[j] += g[j];
         p1[j] = fmaf(g[j], r[j], p1[j]);
         if (!pos) p2[j] = fmaf(d[j], t, p2[j]);
       }
-      if (a.g) a.g[i] = pack8(g);
+      if constexpr (WG) a.g[i] = pack8(g);
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j) { acc[0][j] += (double)p0[j]; acc[1][j] += (double)p1[j]; acc[2][j] += (double)p2[j]; }
@@ -161,7 +162,10 @@ struct Apply8 {
   PW pw; const double* abc; int c; int64_t total8; int recompute_g;
 };
 
-// out = A*(g - mg) + B*(raw - mean), g either given (dout IS g) or recomputed from (dout [+ dout2], mask)
+// out = A*(g - mg) + B*(raw - mean), g either given (dout IS g) or recomputed from (dout [+ dout2], mask).
+// Two 16-byte units per thread and trip with every load of the trip issued before the first use (the variants are
+// template parameters: a load under a run-time condition is waited for on the spot), raw words kept until then.
+template <bool D2, bool AO, bool RG>
 __global__ __launch_bounds__(RB) void bn_backward_apply_bf16_kernel(Apply8 a) {
   const int c = a.c;
   const Pw8 p = pw8_load(a.pw, c);
@@ -171,28 +175,44 @@ __global__ __launch_bounds__(RB) void bn_backward_apply_bf16_kernel(Apply8 a) {
     const int ch = (8 * threadIdx.x + j) % c;
     A[j] = (float)a.abc[ch]; G[j] = (float)a.abc[c + ch]; B[j] = (float)a.abc[2 * c + ch]; M[j] = (float)a.abc[3 * c + ch];
   }
-  for (int64_t i = (int64_t)blockIdx.x * RB + threadIdx.x; i < a.total8; i += (int64_t)gridDim.x * RB) {
+  const int64_t stride = (int64_t)gridDim.x * RB;
+  auto one = [&](const uint4 wd, const uint4 w2, const uint4 wr, const uint4 wa) {
     float d[8], r[8], so[8], o[8];
-    unpack8(a.dout[i], d);
-    if (a.dout2) {
+    unpack8(wd, d);
+    if constexpr (D2) {
       float e[8];
-      unpack8(a.dout2[i], e);
+      unpack8(w2, e);
 #pragma unroll
       for (int j = 0; j < 8; ++j) d[j] += e[j];
     }
-    unpack8(a.raw[i], r);
-    if (a.aout) unpack8(a.aout[i], so);
+    unpack8(wr, r);
+    if constexpr (AO) unpack8(wa, so);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       float g = d[j];
-      if (a.recompute_g) {
+      if constexpr (RG) {
         const float t = fmaf(r[j], p.sc[j], p.sf[j]);
-        const bool pos = (a.aout ? so[j] : t) > 0.f;
+        const bool pos = (AO ? so[j] : t) > 0.f;
         g = pos ? d[j] : d[j] * p.sl[j];
       }
       o[j] = fmaf(A[j], g - G[j], B[j] * (r[j] - M[j]));
     }
-    a.out[i] = pack8(o);
+    return pack8(o);
+  };
+  int64_t i = (int64_t)blockIdx.x * RB + threadIdx.x;
+  for (; i + stride < a.total8; i += 2 * stride) {
+    const int64_t k = i + stride;
+    const uint4 z = make_uint4(0, 0, 0, 0);
+    const uint4 d0 = a.dout[i], d1 = a.dout[k];
+    const uint4 e0 = D2 ? a.dout2[i] : z, e1 = D2 ? a.dout2[k] : z;
+    const uint4 r0 = a.raw[i], r1 = a.raw[k];
+    const uint4 s0 = AO ? a.aout[i] : z, s1 = AO ? a.aout[k] : z;
+    a.out[i] = one(d0, e0, r0, s0);
+    a.out[k] = one(d1, e1, r1, s1);
+  }
+  if (i < a.total8) {
+    const uint4 z = make_uint4(0, 0, 0, 0);
+    a.out[i] = one(a.dout[i], D2 ? a.dout2[i] : z, a.raw[i], AO ? a.aout[i] : z);
   }
 }
 
@@ -267,7 +287,17 @@ int bp_bf16_act_backward(const bp_view* dout, const bp_view* dout2, const bp_vie
   a.dout = u4(dout); a.dout2 = u4(dout2); a.raw = u4(raw); a.aout = u4(act_out);
   a.g = g ? reinterpret_cast<uint4*>(g->ptr) : nullptr;
   a.pw = pw; a.c = raw->c; a.total8 = f.total8; a.chunk8 = f.chunk8; a.partial = reinterpret_cast<double*>(workspace);
-  hipLaunchKernelGGL(act_backward_bf16_kernel, dim3(f.nblk), dim3(RB), 0, st, a);
+  const dim3 grid(f.nblk), block(RB);
+  switch ((a.dout2 ? 4 : 0) | (a.aout ? 2 : 0) | (a.g ? 1 : 0)) {
+    case 0: hipLaunchKernelGGL((act_backward_bf16_kernel<false, false, false>), grid, block, 0, st, a); break;
+    case 1: hipLaunchKernelGGL((act_backward_bf16_kernel<false, false, true>), grid, block, 0, st, a); break;
+    case 2: hipLaunchKernelGGL((act_backward_bf16_kernel<false, true, false>), grid, block, 0, st, a); break;
+    case 3: hipLaunchKernelGGL((act_backward_bf16_kernel<false, true, true>), grid, block, 0, st, a); break;
+    case 4: hipLaunchKernelGGL((act_backward_bf16_kernel<true, false, false>), grid, block, 0, st, a); break;
+    case 5: hipLaunchKernelGGL((act_backward_bf16_kernel<true, false, true>), grid, block, 0, st, a); break;
+    case 6: hipLaunchKernelGGL((act_backward_bf16_kernel<true, true, false>), grid, block, 0, st, a); break;
+    default: hipLaunchKernelGGL((act_backward_bf16_kernel<true, true, true>), grid, block, 0, st, a); break;
+  }
   BP_CHECK_LAUNCH();
   return bp_sum_partials(a.partial, f.nblk, 3 * raw->c, sums, st);
 }
@@ -279,7 +309,18 @@ int bp_bf16_bn_backward_apply(const bp_view* dout, const bp_view* dout2, const b
   a.dout = u4(dout); a.dout2 = u4(dout2); a.raw = u4(raw); a.aout = u4(act_out);
   a.out = reinterpret_cast<uint4*>(out->ptr); a.pw = pw; a.abc = abc; a.c = raw->c;
   a.total8 = bp_view_pixels(raw) * raw->c / 8; a.recompute_g = recompute_g ? 1 : 0;
-  hipLaunchKernelGGL(bn_backward_apply_bf16_kernel, dim3(stream_blocks(a.total8)), dim3(RB), 0, st, a);
+  const dim3 grid(stream_blocks(a.total8)), block(RB);
+  const int variant = (a.dout2 ? 4 : 0) | (a.aout ? 2 : 0) | (a.recompute_g ? 1 : 0);
+  switch (variant) {
+    case 0: hipLaunchKernelGGL((bn_backward_apply_bf16_kernel<false, false, false>), grid, block, 0, st, a); break;
+    case 1: hipLaunchKernelGGL((bn_backward_apply_bf16_kernel<false, false, true>), grid, block, 0, st, a); break;
+    case 2: hipLaunchKernelGGL((bn_backward_apply_bf16_kernel<false, true, false>), grid, block, 0, st, a); break;
+    case 3: hipLaunchKernelGGL((bn_backward_apply_bf16_kernel<false, true, true>), grid, block, 0, st, a); break;
+    case 4: hipLaunchKernelGGL((bn_backward_apply_bf16_kernel<true, false, false>), grid, block, 0, st, a); break;
+    case 5: hipLaunchKernelGGL((bn_backward_apply_bf16_kernel<true, false, true>), grid, block, 0, st, a); break;
+    case 6: hipLaunchKernelGGL((bn_backward_apply_bf16_kernel<true, true, false>), grid, block, 0, st, a); break;
+    default: hipLaunchKernelGGL((bn_backward_apply_bf16_kernel<true, true, true>), grid, block, 0, st, a); break;
+  }
   BP_CHECK_LAUNCH();
   return BP_OK;
 }
