@@ -378,3 +378,251 @@ int bp_flat_t4_run(const bp_view* in, const PW& pw, const float* packed, const f
   if (sr) return bp_sum_partials(a.stat, grid, 2 * TCO, sr->sums, st);
   return BP_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Stride-2 k4 conv form gathering 32 channels into 64 (Conv2d 32 -> 64 k4s2 forward, arch p_y_z_in.6, and the data
+// gradient of ConvTranspose2d 64 -> 32 k4s2, p_y_z_in.19): K = 16 taps x 32 channels = 128 K-groups.  The weights of
+// 16 produced channels are 128 fragments = the registers of one wave, so a workgroup is 8 waves: four blocks of 16
+// produced channels x two row pairs of a 4 x 16 output tile; every wave walks all 128 K-groups of its two rows with one
+// 4-byte LDS read per MFMA.  The gathered tile (10 x 34 pixels, eight channel-quad planes, columns split by parity so
+// that the 16 pixels of a row read 256 contiguous bytes for any tap) is double buffered: the next tile is committed
+// to the other buffer as soon as a wave is done with its MFMAs, one barrier per tile.  Batch-norm sums (forward,
+// mode 1) are kept per lane in double over all the tiles of the workgroup.
+namespace {
+
+constexpr int GK = 4, GS = 2, GPAD = 1, GCG = 32, GCO = 64;
+constexpr int GNQ = GCG / 4;                          // 8 quad planes
+constexpr int GTH = 4, GTW = 16;                      // output tile of a workgroup
+constexpr int GIH = GS * GTH + 2, GIW = GS * GTW + 2; // gathered rows / columns of a tile (10 x 34)
+constexpr int GHALF = GIW / 2;                        // columns of one parity (17)
+constexpr int GPLANE = GIH * GIW * 4;                 // floats of a quad plane
+constexpr int GTILE = GNQ * GPLANE;                   // floats of a tile (10880)
+constexpr int GNU = GIH * GIW * GNQ;                  // float4 units (2720)
+constexpr int GNT = 512;                              // threads
+constexpr int GSL = (GNU + GNT - 1) / GNT;            // units per thread (6)
+constexpr int GNW = GK * GK * GNQ;                    // weight fragments of a wave (128)
+
+struct FlatGArgs {
+  const float* in; int in_h, in_w, in_cs, in_co;
+  float* out; int out_h, out_w, out_cs, out_co;
+  const float* wp;            // [co block][tap][quad][kq][co]
+  const float* bias;
+  PW pw;
+  int n, tiles_x, tiles_y, in_vec;
+  double* stat;               // partial sums [workgroup][2][64] or nullptr
+};
+
+template <bool STATS>
+__global__ __launch_bounds__(GNT) void flat_g4_kernel(FlatGArgs a) {
+  __shared__ __attribute__((aligned(16))) float tile[2 * GTILE];
+  __shared__ double red[STATS ? 8 : 1][2][16];
+  __shared__ float lpw[3][GCG];                     // pending activation of the gathered channels (read at commit time)
+  __shared__ double lsum[STATS ? 8 * GNT : 1];   // per-lane running sums {sum, sum of squares} x 4 channels (not registers)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int cb = wave & 3, rh = wave >> 2;            // block of 16 produced channels, row pair of the tile
+  const int lm = lane & 15, kq = lane >> 4;
+
+  float wreg[GNW];
+#pragma unroll
+  for (int i = 0; i < GNW; ++i) wreg[i] = a.wp[(((int64_t)cb * GNW + i) * 4 + kq) * 16 + lm];
+
+  const int q8 = tid % GNQ;
+  if (tid < GCG) {
+    const bool on = a.pw.scale != nullptr;
+    lpw[0][tid] = on ? a.pw.scale[tid] : 1.f;
+    lpw[1][tid] = on ? a.pw.shift[tid] : 0.f;
+    lpw[2][tid] = on ? a.pw.slope[tid] : 1.f;
+  }
+  __syncthreads();
+  const int per_img = a.tiles_x * a.tiles_y;
+  const int ntiles = per_img * a.n;
+  float4 stage[GSL];
+  unsigned inside = 0;
+  auto fetch = [&](int t) {
+    const int n = t / per_img, r = t % per_img;
+    const int y0 = GS * (r / a.tiles_x) * GTH - GPAD, x0 = GS * (r % a.tiles_x) * GTW - GPAD;
+    const float* in_n = a.in + (int64_t)n * a.in_h * a.in_w * a.in_cs + a.in_co + q8 * 4;
+    unsigned in = 0;
+#pragma unroll
+    for (int i = 0; i < GSL; ++i) {
+      const int e = tid + i * GNT;
+      const int pix = e / GNQ, col = pix % GIW, row = pix / GIW;
+      const int iy = y0 + row, ix = x0 + col;
+      in |= ((unsigned)(e < GNU) & (unsigned)(iy >= 0) & (unsigned)(iy < a.in_h) & (unsigned)(ix >= 0) &
+             (unsigned)(ix < a.in_w)) << i;
+      const int cy = min(max(iy, 0), a.in_h - 1), cx = min(max(ix, 0), a.in_w - 1);
+      const float* p = in_n + ((int64_t)cy * a.in_w + cx) * a.in_cs;
+      stage[i] = a.in_vec ? *reinterpret_cast<const float4*>(p) : make_float4(p[0], p[1], p[2], p[3]);
+    }
+    inside = in;
+  };
+  auto commit = [&](float* buf) {
+    PW4 p4;                                            // (12 LDS reads per tile instead of 12 registers held)
+    p4.on = true;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { p4.sc[j] = lpw[0][q8 * 4 + j]; p4.sf[j] = lpw[1][q8 * 4 + j]; p4.sl[j] = lpw[2][q8 * 4 + j]; }
+#pragma unroll
+    for (int i = 0; i < GSL; ++i) {
+      const int e = tid + i * GNT;
+      if (e < GNU) {
+        const int pix = e / GNQ, col = pix % GIW, row = pix / GIW;
+        const float4 v = pw4_apply4(p4, stage[i]);
+        const bool in = (inside >> i) & 1u;
+        *reinterpret_cast<float4*>(buf + q8 * GPLANE + ((row * 2 + (col & 1)) * GHALF + (col >> 1)) * 4) =
+            make_float4(in ? v.x : 0.f, in ? v.y : 0.f, in ? v.z : 0.f, in ? v.w : 0.f);
+      }
+    }
+  };
+
+  if constexpr (STATS) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) lsum[q * GNT + tid] = 0.0;
+  }
+  int t = blockIdx.x, cur = 0;
+  if (t < ntiles) { fetch(t); commit(tile); }
+  __syncthreads();
+  for (; t < ntiles; t += gridDim.x) {
+    const int tn = t + gridDim.x;
+    if (tn < ntiles) fetch(tn);
+    const int n = t / per_img, r = t % per_img;
+    const int oy0 = (r / a.tiles_x) * GTH + 2 * rh, ox = (r % a.tiles_x) * GTW + lm;
+    // rows 2 rh and 2 rh + 1 of the tile: gathered rows 2 row + ky, column 2 lm + kx -> parity kx & 1, half lm + (kx >> 1)
+    const float* base = tile + cur * GTILE + ((4 * rh) * 2 * GHALF + lm) * 4 + kq;
+    v4f acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    // one tap (8 K-groups, both rows) per stage; the fragments of the next tap are read before the MFMAs of this one
+    float f0[2][GNQ], f1[2][GNQ];
+    auto frags = [&](int buf, int tap) {
+      const int ky = tap / GK, kx = tap % GK;
+#pragma unroll
+      for (int j = 0; j < GNQ; ++j) {
+        const int off = j * GPLANE + ((ky * 2 + (kx & 1)) * GHALF + (kx >> 1)) * 4;
+        f0[buf][j] = base[off];
+        f1[buf][j] = base[off + 2 * 2 * GHALF * 4];
+      }
+    };
+    frags(0, 0);
+#pragma unroll
+    for (int tap = 0; tap < GK * GK; ++tap) {
+      if (tap + 1 < GK * GK) frags((tap + 1) & 1, tap + 1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < GNQ; ++j) {
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[tap * GNQ + j], f0[tap & 1][j], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[tap * GNQ + j], f1[tap & 1][j], acc1, 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    float* out_n = a.out + (int64_t)n * a.out_h * a.out_w * a.out_cs + a.out_co + 16 * cb + 4 * kq;
+    if (a.bias) {                                        // (uniform; read here, not held over the MFMA phase)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { const float b = a.bias[16 * cb + 4 * kq + q]; acc0[q] += b; acc1[q] += b; }
+    }
+    if (ox < a.out_w) {
+      if (oy0 < a.out_h) {
+        *reinterpret_cast<float4*>(out_n + ((int64_t)oy0 * a.out_w + ox) * a.out_cs) = make_float4(acc0[0], acc0[1], acc0[2], acc0[3]);
+        if constexpr (STATS) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            lsum[q * GNT + tid] += (double)acc0[q];
+            lsum[(4 + q) * GNT + tid] = fma((double)acc0[q], (double)acc0[q], lsum[(4 + q) * GNT + tid]);
+          }
+        }
+      }
+      if (oy0 + 1 < a.out_h) {
+        *reinterpret_cast<float4*>(out_n + ((int64_t)(oy0 + 1) * a.out_w + ox) * a.out_cs) = make_float4(acc1[0], acc1[1], acc1[2], acc1[3]);
+        if constexpr (STATS) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            lsum[q * GNT + tid] += (double)acc1[q];
+            lsum[(4 + q) * GNT + tid] = fma((double)acc1[q], (double)acc1[q], lsum[(4 + q) * GNT + tid]);
+          }
+        }
+      }
+    }
+    if (tn < ntiles) commit(tile + (cur ^ 1) * GTILE);     // (nobody reads that buffer in this iteration)
+    __syncthreads();
+    cur ^= 1;
+  }
+  if constexpr (STATS) {
+    double s1[4], s2[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { s1[q] = lsum[q * GNT + tid]; s2[q] = lsum[(4 + q) * GNT + tid]; }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int off = 8; off > 0; off >>= 1) {
+        s1[q] += __shfl_xor(s1[q], off, 16);
+        s2[q] += __shfl_xor(s2[q], off, 16);
+      }
+    if (lm == 0) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { red[wave][0][4 * kq + q] = s1[q]; red[wave][1][4 * kq + q] = s2[q]; }
+    }
+    __syncthreads();
+    if (tid < 2 * GCO) {
+      const int sidx = tid / GCO, c = tid % GCO;
+      a.stat[(int64_t)blockIdx.x * 2 * GCO + tid] = red[c / 16][sidx][c % 16] + red[4 + c / 16][sidx][c % 16];
+    }
+  }
+}
+
+struct FlatGPackArgs { const float* w; float* dst; int64_t sa, sb; };
+__global__ void flat_g4_pack_kernel(FlatGPackArgs a) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;      // (((cb*16 + tap)*8 + j)*4 + kq)*16 + lm
+  if (i >= GCG * GCO * GK * GK) return;
+  const int lm = i % 16, kq = (i / 16) % 4, j = (i / 64) % GNQ, tap = (i / (64 * GNQ)) % (GK * GK), cb = i / (64 * GNQ * GK * GK);
+  const int c = 4 * j + kq, co = 16 * cb + lm;              // gathered channel, produced channel
+  a.dst[i] = a.w[c * a.sa + co * a.sb + tap];
+}
+
+int flat_g4_grid(int ntiles) {
+  static const int cap = getenv("BP_FLATG_GRID") ? atoi(getenv("BP_FLATG_GRID")) : 256;
+  return ntiles < cap ? ntiles : cap;
+}
+
+}  // namespace
+
+bool bp_flat_g4_ok(const ConvGeom& g) {
+  static const bool off = getenv("BP_NOFLAT") != nullptr || getenv("BP_NOFLATG") != nullptr;
+  return !off && !g.gather_transposed && g.k == GK && g.stride == GS && g.pad == GPAD && g.cin_g == GCG && g.cout_g == GCO &&
+         g.nphase == 1 && g.IS == GS;
+}
+
+int64_t bp_flat_g4_packed_floats() { return (int64_t)GCG * GCO * GK * GK; }
+
+int bp_flat_g4_pack(const WeightMap& wm, const float* w_torch, float* packed, hipStream_t st) {
+  FlatGPackArgs a{w_torch, packed, wm.sa, wm.sb};
+  hipLaunchKernelGGL(flat_g4_pack_kernel, dim3((GCG * GCO * GK * GK + 255) / 256), dim3(256), 0, st, a);
+  BP_CHECK_LAUNCH();
+  return BP_OK;
+}
+
+static int flat_g4_tiles(const bp_view* out) { return bp_ceil_div(out->w, GTW) * bp_ceil_div(out->h, GTH) * out->n; }
+
+size_t bp_flat_g4_stats_workspace(const bp_view* out) {
+  return (size_t)flat_g4_grid(flat_g4_tiles(out)) * 2 * GCO * sizeof(double);
+}
+
+int bp_flat_g4_run(const bp_view* in, const PW& pw, const float* packed, const float* bias, const bp_view* out,
+                   hipStream_t st, const IgemmStatsReq* sr) {
+  if ((sr && (bias || sr->mode != 1)) || !bp_view_vec4(out)) return BP_EUNSUPPORTED;
+  FlatGArgs a{};
+  a.bias = bias;
+  a.in = in->ptr; a.in_h = in->h; a.in_w = in->w; a.in_cs = in->cstride; a.in_co = in->coff;
+  a.out = out->ptr; a.out_h = out->h; a.out_w = out->w; a.out_cs = out->cstride; a.out_co = out->coff;
+  a.wp = packed; a.pw = pw; a.n = in->n; a.in_vec = bp_view_vec4(in) ? 1 : 0;
+  a.tiles_x = bp_ceil_div(out->w, GTW); a.tiles_y = bp_ceil_div(out->h, GTH);
+  const int64_t ntiles = (int64_t)a.tiles_x * a.tiles_y * a.n;
+  if (ntiles > 0x7fffffff) return BP_EUNSUPPORTED;
+  const int grid = flat_g4_grid((int)ntiles);
+  if (sr) {
+    if (!sr->ws || sr->ws_bytes < bp_flat_g4_stats_workspace(out) || !sr->sums) return BP_EWORKSPACE;
+    a.stat = reinterpret_cast<double*>(sr->ws);
+  }
+  if (sr) hipLaunchKernelGGL(flat_g4_kernel<true>, dim3(grid), dim3(GNT), 0, st, a);
+  else hipLaunchKernelGGL(flat_g4_kernel<false>, dim3(grid), dim3(GNT), 0, st, a);
+  BP_CHECK_LAUNCH();
+  if (sr) return bp_sum_partials(a.stat, grid, 2 * GCO, sr->sums, st);
+  return BP_OK;
+}

@@ -150,6 +150,8 @@ DMA_CASES = [
     (0, 16, 8, 7, 1, 3, (40, 64, 130)),       # conv_flat.hip data gradient with more tiles than workgroups
     (1, 32, 16, 4, 2, 1, (3, 9, 13)),         # conv_flat.hip four-phase transposed form (forward); gather: wres
     (1, 32, 16, 4, 2, 1, (24, 40, 80)),       # ... more tiles than workgroups
+    (0, 32, 64, 4, 2, 1, (40, 64, 96)),       # conv_flat.hip stride-2 gather 32 -> 64: more tiles than workgroups
+    (1, 64, 32, 4, 2, 1, (5, 31, 50)),        # ... as the data gradient of the transposed layer, ragged tiles
 ]
 
 

@@ -1,7 +1,8 @@
 #!/bin/bash
-python bench.py --steps 16 --warmup 3 --no-cpu-baseline --no-paint --dtype bf16 2>/dev/null | python -c "
+run() { python bench.py --steps 16 --warmup 3 --no-cpu-baseline --no-paint $2 2>/dev/null | python -c "
 import sys, json
-d = json.loads(sys.stdin.read().strip().splitlines()[-1]); print('bf16', d['value'], d['ms_per_step'])
-pk = d['roofline']['per_kernel']
-for k in ('bn_backward_apply_bf16_kernel', 'act_backward_bf16_kernel', 'act_backward_fast_kernel', 'bn_backward_apply_fast_kernel'):
-    print(k, pk.get(k))"
+d = json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$1', d['value'], d['ms_per_step'])"; }
+for i in 1 2; do
+  run f32
+  BP_NOFLATG=1 run f32_noflatg
+done
