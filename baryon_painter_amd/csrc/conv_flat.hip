@@ -626,3 +626,250 @@ int bp_flat_g4_run(const bp_view* in, const PW& pw, const float* packed, const f
   if (sr) return bp_sum_partials(a.stat, grid, 2 * GCO, sr->sums, st);
   return BP_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Stride-2 k4 transposed forms gathering 64 channels into 32 (ConvTranspose2d 64 -> 32 k4s2 forward, arch
+// p_y_z_in.19, and the data gradient of Conv2d 32 -> 64 k4s2, p_y_z_in.6).  Eight waves = the four output phases x two
+// blocks of 16 produced channels: a wave keeps the 2 x 2 taps x 16 channel quads = 64 weight fragments of ITS phase
+// and channel block in registers and walks the 8 rows of the phase-grid tile (8 x 16 pixels; the gathered tile,
+// 10 x 18 pixels in 16 quad planes, serves all four phases).  Double-buffered tile, one barrier per tile,
+// fragments read one tap ahead, batch-norm sums per lane in LDS -- as in flat_g4_kernel.
+namespace {
+
+constexpr int WCG = 64, WCO = 32;
+constexpr int WNQ = WCG / 4;                          // 16 quad planes
+constexpr int WTH = 8, WTW = 16;                      // phase-grid tile
+constexpr int WIH = WTH + 2, WIW = WTW + 2;           // gathered rows / columns (10 x 18)
+constexpr int WPLANE = WIH * WIW * 4;
+constexpr int WTILE = WNQ * WPLANE;                   // floats of a tile (11520)
+constexpr int WNU = WIH * WIW * WNQ;                  // float4 units (2880)
+constexpr int WSL = (WNU + GNT - 1) / GNT;            // per thread (6)
+constexpr int WNW = 4 * WNQ;                          // weight fragments of a wave (64)
+
+struct FlatWArgs {
+  const float* in; int in_h, in_w, in_cs, in_co;
+  float* out; int out_h, out_w, out_cs, out_co;
+  const float* wp;            // [co block][phase][t][s][quad][kq][co]
+  const float* bias;
+  PW pw;
+  int n, tiles_x, tiles_y, in_vec;
+  double* stat;               // partial sums [workgroup][2][32] or nullptr
+};
+
+template <bool STATS>
+__global__ __launch_bounds__(GNT) void flat_t64_kernel(FlatWArgs a) {
+  __shared__ __attribute__((aligned(16))) float tile[2 * WTILE];
+  __shared__ double red[STATS ? 8 : 1][2][16];
+  __shared__ double lsum[STATS ? 8 * GNT : 1];
+  __shared__ float lpw[3][WCG];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ph = wave & 3, cb = wave >> 2;            // output phase, block of 16 produced channels
+  const int py = ph >> 1, px = ph & 1;
+  const int lm = lane & 15, kq = lane >> 4;
+
+  float wreg[WNW];
+#pragma unroll
+  for (int i = 0; i < WNW; ++i) wreg[i] = a.wp[((((int64_t)cb * 4 + ph) * WNW + i) * 4 + kq) * 16 + lm];
+
+  const int q16 = tid % WNQ;
+  if (tid < WCG) {
+    const bool on = a.pw.scale != nullptr;
+    lpw[0][tid] = on ? a.pw.scale[tid] : 1.f;
+    lpw[1][tid] = on ? a.pw.shift[tid] : 0.f;
+    lpw[2][tid] = on ? a.pw.slope[tid] : 1.f;
+  }
+  if constexpr (STATS) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) lsum[q * GNT + tid] = 0.0;
+  }
+  __syncthreads();
+  const int per_img = a.tiles_x * a.tiles_y;
+  const int ntiles = per_img * a.n;
+  float4 stage[WSL];
+  unsigned inside = 0;
+  auto fetch = [&](int t) {
+    const int n = t / per_img, r = t % per_img;
+    const int y0 = (r / a.tiles_x) * WTH - 1, x0 = (r % a.tiles_x) * WTW - 1;
+    const float* in_n = a.in + (int64_t)n * a.in_h * a.in_w * a.in_cs + a.in_co + q16 * 4;
+    unsigned in = 0;
+#pragma unroll
+    for (int i = 0; i < WSL; ++i) {
+      const int e = tid + i * GNT;
+      const int pix = e / WNQ, col = pix % WIW, row = pix / WIW;
+      const int iy = y0 + row, ix = x0 + col;
+      in |= ((unsigned)(e < WNU) & (unsigned)(iy >= 0) & (unsigned)(iy < a.in_h) & (unsigned)(ix >= 0) &
+             (unsigned)(ix < a.in_w)) << i;
+      const int cy = min(max(iy, 0), a.in_h - 1), cx = min(max(ix, 0), a.in_w - 1);
+      const float* p = in_n + ((int64_t)cy * a.in_w + cx) * a.in_cs;
+      stage[i] = a.in_vec ? *reinterpret_cast<const float4*>(p) : make_float4(p[0], p[1], p[2], p[3]);
+    }
+    inside = in;
+  };
+  auto commit = [&](float* buf) {
+    PW4 p4;
+    p4.on = true;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { p4.sc[j] = lpw[0][q16 * 4 + j]; p4.sf[j] = lpw[1][q16 * 4 + j]; p4.sl[j] = lpw[2][q16 * 4 + j]; }
+#pragma unroll
+    for (int i = 0; i < WSL; ++i) {
+      const int e = tid + i * GNT;
+      if (e < WNU) {
+        const float4 v = pw4_apply4(p4, stage[i]);
+        const bool in = (inside >> i) & 1u;
+        *reinterpret_cast<float4*>(buf + q16 * WPLANE + (e / WNQ) * 4) =
+            make_float4(in ? v.x : 0.f, in ? v.y : 0.f, in ? v.z : 0.f, in ? v.w : 0.f);
+      }
+    }
+  };
+
+  int t = blockIdx.x, cur = 0;
+  if (t < ntiles) { fetch(t); commit(tile); }
+  __syncthreads();
+  for (; t < ntiles; t += gridDim.x) {
+    const int tn = t + gridDim.x;
+    if (tn < ntiles) fetch(tn);
+    const int n = t / per_img, r = t % per_img;
+    const int qy0 = (r / a.tiles_x) * WTH, qx0 = (r % a.tiles_x) * WTW;
+    float* out_n = a.out + (int64_t)n * a.out_h * a.out_w * a.out_cs + a.out_co + 16 * cb + 4 * kq;
+    const int X = 2 * (qx0 + lm) + px;
+    v4f b4 = {0.f, 0.f, 0.f, 0.f};
+    if (a.bias) b4 = v4f{a.bias[16 * cb + 4 * kq], a.bias[16 * cb + 4 * kq + 1], a.bias[16 * cb + 4 * kq + 2], a.bias[16 * cb + 4 * kq + 3]};
+    // staged row of tap t: row + py + t, column: lm + px + s
+    const float* base = tile + cur * WTILE + ((py * WIW) + lm + px) * 4 + kq;
+#pragma unroll 1
+    for (int rp = 0; rp < WTH / 2; ++rp) {             // two rows at a time (two accumulator chains)
+      const float* b0 = base + (2 * rp) * WIW * 4;
+      v4f acc0 = b4, acc1 = b4;
+      float f0[2][8], f1[2][8];
+      auto frags = [&](int buf, int g) {               // group g = (tap ts, half of the quads)
+        const int ts = g >> 1, tt = ts >> 1, ss = ts & 1, j0 = (g & 1) * 8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int off = (j0 + j) * WPLANE + (tt * WIW + ss) * 4;
+          f0[buf][j] = b0[off];
+          f1[buf][j] = b0[off + WIW * 4];
+        }
+      };
+      frags(0, 0);
+#pragma unroll
+      for (int g = 0; g < 8; ++g) {
+        if (g + 1 < 8) frags((g + 1) & 1, g + 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[g * 8 + j], f0[g & 1][j], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[g * 8 + j], f1[g & 1][j], acc1, 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      const int Y0 = 2 * (qy0 + 2 * rp) + py;
+      if (X < a.out_w) {
+        if (Y0 < a.out_h) {
+          *reinterpret_cast<float4*>(out_n + ((int64_t)Y0 * a.out_w + X) * a.out_cs) = make_float4(acc0[0], acc0[1], acc0[2], acc0[3]);
+          if constexpr (STATS) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              lsum[q * GNT + tid] += (double)acc0[q];
+              lsum[(4 + q) * GNT + tid] = fma((double)acc0[q], (double)acc0[q], lsum[(4 + q) * GNT + tid]);
+            }
+          }
+        }
+        if (Y0 + 2 < a.out_h) {
+          *reinterpret_cast<float4*>(out_n + ((int64_t)(Y0 + 2) * a.out_w + X) * a.out_cs) = make_float4(acc1[0], acc1[1], acc1[2], acc1[3]);
+          if constexpr (STATS) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              lsum[q * GNT + tid] += (double)acc1[q];
+              lsum[(4 + q) * GNT + tid] = fma((double)acc1[q], (double)acc1[q], lsum[(4 + q) * GNT + tid]);
+            }
+          }
+        }
+      }
+    }
+    if (tn < ntiles) commit(tile + (cur ^ 1) * WTILE);
+    __syncthreads();
+    cur ^= 1;
+  }
+  if constexpr (STATS) {
+    double s1[4], s2[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { s1[q] = lsum[q * GNT + tid]; s2[q] = lsum[(4 + q) * GNT + tid]; }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int off = 8; off > 0; off >>= 1) {
+        s1[q] += __shfl_xor(s1[q], off, 16);
+        s2[q] += __shfl_xor(s2[q], off, 16);
+      }
+    if (lm == 0) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { red[wave][0][4 * kq + q] = s1[q]; red[wave][1][4 * kq + q] = s2[q]; }
+    }
+    __syncthreads();
+    if (tid < 2 * WCO) {
+      const int sidx = tid / WCO, c = tid % WCO, w0 = (c / 16) * 4;
+      a.stat[(int64_t)blockIdx.x * 2 * WCO + tid] =
+          ((red[w0][sidx][c % 16] + red[w0 + 1][sidx][c % 16]) + red[w0 + 2][sidx][c % 16]) + red[w0 + 3][sidx][c % 16];
+    }
+  }
+}
+
+struct FlatWPackArgs { const float* w; float* dst; int64_t sa, sb; };
+__global__ void flat_t64_pack_kernel(FlatWPackArgs a) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;      // ((((cb*4 + ph)*4 + ts)*16 + j)*4 + kq)*16 + lm
+  if (i >= WCG * WCO * 16) return;
+  const int lm = i % 16, kq = (i / 16) % 4, j = (i / 64) % WNQ, ts = (i / (64 * WNQ)) % 4, ph = (i / (64 * WNQ * 4)) % 4,
+            cb = i / (64 * WNQ * 16);
+  const int c = 4 * j + kq, co = 16 * cb + lm;              // gathered channel, produced channel
+  const int ky = bp_t_ky(ph >> 1, TPAD, TS, TT, ts >> 1), kx = bp_t_ky(ph & 1, TPAD, TS, TT, ts & 1);
+  a.dst[i] = a.w[c * a.sa + co * a.sb + ky * TK + kx];
+}
+
+}  // namespace
+
+bool bp_flat_t64_ok(const ConvGeom& g) {
+  static const bool off = getenv("BP_NOFLAT") != nullptr || getenv("BP_NOFLATW") != nullptr;
+  return !off && g.gather_transposed && g.k == TK && g.stride == TS && g.pad == TPAD && g.cin_g == WCG && g.cout_g == WCO &&
+         g.nphase == 2;
+}
+
+int64_t bp_flat_t64_packed_floats() { return (int64_t)WCG * WCO * 16; }
+
+int bp_flat_t64_pack(const WeightMap& wm, const float* w_torch, float* packed, hipStream_t st) {
+  FlatWPackArgs a{w_torch, packed, wm.sa, wm.sb};
+  hipLaunchKernelGGL(flat_t64_pack_kernel, dim3((WCG * WCO * 16 + 255) / 256), dim3(256), 0, st, a);
+  BP_CHECK_LAUNCH();
+  return BP_OK;
+}
+
+static int flat_t64_tiles(const bp_view* out) {
+  return bp_ceil_div(bp_ceil_div(out->w, 2), WTW) * bp_ceil_div(bp_ceil_div(out->h, 2), WTH) * out->n;
+}
+
+size_t bp_flat_t64_stats_workspace(const bp_view* out) {
+  return (size_t)flat_g4_grid(flat_t64_tiles(out)) * 2 * WCO * sizeof(double);
+}
+
+int bp_flat_t64_run(const bp_view* in, const PW& pw, const float* packed, const float* bias, const bp_view* out,
+                    hipStream_t st, const IgemmStatsReq* sr) {
+  if ((sr && (bias || sr->mode != 1)) || !bp_view_vec4(out)) return BP_EUNSUPPORTED;
+  FlatWArgs a{};
+  a.bias = bias;
+  a.in = in->ptr; a.in_h = in->h; a.in_w = in->w; a.in_cs = in->cstride; a.in_co = in->coff;
+  a.out = out->ptr; a.out_h = out->h; a.out_w = out->w; a.out_cs = out->cstride; a.out_co = out->coff;
+  a.wp = packed; a.pw = pw; a.n = in->n; a.in_vec = bp_view_vec4(in) ? 1 : 0;
+  a.tiles_x = bp_ceil_div(bp_ceil_div(out->w, 2), WTW); a.tiles_y = bp_ceil_div(bp_ceil_div(out->h, 2), WTH);
+  const int64_t ntiles = (int64_t)a.tiles_x * a.tiles_y * a.n;
+  if (ntiles > 0x7fffffff) return BP_EUNSUPPORTED;
+  const int grid = flat_g4_grid((int)ntiles);
+  if (sr) {
+    if (!sr->ws || sr->ws_bytes < bp_flat_t64_stats_workspace(out) || !sr->sums) return BP_EWORKSPACE;
+    a.stat = reinterpret_cast<double*>(sr->ws);
+  }
+  if (sr) hipLaunchKernelGGL(flat_t64_kernel<true>, dim3(grid), dim3(GNT), 0, st, a);
+  else hipLaunchKernelGGL(flat_t64_kernel<false>, dim3(grid), dim3(GNT), 0, st, a);
+  BP_CHECK_LAUNCH();
+  if (sr) return bp_sum_partials(a.stat, grid, 2 * WCO, sr->sums, st);
+  return BP_OK;
+}

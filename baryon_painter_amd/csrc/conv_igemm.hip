@@ -1472,11 +1472,20 @@ size_t bp_flat_g4_stats_workspace(const bp_view* out);
 int bp_flat_g4_run(const bp_view* in, const PW& pw, const float* packed, const float* bias, const bp_view* out,
                    hipStream_t st, const IgemmStatsReq* sr);
 
+// ... and the stride-2 k4 transposed form 64 -> 32 (eight waves: four phases x two blocks of 16 produced channels)
+bool bp_flat_t64_ok(const ConvGeom& g);
+int64_t bp_flat_t64_packed_floats();
+int bp_flat_t64_pack(const WeightMap& wm, const float* w_torch, float* packed, hipStream_t st);
+size_t bp_flat_t64_stats_workspace(const bp_view* out);
+int bp_flat_t64_run(const bp_view* in, const PW& pw, const float* packed, const float* bias, const bp_view* out,
+                    hipStream_t st, const IgemmStatsReq* sr);
+
 int bp_igemm_kernel_id(const ConvGeom& g) {
   if (bp_stem_ok(g)) return 700000;
   if (bp_flat_ok(g)) return 710000;
   if (bp_flat_t4_ok(g)) return 720000;
   if (bp_flat_g4_ok(g)) return 730000;
+  if (bp_flat_t64_ok(g)) return 740000;
   if (bp_small_ok(g)) return bp_small_kernel_id(g);
   const IgemmConfig c = igemm_config(g);
   if (c.ok && c.wres) return 400000 + c.CC * 1000 + c.NT * 100 + (c.w_NW / 4) * 10 + 2;
@@ -1488,6 +1497,7 @@ int64_t bp_igemm_packed_floats(const ConvGeom& g) {
   if (bp_flat_ok(g)) return bp_flat_packed_floats();
   if (bp_flat_t4_ok(g)) return bp_flat_t4_packed_floats();
   if (bp_flat_g4_ok(g)) return bp_flat_g4_packed_floats();
+  if (bp_flat_t64_ok(g)) return bp_flat_t64_packed_floats();
   if (bp_small_ok(g)) return bp_small_packed_floats(g);
   const IgemmConfig c = igemm_config(g);
   if (!c.ok) return -1;
@@ -1512,6 +1522,7 @@ int bp_igemm_pack(const ConvGeom& g, const WeightMap& wm, const float* w_torch, 
   if (bp_flat_ok(g)) return bp_flat_pack(g, wm, w_torch, packed, st);
   if (bp_flat_t4_ok(g)) return bp_flat_t4_pack(wm, w_torch, packed, st);
   if (bp_flat_g4_ok(g)) return bp_flat_g4_pack(wm, w_torch, packed, st);
+  if (bp_flat_t64_ok(g)) return bp_flat_t64_pack(wm, w_torch, packed, st);
   if (bp_small_ok(g)) return bp_small_pack(g, wm, w_torch, packed, st);
   PackArgs a;
   if (!igemm_pack_args(g, wm, w_torch, packed, a)) return BP_EUNSUPPORTED;
@@ -1525,7 +1536,7 @@ size_t bp_igemm_pack_job_bytes() { return sizeof(PackArgs); }
 
 int bp_igemm_pack_job(const ConvGeom& g, const WeightMap& wm, const float* w_torch, float* packed, void* job,
                       int64_t* nblocks) {
-  if (bp_stem_ok(g) || bp_flat_ok(g) || bp_flat_t4_ok(g) || bp_flat_g4_ok(g) || bp_small_ok(g)) return BP_EUNSUPPORTED;       // (their own tiny pack kernels: packed by bp_conv_pack)
+  if (bp_stem_ok(g) || bp_flat_ok(g) || bp_flat_t4_ok(g) || bp_flat_g4_ok(g) || bp_flat_t64_ok(g) || bp_small_ok(g)) return BP_EUNSUPPORTED;       // (their own tiny pack kernels: packed by bp_conv_pack)
   PackArgs a;
   if (!igemm_pack_args(g, wm, w_torch, packed, a)) return BP_EUNSUPPORTED;
   *reinterpret_cast<PackArgs*>(job) = a;
@@ -1623,6 +1634,7 @@ size_t bp_igemm_stats_workspace(const ConvGeom& g, const bp_view* in, const bp_v
   if (bp_flat_ok(g)) return 0;
   if (bp_flat_t4_ok(g)) return mode == 1 ? bp_flat_t4_stats_workspace(out) : 0;
   if (bp_flat_g4_ok(g)) return mode == 1 ? bp_flat_g4_stats_workspace(out) : 0;
+  if (bp_flat_t64_ok(g)) return mode == 1 ? bp_flat_t64_stats_workspace(out) : 0;
   if (bp_small_ok(g)) return 0;
   const IgemmConfig c = igemm_config(g);
   IgemmLaunch l;
@@ -1638,6 +1650,7 @@ int bp_igemm_run(const ConvGeom& g, const bp_view* in, const PW& pw, const float
   if (bp_flat_ok(g)) return sr ? BP_EUNSUPPORTED : bp_flat_run(g, in, pw, packed, bias, out, st);
   if (bp_flat_t4_ok(g)) return bp_flat_t4_run(in, pw, packed, bias, out, st, sr);
   if (bp_flat_g4_ok(g)) return bp_flat_g4_run(in, pw, packed, bias, out, st, sr);
+  if (bp_flat_t64_ok(g)) return bp_flat_t64_run(in, pw, packed, bias, out, st, sr);
   if (bp_small_ok(g)) return sr ? BP_EUNSUPPORTED : bp_small_run(g, in, pw, packed, bias, out, st);
   const IgemmConfig c = igemm_config(g);
   if (!c.ok) return BP_EUNSUPPORTED;

@@ -39,6 +39,7 @@ CASES = [
     (1, 32, 16, 4, 2, 1, (3, 9, 11)),          # conv_flat.hip transposed 32 -> 16: sums kept per lane over the tiles
     (1, 32, 16, 4, 2, 1, (24, 40, 80)),
     (0, 32, 64, 4, 2, 1, (40, 64, 96)),        # conv_flat.hip stride-2 gather 32 -> 64: sums kept per lane in LDS
+    (1, 64, 32, 4, 2, 1, (11, 40, 70)),        # ... and the transposed form 64 -> 32 (four phases x two channel blocks)
     (0, 3, 16, 5, 1, 2, (40, 130, 200)),      # ... with more tiles than workgroups (grid-stride walk)
 ]
 
