@@ -207,6 +207,7 @@ template <bool STATS>
 __global__ __launch_bounds__(256, 2) void flat_t4_kernel(FlatTArgs a) {
   __shared__ __attribute__((aligned(16))) float tile[TNQ * TPLANE];
   __shared__ double red[4][2][TCO];
+  __shared__ double lsum[STATS ? 8 * 256 : 1];       // per-lane running sums (registers are full of weights)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lm = lane & 15, kq = lane >> 4;
@@ -222,7 +223,14 @@ __global__ __launch_bounds__(256, 2) void flat_t4_kernel(FlatTArgs a) {
   v4f b4 = {0.f, 0.f, 0.f, 0.f};
   if (a.bias) b4 = v4f{a.bias[4 * kq], a.bias[4 * kq + 1], a.bias[4 * kq + 2], a.bias[4 * kq + 3]};
   const int q8 = tid % TNQ;
-  const PW4 p4 = pw4_load(a.pw, q8 * 4, TCG);
+  __shared__ float lpw[3][TCG];                     // pending activation of the gathered channels (read at commit time)
+  if (tid < TCG) {
+    const bool on = a.pw.scale != nullptr;
+    lpw[0][tid] = on ? a.pw.scale[tid] : 1.f;
+    lpw[1][tid] = on ? a.pw.shift[tid] : 0.f;
+    lpw[2][tid] = on ? a.pw.slope[tid] : 1.f;
+  }
+  __syncthreads();
   const int per_img = a.tiles_x * a.tiles_y;
   const int ntiles = per_img * a.n;
   float4 stage[TSL];
@@ -246,6 +254,10 @@ __global__ __launch_bounds__(256, 2) void flat_t4_kernel(FlatTArgs a) {
     inside = in;
   };
   auto commit = [&]() {
+    PW4 p4;
+    p4.on = true;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { p4.sc[j] = lpw[0][q8 * 4 + j]; p4.sf[j] = lpw[1][q8 * 4 + j]; p4.sl[j] = lpw[2][q8 * 4 + j]; }
 #pragma unroll
     for (int i = 0; i < TSL; ++i) {
       const int e = tid + i * 256;
@@ -258,7 +270,10 @@ __global__ __launch_bounds__(256, 2) void flat_t4_kernel(FlatTArgs a) {
     }
   };
 
-  double s1[STATS ? 4 : 1] = {}, s2[STATS ? 4 : 1] = {};
+  if constexpr (STATS) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) lsum[q * 256 + tid] = 0.0;
+  }
   int t = blockIdx.x;
   if (t < ntiles) { fetch(t); commit(); }
   __syncthreads();
@@ -290,7 +305,10 @@ __global__ __launch_bounds__(256, 2) void flat_t4_kernel(FlatTArgs a) {
             *reinterpret_cast<float4*>(o) = make_float4(acc[0], acc[1], acc[2], acc[3]);
             if constexpr (STATS) {
 #pragma unroll
-              for (int q = 0; q < 4; ++q) { s1[q] += (double)acc[q]; s2[q] = fma((double)acc[q], (double)acc[q], s2[q]); }
+              for (int q = 0; q < 4; ++q) {
+                lsum[q * 256 + tid] += (double)acc[q];
+                lsum[(4 + q) * 256 + tid] = fma((double)acc[q], (double)acc[q], lsum[(4 + q) * 256 + tid]);
+              }
             }
           }
         }
@@ -301,6 +319,9 @@ __global__ __launch_bounds__(256, 2) void flat_t4_kernel(FlatTArgs a) {
     __syncthreads();
   }
   if constexpr (STATS) {
+    double s1[4], s2[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { s1[q] = lsum[q * 256 + tid]; s2[q] = lsum[(4 + q) * 256 + tid]; }
 #pragma unroll
     for (int q = 0; q < 4; ++q)
 #pragma unroll
@@ -636,15 +657,9 @@ int bp_flat_g4_run(const bp_view* in, const PW& pw, const float* packed, const f
 // fragments read one tap ahead, batch-norm sums per lane in LDS -- as in flat_g4_kernel.
 namespace {
 
-constexpr int WCG = 64, WCO = 32;
-constexpr int WNQ = WCG / 4;                          // 16 quad planes
 constexpr int WTH = 8, WTW = 16;                      // phase-grid tile
 constexpr int WIH = WTH + 2, WIW = WTW + 2;           // gathered rows / columns (10 x 18)
 constexpr int WPLANE = WIH * WIW * 4;
-constexpr int WTILE = WNQ * WPLANE;                   // floats of a tile (11520)
-constexpr int WNU = WIH * WIW * WNQ;                  // float4 units (2880)
-constexpr int WSL = (WNU + GNT - 1) / GNT;            // per thread (6)
-constexpr int WNW = 4 * WNQ;                          // weight fragments of a wave (64)
 
 struct FlatWArgs {
   const float* in; int in_h, in_w, in_cs, in_co;
@@ -656,15 +671,26 @@ struct FlatWArgs {
   double* stat;               // partial sums [workgroup][2][32] or nullptr
 };
 
-template <bool STATS>
+// WCG gathered -> WCO produced channels: 64 -> 32 (two channel blocks x four phases) or 32 -> 16 (one channel block:
+// the second group of four waves takes the lower half of the tile's rows)
+template <int WCG, int WCO, bool STATS>
 __global__ __launch_bounds__(GNT) void flat_t64_kernel(FlatWArgs a) {
+  constexpr int WNQ = WCG / 4;                          // quad planes
+  constexpr int WTILE = WNQ * WPLANE;                   // floats of a tile
+  constexpr int WNU = WIH * WIW * WNQ;                  // float4 units
+  constexpr int WSL = (WNU + GNT - 1) / GNT;            // per thread
+  constexpr int WNW = 4 * WNQ;                          // weight fragments of a wave
+  constexpr int NCB = WCO / 16;                         // blocks of 16 produced channels (1 or 2)
+  constexpr int NRP = WTH / 2 / (2 / NCB);              // row pairs a wave walks
+  constexpr int QG = WNQ / 8;                           // fragment groups per tap
   __shared__ __attribute__((aligned(16))) float tile[2 * WTILE];
   __shared__ double red[STATS ? 8 : 1][2][16];
   __shared__ double lsum[STATS ? 8 * GNT : 1];
   __shared__ float lpw[3][WCG];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int ph = wave & 3, cb = wave >> 2;            // output phase, block of 16 produced channels
+  const int ph = wave & 3, cb = NCB == 2 ? wave >> 2 : 0;   // output phase, block of 16 produced channels
+  const int rp0 = NCB == 2 ? 0 : (wave >> 2) * NRP;         // first row pair of this wave
   const int py = ph >> 1, px = ph & 1;
   const int lm = lane & 15, kq = lane >> 4;
 
@@ -738,12 +764,12 @@ __global__ __launch_bounds__(GNT) void flat_t64_kernel(FlatWArgs a) {
     // staged row of tap t: row + py + t, column: lm + px + s
     const float* base = tile + cur * WTILE + ((py * WIW) + lm + px) * 4 + kq;
 #pragma unroll 1
-    for (int rp = 0; rp < WTH / 2; ++rp) {             // two rows at a time (two accumulator chains)
+    for (int rp = rp0; rp < rp0 + NRP; ++rp) {         // two rows at a time (two accumulator chains)
       const float* b0 = base + (2 * rp) * WIW * 4;
       v4f acc0 = b4, acc1 = b4;
       float f0[2][8], f1[2][8];
       auto frags = [&](int buf, int g) {               // group g = (tap ts, half of the quads)
-        const int ts = g >> 1, tt = ts >> 1, ss = ts & 1, j0 = (g & 1) * 8;
+        const int ts = g / QG, tt = ts >> 1, ss = ts & 1, j0 = (g % QG) * 8;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           const int off = (j0 + j) * WPLANE + (tt * WIW + ss) * 4;
@@ -753,8 +779,8 @@ __global__ __launch_bounds__(GNT) void flat_t64_kernel(FlatWArgs a) {
       };
       frags(0, 0);
 #pragma unroll
-      for (int g = 0; g < 8; ++g) {
-        if (g + 1 < 8) frags((g + 1) & 1, g + 1);
+      for (int g = 0; g < 4 * QG; ++g) {
+        if (g + 1 < 4 * QG) frags((g + 1) & 1, g + 1);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -808,17 +834,20 @@ __global__ __launch_bounds__(GNT) void flat_t64_kernel(FlatWArgs a) {
     }
     __syncthreads();
     if (tid < 2 * WCO) {
-      const int sidx = tid / WCO, c = tid % WCO, w0 = (c / 16) * 4;
-      a.stat[(int64_t)blockIdx.x * 2 * WCO + tid] =
-          ((red[w0][sidx][c % 16] + red[w0 + 1][sidx][c % 16]) + red[w0 + 2][sidx][c % 16]) + red[w0 + 3][sidx][c % 16];
+      const int sidx = tid / WCO, c = tid % WCO, w0 = NCB == 2 ? (c / 16) * 4 : 0;
+      double v = ((red[w0][sidx][c % 16] + red[w0 + 1][sidx][c % 16]) + red[w0 + 2][sidx][c % 16]) + red[w0 + 3][sidx][c % 16];
+      if (NCB == 1)
+        v += ((red[4][sidx][c % 16] + red[5][sidx][c % 16]) + red[6][sidx][c % 16]) + red[7][sidx][c % 16];
+      a.stat[(int64_t)blockIdx.x * 2 * WCO + tid] = v;
     }
   }
 }
 
-struct FlatWPackArgs { const float* w; float* dst; int64_t sa, sb; };
+struct FlatWPackArgs { const float* w; float* dst; int64_t sa, sb; int cg, co; };
 __global__ void flat_t64_pack_kernel(FlatWPackArgs a) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;      // ((((cb*4 + ph)*4 + ts)*16 + j)*4 + kq)*16 + lm
-  if (i >= WCG * WCO * 16) return;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;      // ((((cb*4 + ph)*4 + ts)*WNQ + j)*4 + kq)*16 + lm
+  if (i >= a.cg * a.co * 16) return;
+  const int WNQ = a.cg / 4;
   const int lm = i % 16, kq = (i / 16) % 4, j = (i / 64) % WNQ, ts = (i / (64 * WNQ)) % 4, ph = (i / (64 * WNQ * 4)) % 4,
             cb = i / (64 * WNQ * 16);
   const int c = 4 * j + kq, co = 16 * cb + lm;              // gathered channel, produced channel
@@ -828,17 +857,20 @@ __global__ void flat_t64_pack_kernel(FlatWPackArgs a) {
 
 }  // namespace
 
+static bool flat_t64_wide(const ConvGeom& g) { return g.cin_g == 64; }
+
 bool bp_flat_t64_ok(const ConvGeom& g) {
   static const bool off = getenv("BP_NOFLAT") != nullptr || getenv("BP_NOFLATW") != nullptr;
-  return !off && g.gather_transposed && g.k == TK && g.stride == TS && g.pad == TPAD && g.cin_g == WCG && g.cout_g == WCO &&
-         g.nphase == 2;
+  static const bool thin = getenv("BP_FLATW_THIN") != nullptr;       // (32 -> 16 through this kernel instead of flat_t4)
+  return !off && g.gather_transposed && g.k == TK && g.stride == TS && g.pad == TPAD && g.nphase == 2 &&
+         ((g.cin_g == 64 && g.cout_g == 32) || (thin && g.cin_g == 32 && g.cout_g == 16));
 }
 
-int64_t bp_flat_t64_packed_floats() { return (int64_t)WCG * WCO * 16; }
+int64_t bp_flat_t64_packed_floats(const ConvGeom& g) { return (int64_t)g.cin_g * g.cout_g * 16; }
 
-int bp_flat_t64_pack(const WeightMap& wm, const float* w_torch, float* packed, hipStream_t st) {
-  FlatWPackArgs a{w_torch, packed, wm.sa, wm.sb};
-  hipLaunchKernelGGL(flat_t64_pack_kernel, dim3((WCG * WCO * 16 + 255) / 256), dim3(256), 0, st, a);
+int bp_flat_t64_pack(const ConvGeom& g, const WeightMap& wm, const float* w_torch, float* packed, hipStream_t st) {
+  FlatWPackArgs a{w_torch, packed, wm.sa, wm.sb, g.cin_g, g.cout_g};
+  hipLaunchKernelGGL(flat_t64_pack_kernel, dim3((g.cin_g * g.cout_g * 16 + 255) / 256), dim3(256), 0, st, a);
   BP_CHECK_LAUNCH();
   return BP_OK;
 }
@@ -848,11 +880,11 @@ static int flat_t64_tiles(const bp_view* out) {
 }
 
 size_t bp_flat_t64_stats_workspace(const bp_view* out) {
-  return (size_t)flat_g4_grid(flat_t64_tiles(out)) * 2 * WCO * sizeof(double);
+  return (size_t)flat_g4_grid(flat_t64_tiles(out)) * 2 * out->c * sizeof(double);
 }
 
-int bp_flat_t64_run(const bp_view* in, const PW& pw, const float* packed, const float* bias, const bp_view* out,
-                    hipStream_t st, const IgemmStatsReq* sr) {
+int bp_flat_t64_run(const ConvGeom& g, const bp_view* in, const PW& pw, const float* packed, const float* bias,
+                    const bp_view* out, hipStream_t st, const IgemmStatsReq* sr) {
   if ((sr && (bias || sr->mode != 1)) || !bp_view_vec4(out)) return BP_EUNSUPPORTED;
   FlatWArgs a{};
   a.bias = bias;
@@ -867,9 +899,15 @@ int bp_flat_t64_run(const bp_view* in, const PW& pw, const float* packed, const 
     if (!sr->ws || sr->ws_bytes < bp_flat_t64_stats_workspace(out) || !sr->sums) return BP_EWORKSPACE;
     a.stat = reinterpret_cast<double*>(sr->ws);
   }
-  if (sr) hipLaunchKernelGGL(flat_t64_kernel<true>, dim3(grid), dim3(GNT), 0, st, a);
-  else hipLaunchKernelGGL(flat_t64_kernel<false>, dim3(grid), dim3(GNT), 0, st, a);
+  const dim3 gd(grid), bd(GNT);
+  if (flat_t64_wide(g)) {
+    if (sr) hipLaunchKernelGGL((flat_t64_kernel<64, 32, true>), gd, bd, 0, st, a);
+    else hipLaunchKernelGGL((flat_t64_kernel<64, 32, false>), gd, bd, 0, st, a);
+  } else {
+    if (sr) hipLaunchKernelGGL((flat_t64_kernel<32, 16, true>), gd, bd, 0, st, a);
+    else hipLaunchKernelGGL((flat_t64_kernel<32, 16, false>), gd, bd, 0, st, a);
+  }
   BP_CHECK_LAUNCH();
-  if (sr) return bp_sum_partials(a.stat, grid, 2 * WCO, sr->sums, st);
+  if (sr) return bp_sum_partials(a.stat, grid, 2 * g.cout_g, sr->sums, st);
   return BP_OK;
 }

@@ -1474,16 +1474,16 @@ int bp_flat_g4_run(const bp_view* in, const PW& pw, const float* packed, const f
 
 // ... and the stride-2 k4 transposed form 64 -> 32 (eight waves: four phases x two blocks of 16 produced channels)
 bool bp_flat_t64_ok(const ConvGeom& g);
-int64_t bp_flat_t64_packed_floats();
-int bp_flat_t64_pack(const WeightMap& wm, const float* w_torch, float* packed, hipStream_t st);
+int64_t bp_flat_t64_packed_floats(const ConvGeom& g);
+int bp_flat_t64_pack(const ConvGeom& g, const WeightMap& wm, const float* w_torch, float* packed, hipStream_t st);
 size_t bp_flat_t64_stats_workspace(const bp_view* out);
-int bp_flat_t64_run(const bp_view* in, const PW& pw, const float* packed, const float* bias, const bp_view* out,
-                    hipStream_t st, const IgemmStatsReq* sr);
+int bp_flat_t64_run(const ConvGeom& g, const bp_view* in, const PW& pw, const float* packed, const float* bias,
+                    const bp_view* out, hipStream_t st, const IgemmStatsReq* sr);
 
 int bp_igemm_kernel_id(const ConvGeom& g) {
   if (bp_stem_ok(g)) return 700000;
   if (bp_flat_ok(g)) return 710000;
-  if (bp_flat_t4_ok(g)) return 720000;
+  if (bp_flat_t4_ok(g) && !bp_flat_t64_ok(g)) return 720000;
   if (bp_flat_g4_ok(g)) return 730000;
   if (bp_flat_t64_ok(g)) return 740000;
   if (bp_small_ok(g)) return bp_small_kernel_id(g);
@@ -1495,9 +1495,9 @@ int bp_igemm_kernel_id(const ConvGeom& g) {
 int64_t bp_igemm_packed_floats(const ConvGeom& g) {
   if (bp_stem_ok(g)) return bp_stem_packed_floats();
   if (bp_flat_ok(g)) return bp_flat_packed_floats();
-  if (bp_flat_t4_ok(g)) return bp_flat_t4_packed_floats();
+  if (bp_flat_t4_ok(g) && !bp_flat_t64_ok(g)) return bp_flat_t4_packed_floats();
   if (bp_flat_g4_ok(g)) return bp_flat_g4_packed_floats();
-  if (bp_flat_t64_ok(g)) return bp_flat_t64_packed_floats();
+  if (bp_flat_t64_ok(g)) return bp_flat_t64_packed_floats(g);
   if (bp_small_ok(g)) return bp_small_packed_floats(g);
   const IgemmConfig c = igemm_config(g);
   if (!c.ok) return -1;
@@ -1520,9 +1520,9 @@ int bp_igemm_pack(const ConvGeom& g, const WeightMap& wm, const float* w_torch, 
                   hipStream_t st) {
   if (bp_stem_ok(g)) return bp_stem_pack(wm, w_torch, packed, st);
   if (bp_flat_ok(g)) return bp_flat_pack(g, wm, w_torch, packed, st);
-  if (bp_flat_t4_ok(g)) return bp_flat_t4_pack(wm, w_torch, packed, st);
+  if (bp_flat_t4_ok(g) && !bp_flat_t64_ok(g)) return bp_flat_t4_pack(wm, w_torch, packed, st);
   if (bp_flat_g4_ok(g)) return bp_flat_g4_pack(wm, w_torch, packed, st);
-  if (bp_flat_t64_ok(g)) return bp_flat_t64_pack(wm, w_torch, packed, st);
+  if (bp_flat_t64_ok(g)) return bp_flat_t64_pack(g, wm, w_torch, packed, st);
   if (bp_small_ok(g)) return bp_small_pack(g, wm, w_torch, packed, st);
   PackArgs a;
   if (!igemm_pack_args(g, wm, w_torch, packed, a)) return BP_EUNSUPPORTED;
@@ -1632,7 +1632,7 @@ int bp_stats_rows_finish(double* ws, int64_t rows, int C, double* sums, hipStrea
 size_t bp_igemm_stats_workspace(const ConvGeom& g, const bp_view* in, const bp_view* out, int mode) {
   if (bp_stem_ok(g)) return mode == 1 ? bp_stem_stats_workspace(out) : 0;
   if (bp_flat_ok(g)) return 0;
-  if (bp_flat_t4_ok(g)) return mode == 1 ? bp_flat_t4_stats_workspace(out) : 0;
+  if (bp_flat_t4_ok(g) && !bp_flat_t64_ok(g)) return mode == 1 ? bp_flat_t4_stats_workspace(out) : 0;
   if (bp_flat_g4_ok(g)) return mode == 1 ? bp_flat_g4_stats_workspace(out) : 0;
   if (bp_flat_t64_ok(g)) return mode == 1 ? bp_flat_t64_stats_workspace(out) : 0;
   if (bp_small_ok(g)) return 0;
@@ -1648,9 +1648,9 @@ int bp_igemm_run(const ConvGeom& g, const bp_view* in, const PW& pw, const float
                  const float* bias, const bp_view* out, hipStream_t st, const IgemmStatsReq* sr) {
   if (bp_stem_ok(g)) return bp_stem_run(in, pw, packed, bias, out, st, sr);
   if (bp_flat_ok(g)) return sr ? BP_EUNSUPPORTED : bp_flat_run(g, in, pw, packed, bias, out, st);
-  if (bp_flat_t4_ok(g)) return bp_flat_t4_run(in, pw, packed, bias, out, st, sr);
+  if (bp_flat_t4_ok(g) && !bp_flat_t64_ok(g)) return bp_flat_t4_run(in, pw, packed, bias, out, st, sr);
   if (bp_flat_g4_ok(g)) return bp_flat_g4_run(in, pw, packed, bias, out, st, sr);
-  if (bp_flat_t64_ok(g)) return bp_flat_t64_run(in, pw, packed, bias, out, st, sr);
+  if (bp_flat_t64_ok(g)) return bp_flat_t64_run(g, in, pw, packed, bias, out, st, sr);
   if (bp_small_ok(g)) return sr ? BP_EUNSUPPORTED : bp_small_run(g, in, pw, packed, bias, out, st);
   const IgemmConfig c = igemm_config(g);
   if (!c.ok) return BP_EUNSUPPORTED;
