@@ -411,17 +411,11 @@ int bp_flat_t4_run(const bp_view* in, const PW& pw, const float* packed, const f
 // mode 1) are kept per lane in double over all the tiles of the workgroup.
 namespace {
 
-constexpr int GK = 4, GS = 2, GPAD = 1, GCG = 32, GCO = 64;
-constexpr int GNQ = GCG / 4;                          // 8 quad planes
-constexpr int GTH = 4, GTW = 16;                      // output tile of a workgroup
-constexpr int GIH = GS * GTH + 2, GIW = GS * GTW + 2; // gathered rows / columns of a tile (10 x 34)
+constexpr int GK = 4, GS = 2, GPAD = 1;
+constexpr int GTW = 16;                               // output columns of a tile
+constexpr int GIW = GS * GTW + 2;                     // gathered columns of a tile (34)
 constexpr int GHALF = GIW / 2;                        // columns of one parity (17)
-constexpr int GPLANE = GIH * GIW * 4;                 // floats of a quad plane
-constexpr int GTILE = GNQ * GPLANE;                   // floats of a tile (10880)
-constexpr int GNU = GIH * GIW * GNQ;                  // float4 units (2720)
 constexpr int GNT = 512;                              // threads
-constexpr int GSL = (GNU + GNT - 1) / GNT;            // units per thread (6)
-constexpr int GNW = GK * GK * GNQ;                    // weight fragments of a wave (128)
 
 struct FlatGArgs {
   const float* in; int in_h, in_w, in_cs, in_co;
@@ -433,15 +427,26 @@ struct FlatGArgs {
   double* stat;               // partial sums [workgroup][2][64] or nullptr
 };
 
-template <bool STATS>
+// GCG gathered -> GCO produced channels: 32 -> 64 (four channel blocks x two row pairs, tile 4 x 16) or 16 -> 32 (two
+// channel blocks x four row pairs, tile 8 x 16)
+template <int GCG, int GCO, bool STATS>
 __global__ __launch_bounds__(GNT) void flat_g4_kernel(FlatGArgs a) {
+  constexpr int GNQ = GCG / 4;                          // quad planes
+  constexpr int NCB = GCO / 16;                         // blocks of 16 produced channels (4 or 2)
+  constexpr int GTH = 2 * (8 / NCB);                    // output rows of a tile (4 or 8)
+  constexpr int GIH = GS * GTH + 2;                     // gathered rows of a tile (10 or 18)
+  constexpr int GPLANE = GIH * GIW * 4;                 // floats of a quad plane
+  constexpr int GTILE = GNQ * GPLANE;                   // floats of a tile
+  constexpr int GNU = GIH * GIW * GNQ;                  // float4 units
+  constexpr int GSL = (GNU + GNT - 1) / GNT;            // units per thread
+  constexpr int GNW = GK * GK * GNQ;                    // weight fragments of a wave (128 or 64)
   __shared__ __attribute__((aligned(16))) float tile[2 * GTILE];
   __shared__ double red[STATS ? 8 : 1][2][16];
   __shared__ float lpw[3][GCG];                     // pending activation of the gathered channels (read at commit time)
   __shared__ double lsum[STATS ? 8 * GNT : 1];   // per-lane running sums {sum, sum of squares} x 4 channels (not registers)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int cb = wave & 3, rh = wave >> 2;            // block of 16 produced channels, row pair of the tile
+  const int cb = wave % NCB, rh = wave / NCB;         // block of 16 produced channels, row pair of the tile
   const int lm = lane & 15, kq = lane >> 4;
 
   float wreg[GNW];
@@ -511,26 +516,26 @@ __global__ __launch_bounds__(GNT) void flat_g4_kernel(FlatGArgs a) {
     // rows 2 rh and 2 rh + 1 of the tile: gathered rows 2 row + ky, column 2 lm + kx -> parity kx & 1, half lm + (kx >> 1)
     const float* base = tile + cur * GTILE + ((4 * rh) * 2 * GHALF + lm) * 4 + kq;
     v4f acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-    // one tap (8 K-groups, both rows) per stage; the fragments of the next tap are read before the MFMAs of this one
-    float f0[2][GNQ], f1[2][GNQ];
-    auto frags = [&](int buf, int tap) {
-      const int ky = tap / GK, kx = tap % GK;
+    // eight K-groups (both rows) per stage; the fragments of the next stage are read before the MFMAs of this one
+    float f0[2][8], f1[2][8];
+    auto frags = [&](int buf, int g) {
 #pragma unroll
-      for (int j = 0; j < GNQ; ++j) {
+      for (int i = 0; i < 8; ++i) {
+        const int k = g * 8 + i, tap = k / GNQ, j = k % GNQ, ky = tap / GK, kx = tap % GK;
         const int off = j * GPLANE + ((ky * 2 + (kx & 1)) * GHALF + (kx >> 1)) * 4;
-        f0[buf][j] = base[off];
-        f1[buf][j] = base[off + 2 * 2 * GHALF * 4];
+        f0[buf][i] = base[off];
+        f1[buf][i] = base[off + 2 * 2 * GHALF * 4];
       }
     };
     frags(0, 0);
 #pragma unroll
-    for (int tap = 0; tap < GK * GK; ++tap) {
-      if (tap + 1 < GK * GK) frags((tap + 1) & 1, tap + 1);
+    for (int g = 0; g < GNW / 8; ++g) {
+      if (g + 1 < GNW / 8) frags((g + 1) & 1, g + 1);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int j = 0; j < GNQ; ++j) {
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[tap * GNQ + j], f0[tap & 1][j], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[tap * GNQ + j], f1[tap & 1][j], acc1, 0, 0, 0);
+      for (int i = 0; i < 8; ++i) {
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[g * 8 + i], f0[g & 1][i], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[g * 8 + i], f1[g & 1][i], acc1, 0, 0, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -583,15 +588,19 @@ __global__ __launch_bounds__(GNT) void flat_g4_kernel(FlatGArgs a) {
     __syncthreads();
     if (tid < 2 * GCO) {
       const int sidx = tid / GCO, c = tid % GCO;
-      a.stat[(int64_t)blockIdx.x * 2 * GCO + tid] = red[c / 16][sidx][c % 16] + red[4 + c / 16][sidx][c % 16];
+      double v = red[c / 16][sidx][c % 16];
+#pragma unroll
+      for (int r2 = 1; r2 < 8 / NCB; ++r2) v += red[r2 * NCB + c / 16][sidx][c % 16];
+      a.stat[(int64_t)blockIdx.x * 2 * GCO + tid] = v;
     }
   }
 }
 
-struct FlatGPackArgs { const float* w; float* dst; int64_t sa, sb; };
+struct FlatGPackArgs { const float* w; float* dst; int64_t sa, sb; int cg, co; };
 __global__ void flat_g4_pack_kernel(FlatGPackArgs a) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;      // (((cb*16 + tap)*8 + j)*4 + kq)*16 + lm
-  if (i >= GCG * GCO * GK * GK) return;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;      // (((cb*16 + tap)*GNQ + j)*4 + kq)*16 + lm
+  if (i >= a.cg * a.co * GK * GK) return;
+  const int GNQ = a.cg / 4;
   const int lm = i % 16, kq = (i / 16) % 4, j = (i / 64) % GNQ, tap = (i / (64 * GNQ)) % (GK * GK), cb = i / (64 * GNQ * GK * GK);
   const int c = 4 * j + kq, co = 16 * cb + lm;              // gathered channel, produced channel
   a.dst[i] = a.w[c * a.sa + co * a.sb + tap];
@@ -606,34 +615,38 @@ int flat_g4_grid(int ntiles) {
 
 bool bp_flat_g4_ok(const ConvGeom& g) {
   static const bool off = getenv("BP_NOFLAT") != nullptr || getenv("BP_NOFLATG") != nullptr;
-  return !off && !g.gather_transposed && g.k == GK && g.stride == GS && g.pad == GPAD && g.cin_g == GCG && g.cout_g == GCO &&
-         g.nphase == 1 && g.IS == GS;
+  static const bool thin = getenv("BP_FLATG_THIN") != nullptr;     // (16 -> 32: no faster than the weights-resident igemm)
+  return !off && !g.gather_transposed && g.k == GK && g.stride == GS && g.pad == GPAD && g.nphase == 1 && g.IS == GS &&
+         ((g.cin_g == 32 && g.cout_g == 64) || (thin && g.cin_g == 16 && g.cout_g == 32));
 }
 
-int64_t bp_flat_g4_packed_floats() { return (int64_t)GCG * GCO * GK * GK; }
+int64_t bp_flat_g4_packed_floats(const ConvGeom& g) { return (int64_t)g.cin_g * g.cout_g * GK * GK; }
 
-int bp_flat_g4_pack(const WeightMap& wm, const float* w_torch, float* packed, hipStream_t st) {
-  FlatGPackArgs a{w_torch, packed, wm.sa, wm.sb};
-  hipLaunchKernelGGL(flat_g4_pack_kernel, dim3((GCG * GCO * GK * GK + 255) / 256), dim3(256), 0, st, a);
+int bp_flat_g4_pack(const ConvGeom& g, const WeightMap& wm, const float* w_torch, float* packed, hipStream_t st) {
+  FlatGPackArgs a{w_torch, packed, wm.sa, wm.sb, g.cin_g, g.cout_g};
+  hipLaunchKernelGGL(flat_g4_pack_kernel, dim3((g.cin_g * g.cout_g * GK * GK + 255) / 256), dim3(256), 0, st, a);
   BP_CHECK_LAUNCH();
   return BP_OK;
 }
 
-static int flat_g4_tiles(const bp_view* out) { return bp_ceil_div(out->w, GTW) * bp_ceil_div(out->h, GTH) * out->n; }
-
-size_t bp_flat_g4_stats_workspace(const bp_view* out) {
-  return (size_t)flat_g4_grid(flat_g4_tiles(out)) * 2 * GCO * sizeof(double);
+static int flat_g4_th(const bp_view* out) { return out->c == 64 ? 4 : 8; }
+static int flat_g4_tiles(const bp_view* out) {
+  return bp_ceil_div(out->w, GTW) * bp_ceil_div(out->h, flat_g4_th(out)) * out->n;
 }
 
-int bp_flat_g4_run(const bp_view* in, const PW& pw, const float* packed, const float* bias, const bp_view* out,
-                   hipStream_t st, const IgemmStatsReq* sr) {
+size_t bp_flat_g4_stats_workspace(const bp_view* out) {
+  return (size_t)flat_g4_grid(flat_g4_tiles(out)) * 2 * out->c * sizeof(double);
+}
+
+int bp_flat_g4_run(const ConvGeom& g, const bp_view* in, const PW& pw, const float* packed, const float* bias,
+                   const bp_view* out, hipStream_t st, const IgemmStatsReq* sr) {
   if ((sr && (bias || sr->mode != 1)) || !bp_view_vec4(out)) return BP_EUNSUPPORTED;
   FlatGArgs a{};
   a.bias = bias;
   a.in = in->ptr; a.in_h = in->h; a.in_w = in->w; a.in_cs = in->cstride; a.in_co = in->coff;
   a.out = out->ptr; a.out_h = out->h; a.out_w = out->w; a.out_cs = out->cstride; a.out_co = out->coff;
   a.wp = packed; a.pw = pw; a.n = in->n; a.in_vec = bp_view_vec4(in) ? 1 : 0;
-  a.tiles_x = bp_ceil_div(out->w, GTW); a.tiles_y = bp_ceil_div(out->h, GTH);
+  a.tiles_x = bp_ceil_div(out->w, GTW); a.tiles_y = bp_ceil_div(out->h, flat_g4_th(out));
   const int64_t ntiles = (int64_t)a.tiles_x * a.tiles_y * a.n;
   if (ntiles > 0x7fffffff) return BP_EUNSUPPORTED;
   const int grid = flat_g4_grid((int)ntiles);
@@ -641,10 +654,16 @@ int bp_flat_g4_run(const bp_view* in, const PW& pw, const float* packed, const f
     if (!sr->ws || sr->ws_bytes < bp_flat_g4_stats_workspace(out) || !sr->sums) return BP_EWORKSPACE;
     a.stat = reinterpret_cast<double*>(sr->ws);
   }
-  if (sr) hipLaunchKernelGGL(flat_g4_kernel<true>, dim3(grid), dim3(GNT), 0, st, a);
-  else hipLaunchKernelGGL(flat_g4_kernel<false>, dim3(grid), dim3(GNT), 0, st, a);
+  const dim3 gd(grid), bd(GNT);
+  if (g.cin_g == 32) {
+    if (sr) hipLaunchKernelGGL((flat_g4_kernel<32, 64, true>), gd, bd, 0, st, a);
+    else hipLaunchKernelGGL((flat_g4_kernel<32, 64, false>), gd, bd, 0, st, a);
+  } else {
+    if (sr) hipLaunchKernelGGL((flat_g4_kernel<16, 32, true>), gd, bd, 0, st, a);
+    else hipLaunchKernelGGL((flat_g4_kernel<16, 32, false>), gd, bd, 0, st, a);
+  }
   BP_CHECK_LAUNCH();
-  if (sr) return bp_sum_partials(a.stat, grid, 2 * GCO, sr->sums, st);
+  if (sr) return bp_sum_partials(a.stat, grid, 2 * g.cout_g, sr->sums, st);
   return BP_OK;
 }
 

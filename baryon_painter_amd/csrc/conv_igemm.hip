@@ -1466,11 +1466,11 @@ int bp_flat_t4_run(const bp_view* in, const PW& pw, const float* packed, const f
                    hipStream_t st, const IgemmStatsReq* sr);
 // ... and the stride-2 k4 conv form 32 -> 64 (eight waves: four blocks of 16 produced channels, weights in registers)
 bool bp_flat_g4_ok(const ConvGeom& g);
-int64_t bp_flat_g4_packed_floats();
-int bp_flat_g4_pack(const WeightMap& wm, const float* w_torch, float* packed, hipStream_t st);
+int64_t bp_flat_g4_packed_floats(const ConvGeom& g);
+int bp_flat_g4_pack(const ConvGeom& g, const WeightMap& wm, const float* w_torch, float* packed, hipStream_t st);
 size_t bp_flat_g4_stats_workspace(const bp_view* out);
-int bp_flat_g4_run(const bp_view* in, const PW& pw, const float* packed, const float* bias, const bp_view* out,
-                   hipStream_t st, const IgemmStatsReq* sr);
+int bp_flat_g4_run(const ConvGeom& g, const bp_view* in, const PW& pw, const float* packed, const float* bias,
+                   const bp_view* out, hipStream_t st, const IgemmStatsReq* sr);
 
 // ... and the stride-2 k4 transposed form 64 -> 32 (eight waves: four phases x two blocks of 16 produced channels)
 bool bp_flat_t64_ok(const ConvGeom& g);
@@ -1496,7 +1496,7 @@ int64_t bp_igemm_packed_floats(const ConvGeom& g) {
   if (bp_stem_ok(g)) return bp_stem_packed_floats();
   if (bp_flat_ok(g)) return bp_flat_packed_floats();
   if (bp_flat_t4_ok(g) && !bp_flat_t64_ok(g)) return bp_flat_t4_packed_floats();
-  if (bp_flat_g4_ok(g)) return bp_flat_g4_packed_floats();
+  if (bp_flat_g4_ok(g)) return bp_flat_g4_packed_floats(g);
   if (bp_flat_t64_ok(g)) return bp_flat_t64_packed_floats(g);
   if (bp_small_ok(g)) return bp_small_packed_floats(g);
   const IgemmConfig c = igemm_config(g);
@@ -1521,7 +1521,7 @@ int bp_igemm_pack(const ConvGeom& g, const WeightMap& wm, const float* w_torch, 
   if (bp_stem_ok(g)) return bp_stem_pack(wm, w_torch, packed, st);
   if (bp_flat_ok(g)) return bp_flat_pack(g, wm, w_torch, packed, st);
   if (bp_flat_t4_ok(g) && !bp_flat_t64_ok(g)) return bp_flat_t4_pack(wm, w_torch, packed, st);
-  if (bp_flat_g4_ok(g)) return bp_flat_g4_pack(wm, w_torch, packed, st);
+  if (bp_flat_g4_ok(g)) return bp_flat_g4_pack(g, wm, w_torch, packed, st);
   if (bp_flat_t64_ok(g)) return bp_flat_t64_pack(g, wm, w_torch, packed, st);
   if (bp_small_ok(g)) return bp_small_pack(g, wm, w_torch, packed, st);
   PackArgs a;
@@ -1649,7 +1649,7 @@ int bp_igemm_run(const ConvGeom& g, const bp_view* in, const PW& pw, const float
   if (bp_stem_ok(g)) return bp_stem_run(in, pw, packed, bias, out, st, sr);
   if (bp_flat_ok(g)) return sr ? BP_EUNSUPPORTED : bp_flat_run(g, in, pw, packed, bias, out, st);
   if (bp_flat_t4_ok(g) && !bp_flat_t64_ok(g)) return bp_flat_t4_run(in, pw, packed, bias, out, st, sr);
-  if (bp_flat_g4_ok(g)) return bp_flat_g4_run(in, pw, packed, bias, out, st, sr);
+  if (bp_flat_g4_ok(g)) return bp_flat_g4_run(g, in, pw, packed, bias, out, st, sr);
   if (bp_flat_t64_ok(g)) return bp_flat_t64_run(g, in, pw, packed, bias, out, st, sr);
   if (bp_small_ok(g)) return sr ? BP_EUNSUPPORTED : bp_small_run(g, in, pw, packed, bias, out, st);
   const IgemmConfig c = igemm_config(g);
