@@ -930,3 +930,240 @@ int bp_flat_t64_run(const ConvGeom& g, const bp_view* in, const PW& pw, const fl
   if (sr) return bp_sum_partials(a.stat, grid, 2 * g.cout_g, sr->sums, st);
   return BP_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Unit-stride k7 gathering 16 channels into 8 (Conv2d 16 -> 8 k7 forward, the generator head's first layer, arch
+// p_y_z_out).  8 produced channels fill half an MFMA tile, so the 16 MFMA rows are (pixel offset d in {0, 1}) x 8
+// channels and the 16 columns are pixel PAIRS: row (d, co) of pair p is output pixel 2p + d, K walks a window of 8
+// columns x 16 channels per tap row (tap column tx = tx' - d; the two out-of-range taps are zero weights: 12.5 %
+// padding), 7 x 32 = 224 K-groups.  224 weight fragments do not fit one wave, so K is split over TWO waves (two of the
+// four channel quads = 112 fragments each) whose accumulators are added through LDS; eight waves = two K halves x four row pairs of an
+// 8 x 32 tile.  Gathered tile: four channel-quad planes, columns split by parity (pair p, column 2p + tx' -> parity
+// tx' & 1, half p + (tx' >> 1)): one 4-byte read per lane and MFMA, 256 contiguous bytes per wave.
+namespace {
+
+constexpr int HK = 7, HPAD = 3, HCG = 16, HCO = 8;
+constexpr int HNQ = HCG / 4;                          // 4 quad planes
+constexpr int HTH = 8, HTW = 32;                      // output tile
+constexpr int HIH = HTH + HK - 1;                     // gathered rows (14)
+constexpr int HIW = HTW + HK + 1;                     // gathered columns, even (40: 20 per parity; 38 are read)
+constexpr int HHALF = HIW / 2;
+constexpr int HPLANE = HIH * HIW * 4;
+constexpr int HTILE = HNQ * HPLANE;                   // floats of a tile (8960)
+constexpr int HNU = HIH * HIW * HNQ;                  // float4 units (2240)
+constexpr int HSL = (HNU + GNT - 1) / GNT;            // per thread (5)
+constexpr int HKS = HK * 8 * HNQ;                     // K-groups (224)
+constexpr int HNW = HKS / 2;                          // weight fragments of a wave (112)
+
+struct FlatHArgs {
+  const float* in; int h, w, in_cs, in_co;
+  float* out; int out_cs, out_co;
+  const float* wp;            // [K half][K-group][kq][(d, co)]
+  const float* bias;
+  PW pw;
+  int n, tiles_x, tiles_y, in_vec;
+};
+
+__global__ __launch_bounds__(GNT) void flat_h7_kernel(FlatHArgs a) {
+  __shared__ __attribute__((aligned(16))) float tile[2 * HTILE];
+  __shared__ __attribute__((aligned(16))) float xch[2 * 4 * 2 * 64 * 4];   // accumulators of the upper-K waves (two tiles deep)
+  __shared__ float lpw[3][HCG];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kh = wave >> 2, rg = wave & 3;            // K half, row pair of the tile (a SIMD hosts waves w and w + 4:
+                                                      // one of each half, so the epilogue of one overlaps MFMAs of the other)
+  const int lm = lane & 15, kq = lane >> 4;
+
+  float wreg[HNW];
+#pragma unroll
+  for (int i = 0; i < HNW; ++i) wreg[i] = a.wp[(((int64_t)kh * HNW + i) * 4 + kq) * 16 + lm];
+
+  const int q4 = tid % HNQ;
+  if (tid < HCG) {
+    const bool on = a.pw.scale != nullptr;
+    lpw[0][tid] = on ? a.pw.scale[tid] : 1.f;
+    lpw[1][tid] = on ? a.pw.shift[tid] : 0.f;
+    lpw[2][tid] = on ? a.pw.slope[tid] : 1.f;
+  }
+  __syncthreads();
+  const int per_img = a.tiles_x * a.tiles_y;
+  const int ntiles = per_img * a.n;
+  float4 stage[HSL];
+  unsigned inside = 0;
+  // Staging of the next tile, one unit at a time and branch-free, so that it can be issued between the MFMAs of the
+  // current tile (the eight waves run in lockstep from barrier to barrier: vector-ALU work outside the MFMA stream
+  // is not hidden by another wave): fetch_unit = clamped address + load + validity bit, finish_unit = activation and
+  // zero padding in registers, commit = the LDS stores.
+  int fy0 = 0, fx0 = 0;
+  const float* fin_n = nullptr;
+  auto tile_setup = [&](int t) {
+    const int n = t / per_img, r = t % per_img;
+    fy0 = (r / a.tiles_x) * HTH - HPAD; fx0 = (r % a.tiles_x) * HTW - HPAD;
+    fin_n = a.in + (int64_t)n * a.h * a.w * a.in_cs + a.in_co + q4 * 4;
+    inside = 0;
+  };
+  auto fetch_unit = [&](int i) {
+    if (i >= HSL) return;
+    const int e = tid + i * GNT;
+    const int pix = e / HNQ, col = pix % HIW, row = pix / HIW;
+    const int iy = fy0 + row, ix = fx0 + col;
+    inside |= ((unsigned)(e < HNU) & (unsigned)(iy >= 0) & (unsigned)(iy < a.h) & (unsigned)(ix >= 0) & (unsigned)(ix < a.w)) << i;
+    const int cy = min(max(iy, 0), a.h - 1), cx = min(max(ix, 0), a.w - 1);
+    const float* p = fin_n + (cy * a.w + cx) * a.in_cs;
+    stage[i] = *reinterpret_cast<const float4*>(p);
+  };
+  float psc[4], psf[4], psl[4];
+  auto finish_unit = [&](int i) {
+    if (i >= HSL) return;
+    const unsigned m = 0u - ((inside >> i) & 1u);
+    float v[4] = {stage[i].x, stage[i].y, stage[i].z, stage[i].w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float tt = fmaf(v[j], psc[j], psf[j]);
+      v[j] = __uint_as_float(__float_as_uint(tt > 0.f ? tt : tt * psl[j]) & m);
+    }
+    stage[i] = make_float4(v[0], v[1], v[2], v[3]);
+  };
+  auto commit = [&](float* buf) {
+#pragma unroll
+    for (int i = 0; i < HSL; ++i) {
+      const int e = tid + i * GNT;
+      if (e < HNU) {
+        const int pix = e / HNQ, col = pix % HIW, row = pix / HIW;
+        *reinterpret_cast<float4*>(buf + q4 * HPLANE + ((row * 2 + (col & 1)) * HHALF + (col >> 1)) * 4) = stage[i];
+      }
+    }
+  };
+  auto load_pw = [&]() {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { psc[j] = lpw[0][q4 * 4 + j]; psf[j] = lpw[1][q4 * 4 + j]; psl[j] = lpw[2][q4 * 4 + j]; }
+  };
+
+  int t = blockIdx.x, cur = 0;
+  if (t < ntiles) {
+    tile_setup(t);
+    load_pw();
+#pragma unroll
+    for (int i = 0; i < HSL; ++i) fetch_unit(i);
+#pragma unroll
+    for (int i = 0; i < HSL; ++i) finish_unit(i);
+    commit(tile);
+  }
+  __syncthreads();
+  for (; t < ntiles; t += gridDim.x) {
+    const int tn = t + gridDim.x;
+    tile_setup(tn < ntiles ? tn : t);              // (past the end: this tile again, not committed)
+    const int n = t / per_img, r = t % per_img;
+    const int oy0 = (r / a.tiles_x) * HTH + 2 * rg, ox0 = (r % a.tiles_x) * HTW;
+    // output rows 2 rg, 2 rg + 1 of the tile: gathered rows (2 rg [+ 1]) + ty; pair lm, window column tx'
+    const float* base = tile + cur * HTILE + kh * 2 * HPLANE + ((2 * rg) * 2 * HHALF + lm) * 4 + kq;
+    v4f acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    float f0[2][8], f1[2][8];
+    auto frags = [&](int buf, int g) {                 // K-groups 8g .. 8g + 7 of this half: i = (ty*8 + tx')*2 + j2,
+#pragma unroll                                         // channel quad 2 kh + j2 (the half is folded into `base`)
+      for (int ii = 0; ii < 8; ++ii) {
+        const int i = g * 8 + ii, j2 = i % 2, txp = (i / 2) % 8, ty = i / 16;
+        const int off = j2 * HPLANE + ((ty * 2 + (txp & 1)) * HHALF + (txp >> 1)) * 4;
+        f0[buf][ii] = base[off];
+        f1[buf][ii] = base[off + 2 * HHALF * 4];
+      }
+    };
+    frags(0, 0);
+#pragma unroll
+    for (int g = 0; g < HNW / 8; ++g) {                // 14 stages of 16 MFMAs
+      if (g + 1 < HNW / 8) frags((g + 1) & 1, g + 1);
+      if (g == 8) load_pw();
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[g * 8 + i], f0[g & 1][i], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[g * 8 + i], f1[g & 1][i], acc1, 0, 0, 0);
+      }
+      if (g < HSL) fetch_unit(g);                      // stages 0..4: the loads of the next tile
+      if (g >= 9) finish_unit(g - 9);                  // stages 9..13: its activation, in the MFMA shadow
+      if (g < HSL || g >= 9) {
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // the upper-K wave hands its accumulators to the lower-K wave of the same rows
+    float4* xw = reinterpret_cast<float4*>(xch) + ((cur * 4 + rg) * 2) * 64 + lane;
+    if (kh == 1) {
+      xw[0] = make_float4(acc0[0], acc0[1], acc0[2], acc0[3]);
+      xw[64] = make_float4(acc1[0], acc1[1], acc1[2], acc1[3]);
+    }
+    if (tn < ntiles) commit(tile + (cur ^ 1) * HTILE);
+    __syncthreads();
+    if (kh == 0) {
+      const float4 u0 = xw[0], u1 = xw[64];
+      acc0[0] += u0.x; acc0[1] += u0.y; acc0[2] += u0.z; acc0[3] += u0.w;
+      acc1[0] += u1.x; acc1[1] += u1.y; acc1[2] += u1.z; acc1[3] += u1.w;
+      const int c0 = 4 * (kq & 1);                     // lane: pixel 2 lm + (kq >> 1), channels c0 .. c0 + 3
+      if (a.bias) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const float b = a.bias[c0 + q]; acc0[q] += b; acc1[q] += b; }
+      }
+      const int ox = ox0 + 2 * lm + (kq >> 1);
+      float* out_n = a.out + (int64_t)n * a.h * a.w * a.out_cs + a.out_co + c0;
+      if (ox < a.w) {
+        if (oy0 < a.h)
+          *reinterpret_cast<float4*>(out_n + ((int64_t)oy0 * a.w + ox) * a.out_cs) = make_float4(acc0[0], acc0[1], acc0[2], acc0[3]);
+        if (oy0 + 1 < a.h)
+          *reinterpret_cast<float4*>(out_n + ((int64_t)(oy0 + 1) * a.w + ox) * a.out_cs) = make_float4(acc1[0], acc1[1], acc1[2], acc1[3]);
+      }
+    }
+    cur ^= 1;
+  }
+}
+
+struct FlatHPackArgs { const float* w; float* dst; int64_t sa, sb; int flip; };
+__global__ void flat_h7_pack_kernel(FlatHPackArgs a) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;      // ((kh*112 + ii)*4 + kq)*16 + m,  ii = (ty*8 + tx')*2 + j2,
+  if (i >= HKS * 64) return;                                // channel quad j = 2 kh + j2, m = d*8 + co
+  const int m = i % 16, kq = (i / 16) % 4, k = i / 64;
+  const int kh = k / HNW, ii = k % HNW;
+  const int j = 2 * kh + ii % 2, txp = (ii / 2) % 8, ty = ii / 16;
+  const int d = m / 8, co = m % 8, tx = txp - d, c = 4 * j + kq;
+  float v = 0.f;
+  if (tx >= 0 && tx < HK) {
+    const int ky = a.flip ? HK - 1 - ty : ty, kx = a.flip ? HK - 1 - tx : tx;
+    v = a.w[c * a.sa + co * a.sb + ky * HK + kx];
+  }
+  a.dst[i] = v;
+}
+
+}  // namespace
+
+bool bp_flat_h7_ok(const ConvGeom& g) {
+  static const bool off = getenv("BP_NOFLAT") != nullptr || getenv("BP_NOFLATH") != nullptr;
+  return !off && g.k == HK && g.stride == 1 && g.pad == HPAD && g.cin_g == HCG && g.cout_g == HCO && g.nphase == 1;
+}
+
+int64_t bp_flat_h7_packed_floats() { return (int64_t)HKS * 64; }
+
+int bp_flat_h7_pack(const ConvGeom& g, const WeightMap& wm, const float* w_torch, float* packed, hipStream_t st) {
+  FlatHPackArgs a{w_torch, packed, wm.sa, wm.sb, g.gather_transposed};
+  hipLaunchKernelGGL(flat_h7_pack_kernel, dim3((HKS * 64 + 255) / 256), dim3(256), 0, st, a);
+  BP_CHECK_LAUNCH();
+  return BP_OK;
+}
+
+int bp_flat_h7_run(const bp_view* in, const PW& pw, const float* packed, const float* bias, const bp_view* out,
+                   hipStream_t st) {
+  if (!bp_view_vec4(out) || !bp_view_vec4(in)) return BP_EUNSUPPORTED;
+  FlatHArgs a{};
+  a.bias = bias;
+  a.in = in->ptr; a.h = in->h; a.w = in->w; a.in_cs = in->cstride; a.in_co = in->coff;
+  a.out = out->ptr; a.out_cs = out->cstride; a.out_co = out->coff;
+  a.wp = packed; a.pw = pw; a.n = in->n; a.in_vec = bp_view_vec4(in) ? 1 : 0;
+  a.tiles_x = bp_ceil_div(out->w, HTW); a.tiles_y = bp_ceil_div(out->h, HTH);
+  const int64_t ntiles = (int64_t)a.tiles_x * a.tiles_y * a.n;
+  if (ntiles > 0x7fffffff) return BP_EUNSUPPORTED;
+  hipLaunchKernelGGL(flat_h7_kernel, dim3(flat_g4_grid((int)ntiles)), dim3(GNT), 0, st, a);
+  BP_CHECK_LAUNCH();
+  return BP_OK;
+}

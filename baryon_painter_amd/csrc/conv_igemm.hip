@@ -1480,12 +1480,20 @@ size_t bp_flat_t64_stats_workspace(const bp_view* out);
 int bp_flat_t64_run(const ConvGeom& g, const bp_view* in, const PW& pw, const float* packed, const float* bias,
                     const bp_view* out, hipStream_t st, const IgemmStatsReq* sr);
 
+// ... and unit-stride k7 16 -> 8 (the head's first layer forward: K split over two waves, pixel pairs per MFMA column)
+bool bp_flat_h7_ok(const ConvGeom& g);
+int64_t bp_flat_h7_packed_floats();
+int bp_flat_h7_pack(const ConvGeom& g, const WeightMap& wm, const float* w_torch, float* packed, hipStream_t st);
+int bp_flat_h7_run(const bp_view* in, const PW& pw, const float* packed, const float* bias, const bp_view* out,
+                   hipStream_t st);
+
 int bp_igemm_kernel_id(const ConvGeom& g) {
   if (bp_stem_ok(g)) return 700000;
   if (bp_flat_ok(g)) return 710000;
   if (bp_flat_t4_ok(g) && !bp_flat_t64_ok(g)) return 720000;
   if (bp_flat_g4_ok(g)) return 730000;
   if (bp_flat_t64_ok(g)) return 740000;
+  if (bp_flat_h7_ok(g)) return 750000;
   if (bp_small_ok(g)) return bp_small_kernel_id(g);
   const IgemmConfig c = igemm_config(g);
   if (c.ok && c.wres) return 400000 + c.CC * 1000 + c.NT * 100 + (c.w_NW / 4) * 10 + 2;
@@ -1498,6 +1506,7 @@ int64_t bp_igemm_packed_floats(const ConvGeom& g) {
   if (bp_flat_t4_ok(g) && !bp_flat_t64_ok(g)) return bp_flat_t4_packed_floats();
   if (bp_flat_g4_ok(g)) return bp_flat_g4_packed_floats(g);
   if (bp_flat_t64_ok(g)) return bp_flat_t64_packed_floats(g);
+  if (bp_flat_h7_ok(g)) return bp_flat_h7_packed_floats();
   if (bp_small_ok(g)) return bp_small_packed_floats(g);
   const IgemmConfig c = igemm_config(g);
   if (!c.ok) return -1;
@@ -1523,6 +1532,7 @@ int bp_igemm_pack(const ConvGeom& g, const WeightMap& wm, const float* w_torch, 
   if (bp_flat_t4_ok(g) && !bp_flat_t64_ok(g)) return bp_flat_t4_pack(wm, w_torch, packed, st);
   if (bp_flat_g4_ok(g)) return bp_flat_g4_pack(g, wm, w_torch, packed, st);
   if (bp_flat_t64_ok(g)) return bp_flat_t64_pack(g, wm, w_torch, packed, st);
+  if (bp_flat_h7_ok(g)) return bp_flat_h7_pack(g, wm, w_torch, packed, st);
   if (bp_small_ok(g)) return bp_small_pack(g, wm, w_torch, packed, st);
   PackArgs a;
   if (!igemm_pack_args(g, wm, w_torch, packed, a)) return BP_EUNSUPPORTED;
@@ -1536,7 +1546,7 @@ size_t bp_igemm_pack_job_bytes() { return sizeof(PackArgs); }
 
 int bp_igemm_pack_job(const ConvGeom& g, const WeightMap& wm, const float* w_torch, float* packed, void* job,
                       int64_t* nblocks) {
-  if (bp_stem_ok(g) || bp_flat_ok(g) || bp_flat_t4_ok(g) || bp_flat_g4_ok(g) || bp_flat_t64_ok(g) || bp_small_ok(g)) return BP_EUNSUPPORTED;       // (their own tiny pack kernels: packed by bp_conv_pack)
+  if (bp_stem_ok(g) || bp_flat_ok(g) || bp_flat_t4_ok(g) || bp_flat_g4_ok(g) || bp_flat_t64_ok(g) || bp_flat_h7_ok(g) || bp_small_ok(g)) return BP_EUNSUPPORTED;       // (their own tiny pack kernels: packed by bp_conv_pack)
   PackArgs a;
   if (!igemm_pack_args(g, wm, w_torch, packed, a)) return BP_EUNSUPPORTED;
   *reinterpret_cast<PackArgs*>(job) = a;
@@ -1635,6 +1645,7 @@ size_t bp_igemm_stats_workspace(const ConvGeom& g, const bp_view* in, const bp_v
   if (bp_flat_t4_ok(g) && !bp_flat_t64_ok(g)) return mode == 1 ? bp_flat_t4_stats_workspace(out) : 0;
   if (bp_flat_g4_ok(g)) return mode == 1 ? bp_flat_g4_stats_workspace(out) : 0;
   if (bp_flat_t64_ok(g)) return mode == 1 ? bp_flat_t64_stats_workspace(out) : 0;
+  if (bp_flat_h7_ok(g)) return 0;
   if (bp_small_ok(g)) return 0;
   const IgemmConfig c = igemm_config(g);
   IgemmLaunch l;
@@ -1651,6 +1662,7 @@ int bp_igemm_run(const ConvGeom& g, const bp_view* in, const PW& pw, const float
   if (bp_flat_t4_ok(g) && !bp_flat_t64_ok(g)) return bp_flat_t4_run(in, pw, packed, bias, out, st, sr);
   if (bp_flat_g4_ok(g)) return bp_flat_g4_run(g, in, pw, packed, bias, out, st, sr);
   if (bp_flat_t64_ok(g)) return bp_flat_t64_run(g, in, pw, packed, bias, out, st, sr);
+  if (bp_flat_h7_ok(g)) return sr ? BP_EUNSUPPORTED : bp_flat_h7_run(in, pw, packed, bias, out, st);
   if (bp_small_ok(g)) return sr ? BP_EUNSUPPORTED : bp_small_run(g, in, pw, packed, bias, out, st);
   const IgemmConfig c = igemm_config(g);
   if (!c.ok) return BP_EUNSUPPORTED;

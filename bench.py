@@ -73,6 +73,8 @@ def kernel_name(kind, unit, lib):
     kid = lib.bp_conv_kernel_id(C.byref(cv), L.PACK_FWD if kind == "forward" else L.PACK_BWD)
     if kid == 700000:
         return "stem_forward_kernel"
+    if kid == 750000:
+        return "flat_h7_kernel"
     if kid == 740000:
         return "flat_t64_kernel"
     if kid == 730000:

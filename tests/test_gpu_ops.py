@@ -144,7 +144,7 @@ DMA_CASES = [
     (1, 64, 32, 4, 2, 1, (3, 5, 9)),
     (1, 128, 64, 4, 2, 1, (2, 7, 18)),
     (0, 16, 32, 4, 2, 1, (3, 30, 70)),        # weights-resident persistent igemm (stride-2 gather)
-    (0, 16, 8, 7, 1, 3, (3, 21, 45)),         # ... 49 taps; weight gradient: conv_wgrad_flat.hip
+    (0, 16, 8, 7, 1, 3, (3, 21, 45)),         # forward: conv_flat.hip flat_h7 (K split over two waves); weight gradient: conv_wgrad_flat.hip
     (0, 16, 8, 7, 1, 3, (9, 64, 250)),        # ... more tiles than workgroups (grid-stride walk)
     (0, 8, 16, 7, 1, 3, (3, 21, 45)),         # conv_flat.hip forward (weights in registers); its data gradient: wres
     (0, 16, 8, 7, 1, 3, (40, 64, 130)),       # conv_flat.hip data gradient with more tiles than workgroups

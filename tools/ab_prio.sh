@@ -4,5 +4,5 @@ import sys, json
 d = json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$1', d['value'], d['ms_per_step'])"; }
 for i in 1 2; do
   run f32
-  BP_NOFLATG=1 run f32_noflatg
+  BP_NOFLATH=1 run f32_noflath
 done
