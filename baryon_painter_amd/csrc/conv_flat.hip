@@ -32,11 +32,18 @@ struct FlatArgs {
   const float* wp;            // [u][g][kq][co]
   PW pw;
   int n, tiles_x, tiles_y, i0, in_vec;
+  // mode-2 statistics (data gradient): the sums {sum g, sum g*raw} of bp_act_backward for the layer that produced the
+  // tensor this kernel writes the gradient of, g = out * act'(spw(raw)); partial rows [workgroup][2][16]
+  const float* raw; int raw_cs, raw_co;
+  PW spw;
+  double* stat;
 };
 
-template <bool OUT_VEC>
+template <bool OUT_VEC, bool STATS2>
 __global__ __launch_bounds__(256, 2) void flat_k7_kernel(FlatArgs a) {
   __shared__ __attribute__((aligned(16))) float tile[NQ * PLANE];
+  __shared__ double lsum[STATS2 ? 8 * 256 : 1];      // per-lane running sums (registers hold the weights)
+  __shared__ double red[STATS2 ? 4 : 1][2][CO];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lm = lane & 15, kq = lane >> 4;
@@ -49,6 +56,20 @@ __global__ __launch_bounds__(256, 2) void flat_k7_kernel(FlatArgs a) {
   v4f b4 = {0.f, 0.f, 0.f, 0.f};
   if (a.bias) b4 = v4f{a.bias[4 * kq], a.bias[4 * kq + 1], a.bias[4 * kq + 2], a.bias[4 * kq + 3]};
 
+  if constexpr (STATS2) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) lsum[q * 256 + tid] = 0.0;
+  }
+  float ssc[STATS2 ? 4 : 1], ssf[STATS2 ? 4 : 1], ssl[STATS2 ? 4 : 1];   // activation of the lane's 4 channels
+  if constexpr (STATS2) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const bool on = a.spw.scale != nullptr;
+      ssc[q] = on ? a.spw.scale[4 * kq + q] : 1.f;
+      ssf[q] = on ? a.spw.shift[4 * kq + q] : 0.f;
+      ssl[q] = on ? a.spw.slope[4 * kq + q] : 1.f;
+    }
+  }
   // staging: unit e = (pixel, quad); a thread always holds the same quad
   const int q4 = tid % NQ;
   const PW4 p4 = pw4_load(a.pw, q4 * 4, CG);
@@ -95,6 +116,7 @@ __global__ __launch_bounds__(256, 2) void flat_k7_kernel(FlatArgs a) {
     const int n = t / per_img, r = t % per_img;
     const int y0 = (r / a.tiles_x) * TH, x0 = (r % a.tiles_x) * TW;
     float* out_n = a.out + (int64_t)n * a.h * a.w * a.out_cs + a.out_co;
+    float ps[STATS2 ? 8 : 1] = {};                     // fp32 partial sums over the wave's 8 pixel groups of this tile
 #pragma unroll 1
     for (int rr = 0; rr < 2; ++rr) {
       const int row = wave * 2 + rr;
@@ -102,6 +124,12 @@ __global__ __launch_bounds__(256, 2) void flat_k7_kernel(FlatArgs a) {
       for (int ct = 0; ct < TW / 16; ++ct) {
         v4f acc = b4;
         const float* base = tile + (row * IWP + ct * 16 + lm) * 4 + kq;
+        float4 rq = make_float4(0.f, 0.f, 0.f, 0.f);
+        if constexpr (STATS2) {                        // (issued before the MFMA chain, used after it)
+          const int Yc = min(y0 + row, a.h - 1), Xc = min(x0 + ct * 16 + lm, a.w - 1);
+          rq = *reinterpret_cast<const float4*>(a.raw + (((int64_t)n * a.h + Yc) * a.w + Xc) * a.raw_cs + a.raw_co + 4 * kq);
+          __builtin_amdgcn_sched_barrier(0);           // (keep the load in front of the MFMA chain)
+        }
 #pragma unroll
         for (int u = 0; u < K; ++u)
 #pragma unroll
@@ -113,12 +141,47 @@ __global__ __launch_bounds__(256, 2) void flat_k7_kernel(FlatArgs a) {
           float* o = out_n + ((int64_t)Y * a.w + X) * a.out_cs + 4 * kq;
           if constexpr (OUT_VEC) *reinterpret_cast<float4*>(o) = make_float4(acc[0], acc[1], acc[2], acc[3]);
           else { o[0] = acc[0]; o[1] = acc[1]; o[2] = acc[2]; o[3] = acc[3]; }
+          if constexpr (STATS2) {
+            const float rv[4] = {rq.x, rq.y, rq.z, rq.w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const float tt = fmaf(rv[q], ssc[q], ssf[q]);
+              const float g = tt > 0.f ? acc[q] : acc[q] * ssl[q];
+              ps[q] += g;
+              ps[4 + q] = fmaf(g, rv[q], ps[4 + q]);
+            }
+          }
         }
       }
+    }
+    if constexpr (STATS2) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) lsum[q * 256 + tid] += (double)ps[q];
     }
     __syncthreads();                 // every wave is done reading the tile
     if (tn < ntiles) commit();
     __syncthreads();
+  }
+  if constexpr (STATS2) {
+    double s1[4], s2[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { s1[q] = lsum[q * 256 + tid]; s2[q] = lsum[(4 + q) * 256 + tid]; }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int off = 8; off > 0; off >>= 1) {
+        s1[q] += __shfl_xor(s1[q], off, 16);
+        s2[q] += __shfl_xor(s2[q], off, 16);
+      }
+    if (lm == 0) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { red[wave][0][4 * kq + q] = s1[q]; red[wave][1][4 * kq + q] = s2[q]; }
+    }
+    __syncthreads();
+    if (tid < 2 * CO) {
+      const int sidx = tid / CO, c = tid % CO;
+      a.stat[(int64_t)blockIdx.x * 2 * CO + tid] = ((red[0][sidx][c] + red[1][sidx][c]) + red[2][sidx][c]) + red[3][sidx][c];
+    }
   }
 }
 
@@ -154,9 +217,25 @@ int bp_flat_pack(const ConvGeom& g, const WeightMap& wm, const float* w_torch, f
   return BP_OK;
 }
 
+static int flat_k7_tiles(const bp_view* out) { return bp_ceil_div(out->w, TW) * bp_ceil_div(out->h, TH) * out->n; }
+
+// mode-2 statistics are offered where the raw tensor (same grid as `out`) can be read 16 bytes at a time
+size_t bp_flat_stats_workspace(const bp_view* out, int mode) {
+  if (mode != 2 || !bp_view_vec4(out)) return 0;
+  return (size_t)flat_grid(flat_k7_tiles(out)) * 2 * CO * sizeof(double);
+}
+
 int bp_flat_run(const ConvGeom& g, const bp_view* in, const PW& pw, const float* packed, const float* bias,
-                const bp_view* out, hipStream_t st) {
+                const bp_view* out, hipStream_t st, const IgemmStatsReq* sr) {
   FlatArgs a{};
+  if (sr) {
+    if (sr->mode != 2 || bias || !sr->raw || !bp_view_vec4(sr->raw) || !bp_view_vec4(out) || sr->raw->n != out->n ||
+        sr->raw->h != out->h || sr->raw->w != out->w || sr->raw->c != CO)
+      return BP_EUNSUPPORTED;
+    if (!sr->ws || sr->ws_bytes < bp_flat_stats_workspace(out, 2) || !sr->sums) return BP_EWORKSPACE;
+    a.raw = sr->raw->ptr; a.raw_cs = sr->raw->cstride; a.raw_co = sr->raw->coff; a.spw = sr->spw;
+    a.stat = reinterpret_cast<double*>(sr->ws);
+  }
   a.in_vec = bp_view_vec4(in) ? 1 : 0;
   a.in = in->ptr; a.h = in->h; a.w = in->w; a.in_cs = in->cstride; a.in_co = in->coff;
   a.out = out->ptr; a.out_cs = out->cstride; a.out_co = out->coff;
@@ -166,9 +245,11 @@ int bp_flat_run(const ConvGeom& g, const bp_view* in, const PW& pw, const float*
   const int64_t ntiles = (int64_t)a.tiles_x * a.tiles_y * a.n;
   if (ntiles > 0x7fffffff) return BP_EUNSUPPORTED;
   const int grid = flat_grid((int)ntiles);
-  if (bp_view_vec4(out)) hipLaunchKernelGGL(flat_k7_kernel<true>, dim3(grid), dim3(256), 0, st, a);
-  else hipLaunchKernelGGL(flat_k7_kernel<false>, dim3(grid), dim3(256), 0, st, a);
+  if (sr) hipLaunchKernelGGL((flat_k7_kernel<true, true>), dim3(grid), dim3(256), 0, st, a);
+  else if (bp_view_vec4(out)) hipLaunchKernelGGL((flat_k7_kernel<true, false>), dim3(grid), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((flat_k7_kernel<false, false>), dim3(grid), dim3(256), 0, st, a);
   BP_CHECK_LAUNCH();
+  if (sr) return bp_sum_partials(a.stat, grid, 2 * CO, sr->sums, st);
   return BP_OK;
 }
 

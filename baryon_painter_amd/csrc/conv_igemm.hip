@@ -1455,8 +1455,9 @@ int bp_stem_run(const bp_view* in, const PW& pw, const float* packed, const floa
 bool bp_flat_ok(const ConvGeom& g);
 int64_t bp_flat_packed_floats();
 int bp_flat_pack(const ConvGeom& g, const WeightMap& wm, const float* w_torch, float* packed, hipStream_t st);
+size_t bp_flat_stats_workspace(const bp_view* out, int mode);
 int bp_flat_run(const ConvGeom& g, const bp_view* in, const PW& pw, const float* packed, const float* bias,
-                const bp_view* out, hipStream_t st);
+                const bp_view* out, hipStream_t st, const IgemmStatsReq* sr);
 // ... and the stride-2 k4 transposed form 32 -> 16 (four phases, all weights in registers)
 bool bp_flat_t4_ok(const ConvGeom& g);
 int64_t bp_flat_t4_packed_floats();
@@ -1641,7 +1642,7 @@ int bp_stats_rows_finish(double* ws, int64_t rows, int C, double* sums, hipStrea
 
 size_t bp_igemm_stats_workspace(const ConvGeom& g, const bp_view* in, const bp_view* out, int mode) {
   if (bp_stem_ok(g)) return mode == 1 ? bp_stem_stats_workspace(out) : 0;
-  if (bp_flat_ok(g)) return 0;
+  if (bp_flat_ok(g)) return bp_flat_stats_workspace(out, mode);
   if (bp_flat_t4_ok(g) && !bp_flat_t64_ok(g)) return mode == 1 ? bp_flat_t4_stats_workspace(out) : 0;
   if (bp_flat_g4_ok(g)) return mode == 1 ? bp_flat_g4_stats_workspace(out) : 0;
   if (bp_flat_t64_ok(g)) return mode == 1 ? bp_flat_t64_stats_workspace(out) : 0;
@@ -1658,7 +1659,7 @@ size_t bp_igemm_stats_workspace(const ConvGeom& g, const bp_view* in, const bp_v
 int bp_igemm_run(const ConvGeom& g, const bp_view* in, const PW& pw, const float* packed,
                  const float* bias, const bp_view* out, hipStream_t st, const IgemmStatsReq* sr) {
   if (bp_stem_ok(g)) return bp_stem_run(in, pw, packed, bias, out, st, sr);
-  if (bp_flat_ok(g)) return sr ? BP_EUNSUPPORTED : bp_flat_run(g, in, pw, packed, bias, out, st);
+  if (bp_flat_ok(g)) return bp_flat_run(g, in, pw, packed, bias, out, st, sr);
   if (bp_flat_t4_ok(g) && !bp_flat_t64_ok(g)) return bp_flat_t4_run(in, pw, packed, bias, out, st, sr);
   if (bp_flat_g4_ok(g)) return bp_flat_g4_run(g, in, pw, packed, bias, out, st, sr);
   if (bp_flat_t64_ok(g)) return bp_flat_t64_run(g, in, pw, packed, bias, out, st, sr);

@@ -23,9 +23,12 @@ from .. import _lib as L
 
 # BP_EPILOGUE_STATS=0: batch-norm sums by separate streaming passes (bp_channel_sums / bp_act_backward) everywhere;
 # "fwd" / "bwd": only the forward statistics / only the backward sums from the convolution epilogues
-_ES = os.environ.get("BP_EPILOGUE_STATS", "fwd")
+_ES = os.environ.get("BP_EPILOGUE_STATS", "auto")
 EPILOGUE_STATS = _ES != "0"
-EPILOGUE_FWD, EPILOGUE_BWD = _ES in ("1", "fwd"), _ES in ("1", "bwd")
+EPILOGUE_FWD, EPILOGUE_BWD = _ES in ("1", "fwd", "auto"), _ES in ("1", "bwd", "auto")
+# "auto": the backward sums only from the flattened-K data-gradient kernels (conv_flat.hip: weights in registers, sums
+# per lane in LDS).  In the tiled igemm kernels the double-precision sums cost what the saved pass costs ("1": all).
+_BWD_KERNEL_IDS = (710000,) if _ES == "auto" else None
 
 
 def _stream():
@@ -482,7 +485,9 @@ class ConvUnit:
         self.plan.need_ws(lib.bp_conv_backward_weight_workspace(C.byref(self.cv), C.byref(self.inp.view),
                                                                 C.byref(self.out.view)))
         self.dx = self.inp.claim_grad() if self.need_dgrad else None
-        if self.dx is not None and self._sub is None and EPILOGUE_BWD and not self.bf16 and self.inp.dt == L.F32:
+        if self.dx is not None and self._sub is None and EPILOGUE_BWD and not self.bf16 and self.inp.dt == L.F32 \
+                and (_BWD_KERNEL_IDS is None
+                     or lib.bp_conv_kernel_id(C.byref(self.cv), L.PACK_BWD) in _BWD_KERNEL_IDS):
             self.plan.need_ws(lib.bp_conv_stats_workspace(C.byref(self.cv), L.PACK_BWD, C.byref(self.inp.view),
                                                           C.byref(self.out.view), L.IMPL_MFMA))
         if self.dx is not None and self._sub is not None:
@@ -569,6 +574,9 @@ class ConvUnit:
                     and self._impl("dgrad") in (L.IMPL_AUTO, L.IMPL_MFMA):
                 nb = self.plan.lib.bp_conv_stats_workspace(C.byref(self.cv), L.PACK_BWD, C.byref(self.inp.view),
                                                            C.byref(self.out.view), L.IMPL_MFMA)
+                if _BWD_KERNEL_IDS is not None \
+                        and self.plan.lib.bp_conv_kernel_id(C.byref(self.cv), L.PACK_BWD) not in _BWD_KERNEL_IDS:
+                    nb = 0
                 if 0 < nb <= self.plan.ws_bytes:
                     self._fused_producer = p
         return self._fused_producer
