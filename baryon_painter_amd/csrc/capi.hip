@@ -123,7 +123,14 @@ int bp_conv_forward(const bp_conv* cv, const bp_view* x, const bp_pointwise* x_p
     if (!packed_fwd) return BP_EINVAL;
     return bp_bf16_igemm_run(g, x, bp_pw(x_pw), packed_fwd, bias, y, bp_stream(stream));
   }
-  if (impl == BP_IMPL_AUTO) impl = packed_fwd ? BP_IMPL_MFMA : BP_IMPL_DIRECT;
+  if (impl == BP_IMPL_AUTO && packed_fwd) {
+    // the register-resident kernels (conv_flat.hip) want 16-byte aligned produced views: AUTO takes the direct kernel
+    // for the odd view instead of refusing it (BP_IMPL_MFMA, asked for by name, still reports BP_EUNSUPPORTED)
+    const int rc = bp_igemm_run(g, x, bp_pw(x_pw), packed_fwd, bias, y, bp_stream(stream));
+    if (rc != BP_EUNSUPPORTED || !w_torch) return rc;
+    impl = BP_IMPL_DIRECT;
+  }
+  if (impl == BP_IMPL_AUTO) impl = BP_IMPL_DIRECT;
   if (impl == BP_IMPL_MFMA) {
     if (!packed_fwd) return BP_EINVAL;
     return bp_igemm_run(g, x, bp_pw(x_pw), packed_fwd, bias, y, bp_stream(stream));
@@ -167,7 +174,12 @@ int bp_conv_backward_data(const bp_conv* cv, const bp_view* dy, const float* pac
     if (!packed_bwd) return BP_EINVAL;
     return bp_bf16_igemm_run(g, dy, PW{nullptr, nullptr, nullptr}, packed_bwd, nullptr, dx, bp_stream(stream));
   }
-  if (impl == BP_IMPL_AUTO) impl = packed_bwd ? BP_IMPL_MFMA : BP_IMPL_DIRECT;
+  if (impl == BP_IMPL_AUTO && packed_bwd) {
+    const int rc = bp_igemm_run(g, dy, PW{nullptr, nullptr, nullptr}, packed_bwd, nullptr, dx, bp_stream(stream));
+    if (rc != BP_EUNSUPPORTED || !w_torch) return rc;
+    impl = BP_IMPL_DIRECT;
+  }
+  if (impl == BP_IMPL_AUTO) impl = BP_IMPL_DIRECT;
   if (impl == BP_IMPL_MFMA) {
     if (!packed_bwd) return BP_EINVAL;
     return bp_igemm_run(g, dy, PW{nullptr, nullptr, nullptr}, packed_bwd, nullptr, dx, bp_stream(stream));

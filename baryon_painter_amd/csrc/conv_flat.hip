@@ -1091,7 +1091,7 @@ __global__ __launch_bounds__(GNT) void flat_h7_kernel(FlatHArgs a) {
     inside |= ((unsigned)(e < HNU) & (unsigned)(iy >= 0) & (unsigned)(iy < a.h) & (unsigned)(ix >= 0) & (unsigned)(ix < a.w)) << i;
     const int cy = min(max(iy, 0), a.h - 1), cx = min(max(ix, 0), a.w - 1);
     const float* p = fin_n + (cy * a.w + cx) * a.in_cs;
-    stage[i] = *reinterpret_cast<const float4*>(p);
+    stage[i] = a.in_vec ? *reinterpret_cast<const float4*>(p) : make_float4(p[0], p[1], p[2], p[3]);
   };
   float psc[4], psf[4], psl[4];
   auto finish_unit = [&](int i) {
@@ -1235,7 +1235,7 @@ int bp_flat_h7_pack(const ConvGeom& g, const WeightMap& wm, const float* w_torch
 
 int bp_flat_h7_run(const bp_view* in, const PW& pw, const float* packed, const float* bias, const bp_view* out,
                    hipStream_t st) {
-  if (!bp_view_vec4(out) || !bp_view_vec4(in)) return BP_EUNSUPPORTED;
+  if (!bp_view_vec4(out)) return BP_EUNSUPPORTED;
   FlatHArgs a{};
   a.bias = bias;
   a.in = in->ptr; a.h = in->h; a.w = in->w; a.in_cs = in->cstride; a.in_co = in->coff;

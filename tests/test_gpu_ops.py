@@ -466,3 +466,29 @@ def test_adam_matches_torch():
                                  step, G.stream()))
         torch.cuda.synchronize()
     assert G.rel_err(p.cpu().numpy(), ref.detach().numpy()) < 1e-6
+
+
+@pytest.mark.parametrize("case", [(0, 32, 64, 4, 2, 1, (2, 14, 22)), (1, 64, 32, 4, 2, 1, (2, 5, 9)), (0, 16, 8, 7, 1, 3, (2, 11, 21)),
+                                  (1, 32, 16, 4, 2, 1, (2, 9, 13))],
+                         ids=lambda c: "%s%d_%d_k%ds%d" % ("T" if c[0] else "C", *c[1:5]))
+def test_auto_takes_the_direct_kernel_for_views_the_register_resident_kernels_refuse(case):
+    """conv_flat.hip stores 16 bytes per lane: a produced view at an odd channel offset is refused by name
+    (BP_IMPL_MFMA -> BP_EUNSUPPORTED) and served by the direct kernel under BP_IMPL_AUTO."""
+    lib = L.load()
+    tr, ci, co, k, s, p, (n, h, w) = case
+    rng = np.random.default_rng(ci + 3 * co + k)
+    x = rng.standard_normal((n, ci, h, w)).astype(np.float32)
+    wt = (rng.standard_normal(((ci, co) if tr else (co, ci)) + (k, k)) * 0.1).astype(np.float32)
+    y_ref = ops.convT2d_fwd(x.astype(np.float64), wt.astype(np.float64), s, p, 0) if tr else \
+        ops.conv2d_fwd(x.astype(np.float64), wt.astype(np.float64), s, p)
+    _, _, ho, wo = y_ref.shape
+    cv = L.Conv(tr, ci, co, k, s, p, 0)
+    st = G.stream()
+    xb, xv = G.to_nhwc(x)
+    yb, yv = G.empty_nhwc(n, ho, wo, co, cstride=co + 3, coff=1)
+    wd = G.dev(wt)
+    pf = torch.zeros(lib.bp_conv_packed_floats(C.byref(cv), L.PACK_FWD), device="cuda")
+    L.check(lib.bp_conv_pack(C.byref(cv), L.PACK_FWD, L.ptr(wd), L.ptr(pf), st))
+    assert lib.bp_conv_forward(C.byref(cv), C.byref(xv), None, L.ptr(pf), L.ptr(wd), None, C.byref(yv), L.IMPL_MFMA, st) == -2
+    L.check(lib.bp_conv_forward(C.byref(cv), C.byref(xv), None, L.ptr(pf), L.ptr(wd), None, C.byref(yv), L.IMPL_AUTO, st))
+    assert G.rel_err(G.from_nhwc(yb, co, coff=1), y_ref) < 2e-5
