@@ -30,6 +30,13 @@ class Conv(C.Structure):
                 ("k", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32), ("out_pad", C.c_int32)]
 
 
+class BnTrain(C.Structure):
+    _fields_ = [("count", C.c_double), ("gamma", C.c_void_p), ("beta", C.c_void_p), ("eps", C.c_float),
+                ("momentum", C.c_float), ("running_mean", C.c_void_p), ("running_var", C.c_void_p),
+                ("num_batches_tracked", C.c_void_p), ("scale", C.c_void_p), ("shift", C.c_void_p),
+                ("save_mean", C.c_void_p), ("save_invstd", C.c_void_p)]
+
+
 class Latent(C.Structure):
     _fields_ = [("n", C.c_int32), ("L", C.c_int32), ("zc", C.c_int32), ("zh", C.c_int32),
                 ("zw", C.c_int32), ("min_z_var", C.c_float)]
@@ -63,6 +70,7 @@ SIGNATURES = {
     "bp_conv_backward_data": (C.c_int, [_CP, _VP, _P, _P, _VP, C.c_int, _P]),
     "bp_conv_stats_workspace": (C.c_size_t, [_CP, C.c_int, _VP, _VP, C.c_int]),
     "bp_conv_forward_stats": (C.c_int, [_CP, _VP, _PWP, _P, _VP, _P, _P, C.c_size_t, C.c_int, _P]),
+    "bp_conv_forward_bn": (C.c_int, [_CP, _VP, _PWP, _P, _VP, _P, C.POINTER(BnTrain), _P, C.c_size_t, C.c_int, _P]),
     "bp_conv_backward_data_stats": (C.c_int, [_CP, _VP, _P, _VP, _VP, _PWP, _P, _P, C.c_size_t, _P]),
     "bp_conv_backward_weight_workspace": (C.c_size_t, [_CP, _VP, _VP]),
     "bp_conv_backward_weight": (C.c_int, [_CP, _VP, _PWP, _VP, _P, _P, _P, C.c_size_t, C.c_int, _P]),

@@ -156,6 +156,20 @@ int bp_conv_forward_stats(const bp_conv* cv, const bp_view* x, const bp_pointwis
   return bp_igemm_run(bp_geom_forward(cv), x, bp_pw(x_pw), packed_fwd, nullptr, y, bp_stream(stream), &sr);
 }
 
+int bp_conv_forward_bn(const bp_conv* cv, const bp_view* x, const bp_pointwise* x_pw, const float* packed_fwd,
+                       const bp_view* y, double* sums, const bp_bn_train* bn, void* workspace, size_t workspace_bytes,
+                       int impl, void* stream) {
+  if (!conv_ok(cv) || !shapes_ok(cv, x, y, impl == BP_IMPL_BF16) || !packed_fwd || !sums || !bn || bn->count <= 0 ||
+      !bn->scale || !bn->shift)
+    return BP_EINVAL;
+  const BnFin fin{bn->count, bn->gamma, bn->beta, bn->eps, bn->momentum, bn->running_mean, bn->running_var,
+                  bn->num_batches_tracked, bn->scale, bn->shift, bn->save_mean, bn->save_invstd};
+  const IgemmStatsReq sr{1, nullptr, PW{nullptr, nullptr, nullptr}, sums, workspace, workspace_bytes, &fin};
+  if (impl == BP_IMPL_BF16)
+    return bp_bf16_igemm_run(bp_geom_forward(cv), x, bp_pw(x_pw), packed_fwd, nullptr, y, bp_stream(stream), &sr);
+  return bp_igemm_run(bp_geom_forward(cv), x, bp_pw(x_pw), packed_fwd, nullptr, y, bp_stream(stream), &sr);
+}
+
 int bp_conv_backward_data_stats(const bp_conv* cv, const bp_view* dy, const float* packed_bwd, const bp_view* dx,
                                 const bp_view* x_raw, const bp_pointwise* x_pw, double* sums, void* workspace,
                                 size_t workspace_bytes, void* stream) {

@@ -44,6 +44,16 @@ static inline PW bp_pw(const bp_pointwise* p) {
 // Request for per-channel sums out of an igemm epilogue (conv_igemm.hip, IgemmArgs::stat).  mode 1: {sum y,
 // sum y^2} of the produced tensor; mode 2: the produced tensor is d(loss)/d(activated slot), `raw` / `spw` are that
 // slot's raw values and pending activation: {sum g, sum g*raw} with g = d * act'(spw(raw)).  sums[2c].
+// Training-mode batch-norm finalize (bp_bn_finalize's arguments) folded into the launch that sums the partial rows
+// of a mode-1 request: one small launch less per batch-norm layer and step.
+struct BnFin {
+  double count;
+  const float* gamma; const float* beta;
+  float eps, momentum;
+  float* rm; float* rv; int64_t* nbt;
+  float* scale; float* shift;
+  double* smean; double* sinv;
+};
 struct IgemmStatsReq {
   int mode;
   const bp_view* raw;
@@ -51,8 +61,11 @@ struct IgemmStatsReq {
   double* sums;
   void* ws;
   size_t ws_bytes;
+  const BnFin* fin;         // mode 1 only; nullptr: sums only
 };
 int bp_sum_partials(const double* partial, int nblk, int n, double* out, hipStream_t st);
+// the last stage of a statistics request: partial[nblk][n] -> sr->sums (and, with sr->fin, the finalize)
+int bp_sum_partials_req(const double* partial, int nblk, int n, const IgemmStatsReq* sr, hipStream_t st);
 
 __device__ __forceinline__ float pw_apply(const PW& pw, int ch, float x) {
   if (pw.scale == nullptr) return x;

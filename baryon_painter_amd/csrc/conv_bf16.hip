@@ -96,7 +96,7 @@ int bp_bf16_pack(const ConvGeom& g, const WeightMap& wm, const float* w_torch, v
 
 // conv_igemm.hip: partial rows of epilogue statistics -> sums
 size_t bp_stats_rows_bytes(int64_t rows, int C);
-int bp_stats_rows_finish(double* ws, int64_t rows, int C, double* sums, hipStream_t st);
+int bp_stats_rows_finish(double* ws, int64_t rows, int C, const IgemmStatsReq* sr, hipStream_t st);
 
 static int64_t bf16_stat_rows(const ConvGeom& g, const BConfig& c, const bp_view* in, const bp_view* out) {
   const int qh = bp_ceil_div(out->h, g.OS), qw = bp_ceil_div(out->w, g.OS);
@@ -146,6 +146,6 @@ int bp_bf16_igemm_run(const ConvGeom& g, const bp_view* in, const PW& pw, const 
     case 4: rc = bp_bf16_launch_cc4(c, a, ib, ob, grid, st); break;
   }
   if (rc != BP_OK || !sr) return rc;
-  return bp_stats_rows_finish(a.stat, rows, g.cout_g, sr->sums, st);
+  return bp_stats_rows_finish(a.stat, rows, g.cout_g, sr, st);
 }
 

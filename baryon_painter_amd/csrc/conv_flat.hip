@@ -477,7 +477,7 @@ int bp_flat_t4_run(const bp_view* in, const PW& pw, const float* packed, const f
   if (sr) hipLaunchKernelGGL(flat_t4_kernel<true>, dim3(grid), dim3(256), 0, st, a);
   else hipLaunchKernelGGL(flat_t4_kernel<false>, dim3(grid), dim3(256), 0, st, a);
   BP_CHECK_LAUNCH();
-  if (sr) return bp_sum_partials(a.stat, grid, 2 * TCO, sr->sums, st);
+  if (sr) return bp_sum_partials_req(a.stat, grid, 2 * TCO, sr, st);
   return BP_OK;
 }
 
@@ -744,7 +744,7 @@ int bp_flat_g4_run(const ConvGeom& g, const bp_view* in, const PW& pw, const flo
     else hipLaunchKernelGGL((flat_g4_kernel<16, 32, false>), gd, bd, 0, st, a);
   }
   BP_CHECK_LAUNCH();
-  if (sr) return bp_sum_partials(a.stat, grid, 2 * g.cout_g, sr->sums, st);
+  if (sr) return bp_sum_partials_req(a.stat, grid, 2 * g.cout_g, sr, st);
   return BP_OK;
 }
 
@@ -1008,7 +1008,7 @@ int bp_flat_t64_run(const ConvGeom& g, const bp_view* in, const PW& pw, const fl
     else hipLaunchKernelGGL((flat_t64_kernel<32, 16, false>), gd, bd, 0, st, a);
   }
   BP_CHECK_LAUNCH();
-  if (sr) return bp_sum_partials(a.stat, grid, 2 * g.cout_g, sr->sums, st);
+  if (sr) return bp_sum_partials_req(a.stat, grid, 2 * g.cout_g, sr, st);
   return BP_OK;
 }
 

@@ -1612,7 +1612,7 @@ static bool stats_plan(const ConvGeom& g, const IgemmConfig& c, const IgemmLaunc
   stats_fold_plan(p);
   return true;
 }
-static int stats_finish(const StatsPlan& sp, double* ws, double* sums, hipStream_t st) {
+static int stats_finish(const StatsPlan& sp, double* ws, const IgemmStatsReq* sr, hipStream_t st) {
   const double* rows = ws;
   int64_t nrows = sp.rows;
   if (sp.nfold) {
@@ -1621,7 +1621,7 @@ static int stats_finish(const StatsPlan& sp, double* ws, double* sums, hipStream
     BP_CHECK_LAUNCH();
     rows = folded; nrows = sp.nfold;
   }
-  return bp_sum_partials(rows, (int)nrows, sp.n, sums, st);
+  return bp_sum_partials_req(rows, (int)nrows, sp.n, sr, st);
 }
 
 // Partial rows [rows][2*C] written by some kernel's epilogue -> sums[2*C] (used by the bf16 kernels too):
@@ -1633,11 +1633,11 @@ size_t bp_stats_rows_bytes(int64_t rows, int C) {
   stats_fold_plan(p);
   return p.bytes;
 }
-int bp_stats_rows_finish(double* ws, int64_t rows, int C, double* sums, hipStream_t st) {
+int bp_stats_rows_finish(double* ws, int64_t rows, int C, const IgemmStatsReq* sr, hipStream_t st) {
   StatsPlan p{};
   p.rows = rows; p.n = 2 * C;
   stats_fold_plan(p);
-  return stats_finish(p, ws, sums, st);
+  return stats_finish(p, ws, sr, st);
 }
 
 size_t bp_igemm_stats_workspace(const ConvGeom& g, const bp_view* in, const bp_view* out, int mode) {
@@ -1704,5 +1704,5 @@ int bp_igemm_run(const ConvGeom& g, const bp_view* in, const PW& pw, const float
   else if (c.MT == 4) rc = launch_mt<4>(c, a, grid, st);
   else rc = launch_mt<1>(c, a, grid, st);
   if (rc != BP_OK || !sr) return rc;
-  return stats_finish(sp, a.stat, sr->sums, st);
+  return stats_finish(sp, a.stat, sr, st);
 }

@@ -366,7 +366,7 @@ int bp_stem_run(const bp_view* in, const PW& pw, const float* packed, const floa
   if (a.out_vec) hipLaunchKernelGGL(stem_forward_kernel<true>, dim3(grid), dim3(256), 0, st, a);
   else hipLaunchKernelGGL(stem_forward_kernel<false>, dim3(grid), dim3(256), 0, st, a);
   BP_CHECK_LAUNCH();
-  if (sr) return bp_sum_partials(a.stat, grid, 2 * CO16, sr->sums, st);
+  if (sr) return bp_sum_partials_req(a.stat, grid, 2 * CO16, sr, st);
   return BP_OK;
 }
 

@@ -824,6 +824,43 @@ __global__ __launch_bounds__(RB) void adam_dev_kernel(float* p, const float* g, 
 
 }  // namespace
 
+// sum_partials_wave_kernel for the two columns {c, C + c} of a channel (same order of additions: bitwise the same sums)
+// followed by bn_finalize_kernel's arithmetic for that channel
+__global__ __launch_bounds__(128) void sum_partials_bn_kernel(const double* partial, int nblk, int c, double* out, BnFin f) {
+  __shared__ double sh[2];
+  const int ch = blockIdx.x, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int col = w * c + ch;
+  double t = 0.0;
+  for (int b = lane; b < nblk; b += 64) t += partial[(int64_t)b * 2 * c + col];
+#pragma unroll
+  for (int s = 32; s > 0; s >>= 1) t += __shfl_down(t, s, 64);
+  if (lane == 0) { out[col] = t; sh[w] = t; }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  if (ch == 0 && f.nbt) *f.nbt += 1;
+  const double mean = sh[0] / f.count;
+  double var = sh[1] / f.count - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const double invstd = 1.0 / sqrt(var + (double)f.eps);
+  const double g = f.gamma ? (double)f.gamma[ch] : 1.0, b = f.beta ? (double)f.beta[ch] : 0.0;
+  f.scale[ch] = (float)(g * invstd);
+  f.shift[ch] = (float)(b - mean * g * invstd);
+  if (f.smean) f.smean[ch] = mean;
+  if (f.sinv) f.sinv[ch] = invstd;
+  if (f.rm) f.rm[ch] = (float)((1.0 - f.momentum) * f.rm[ch] + f.momentum * mean);
+  if (f.rv) {
+    const double unb = f.count > 1.0 ? var * (f.count / (f.count - 1.0)) : var;
+    f.rv[ch] = (float)((1.0 - f.momentum) * f.rv[ch] + f.momentum * unb);
+  }
+}
+
+int bp_sum_partials_req(const double* partial, int nblk, int n, const IgemmStatsReq* sr, hipStream_t st) {
+  if (!sr->fin) return bp_sum_partials(partial, nblk, n, sr->sums, st);
+  hipLaunchKernelGGL(sum_partials_bn_kernel, dim3(n / 2), dim3(128), 0, st, partial, nblk, n / 2, sr->sums, *sr->fin);
+  BP_CHECK_LAUNCH();
+  return BP_OK;
+}
+
 // out[i] = sum over blocks of partial[b][i], fixed order (shared with pointwise_bf16.hip)
 int bp_sum_partials(const double* partial, int nblk, int n, double* out, hipStream_t st) {
   hipLaunchKernelGGL(sum_partials_wave_kernel, dim3(n), dim3(64), 0, st, partial, nblk, n, out);

@@ -29,6 +29,7 @@ EPILOGUE_FWD, EPILOGUE_BWD = _ES in ("1", "fwd", "auto"), _ES in ("1", "bwd", "a
 # "auto": the backward sums only from the flattened-K data-gradient kernels (conv_flat.hip: weights in registers, sums
 # per lane in LDS).  In the tiled igemm kernels the double-precision sums cost what the saved pass costs ("1": all).
 _BWD_KERNEL_IDS = (710000,) if _ES == "auto" else None
+FUSED_FINALIZE = os.environ.get("BP_FUSED_FINALIZE", "1") != "0"
 
 
 def _stream():
@@ -438,8 +439,22 @@ class ConvUnit:
         self.maybe_pack()
         hold = self.holder
         fused = training and self.fwd_stats
+        # single device: the batch-norm finalize rides on the launch that sums the epilogue's partial rows
+        fused_bn = fused and self.bn is not None and FUSED_FINALIZE \
+            and not (plan.sync is not None and plan.sync.sync_bn)
         t0 = plan.prof_begin()
-        if fused:
+        if fused_bn:
+            bn = self.bn
+            self.count = float(self.out.n * self.out.h * self.out.w)
+            dp = lambda t: None if t is None else t.data_ptr()
+            bt = L.BnTrain(self.count, dp(bn.weight), dp(bn.bias), float(bn.eps), float(bn.momentum),
+                           dp(bn.running_mean), dp(bn.running_var), dp(bn.num_batches_tracked),
+                           dp(self.out_pw.scale), dp(self.out_pw.shift), dp(self.save_mean), dp(self.save_invstd))
+            L.check(lib.bp_conv_forward_bn(C.byref(self.cv), C.byref(self.inp.view), self.inp.pw_struct(),
+                                           L.ptr(self.packed_fwd), C.byref(self.out.view), L.ptr(self.sums),
+                                           C.byref(bt), L.ptr(self._ws()), plan.ws_bytes, self._stats_impl, st),
+                    f"{self.name} forward + bn stats + finalize")
+        elif fused:
             L.check(lib.bp_conv_forward_stats(C.byref(self.cv), C.byref(self.inp.view), self.inp.pw_struct(),
                                               L.ptr(self.packed_fwd), C.byref(self.out.view), L.ptr(self.sums),
                                               L.ptr(self._ws()), plan.ws_bytes, self._stats_impl, st),
@@ -454,7 +469,7 @@ class ConvUnit:
         if self.act == "prelu":
             self.out_pw.slope.copy_(self.act_holder.weight.detach().expand(c))
         bn = self.bn
-        if bn is None:
+        if bn is None or fused_bn:
             return
         if training:
             if not fused:

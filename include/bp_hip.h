@@ -143,6 +143,22 @@ int bp_conv_backward_data_stats(const bp_conv* cv, const bp_view* dy, const floa
                                 const bp_view* x_raw, const bp_pointwise* x_pw, double* sums, void* workspace,
                                 size_t workspace_bytes, void* stream);
 
+/* bp_conv_forward_stats followed by bp_bn_finalize(sums, ...) of the produced tensor, with the finalize folded into
+ * the launch that sums the epilogue's partial rows (one small launch less per batch-norm layer and step; the same
+ * numbers bit for bit).  Single-device training only: under data parallelism the sums are all-reduced between the two
+ * calls (utils.py:146-147 on the global batch).  The fields are bp_bn_finalize's arguments. */
+typedef struct bp_bn_train {
+  double count;                       /* elements per channel: n * h * w of y */
+  const float* gamma; const float* beta; /* NULL: 1 / 0 */
+  float eps, momentum;
+  float* running_mean; float* running_var; int64_t* num_batches_tracked; /* updated in place; NULL: skipped */
+  float* scale; float* shift;         /* the pending batch-norm of y as a bp_pointwise */
+  double* save_mean; double* save_invstd; /* for bp_bn_backward_finalize; NULL: skipped */
+} bp_bn_train;
+int bp_conv_forward_bn(const bp_conv* cv, const bp_view* x, const bp_pointwise* x_pw, const float* packed_fwd,
+                       const bp_view* y, double* sums, const bp_bn_train* bn, void* workspace, size_t workspace_bytes,
+                       int impl, void* stream);
+
 /* dw (torch layout, overwritten) and optionally dbias (NULL to skip) from act(x) and dy. */
 size_t bp_conv_backward_weight_workspace(const bp_conv* cv, const bp_view* x, const bp_view* dy);
 int bp_conv_backward_weight(const bp_conv* cv, const bp_view* x, const bp_pointwise* x_pw,

@@ -164,3 +164,52 @@ def test_statistics_are_refused_where_the_kernel_has_none():
         xb, xv = G.empty_nhwc(n, h, w, cv.cin)
         yb, yv = G.empty_nhwc(n, h, w, cv.cout)
         assert lib.bp_conv_stats_workspace(C.byref(cv), L.PACK_FWD, C.byref(xv), C.byref(yv), L.IMPL_MFMA) == 0
+
+
+@pytest.mark.parametrize("case", [(0, 32, 32, 3, 1, 1, (4, 96, 96)), (0, 32, 64, 4, 2, 1, (5, 30, 44)), (0, 3, 16, 5, 1, 2, (3, 37, 70)),
+                                  (1, 32, 16, 4, 2, 1, (3, 9, 11))], ids=_ids)
+def test_forward_with_the_batch_norm_finalize_folded_in(case):
+    """bp_conv_forward_bn == bp_conv_forward_stats followed by bp_bn_finalize, bit for bit (sums, scale / shift,
+    saved statistics, running statistics, the batch counter)."""
+    lib = L.load()
+    tr, ci, co, k, s, p, (n, h, w) = case
+    rng = np.random.default_rng(ci + co + k)
+    x = rng.standard_normal((n, ci, h, w)).astype(np.float32)
+    wt = (rng.standard_normal(((ci, co) if tr else (co, ci)) + (k, k)) * 0.1).astype(np.float32)
+    ho = (h - 1) * s - 2 * p + k if tr else (h + 2 * p - k) // s + 1
+    wo = (w - 1) * s - 2 * p + k if tr else (w + 2 * p - k) // s + 1
+    cv = L.Conv(tr, ci, co, k, s, p, 0)
+    st = G.stream()
+    xb, xv = G.to_nhwc(x)
+    wd = G.dev(wt)
+    pf = torch.zeros(lib.bp_conv_packed_floats(C.byref(cv), L.PACK_FWD), device="cuda")
+    L.check(lib.bp_conv_pack(C.byref(cv), L.PACK_FWD, L.ptr(wd), L.ptr(pf), st))
+    gamma = torch.from_numpy(rng.uniform(0.5, 1.5, co).astype(np.float32)).cuda()
+    beta = torch.from_numpy(rng.uniform(-0.5, 0.5, co).astype(np.float32)).cuda()
+    out = []
+    for fused in (False, True):
+        yb, yv = G.empty_nhwc(n, ho, wo, co)
+        nb = lib.bp_conv_stats_workspace(C.byref(cv), L.PACK_FWD, C.byref(xv), C.byref(yv), L.IMPL_MFMA)
+        assert nb > 0
+        ws = torch.zeros(nb // 8 + 8, dtype=torch.float64, device="cuda")
+        sums = torch.zeros(3 * co, dtype=torch.float64, device="cuda")
+        rm, rv = torch.full((co,), 0.25, device="cuda"), torch.full((co,), 0.75, device="cuda")
+        nbt = torch.full((1,), 7, dtype=torch.int64, device="cuda")
+        scale, shift = torch.zeros(co, device="cuda"), torch.zeros(co, device="cuda")
+        sm, si = torch.zeros(co, dtype=torch.float64, device="cuda"), torch.zeros(co, dtype=torch.float64, device="cuda")
+        cnt = float(n * ho * wo)
+        if fused:
+            bt = L.BnTrain(cnt, gamma.data_ptr(), beta.data_ptr(), 1e-5, 0.1, rm.data_ptr(), rv.data_ptr(), nbt.data_ptr(),
+                           scale.data_ptr(), shift.data_ptr(), sm.data_ptr(), si.data_ptr())
+            L.check(lib.bp_conv_forward_bn(C.byref(cv), C.byref(xv), None, L.ptr(pf), C.byref(yv), L.ptr(sums), C.byref(bt),
+                                           L.ptr(ws), nb, L.IMPL_MFMA, st))
+        else:
+            L.check(lib.bp_conv_forward_stats(C.byref(cv), C.byref(xv), None, L.ptr(pf), C.byref(yv), L.ptr(sums),
+                                              L.ptr(ws), nb, L.IMPL_MFMA, st))
+            L.check(lib.bp_bn_finalize(L.ptr(sums), cnt, co, L.ptr(gamma), L.ptr(beta), 1e-5, 0.1, L.ptr(rm), L.ptr(rv),
+                                       L.ptr(nbt), L.ptr(scale), L.ptr(shift), L.ptr(sm), L.ptr(si), st))
+        torch.cuda.synchronize()
+        out.append([t.cpu().numpy().copy() for t in (yb, sums[:2 * co], scale, shift, sm, si, rm, rv, nbt)])
+    for a, b in zip(*out):
+        assert np.array_equal(a, b)
+    assert out[1][8][0] == 8
