@@ -8,6 +8,8 @@ changes nothing arithmetically if (a) batch-norm uses GLOBAL batch statistics --
 batch, cvae.py:129,144).  Gradients travel as ONE flat buffer (all parameters are views of a
 single allocation, see CVAE._flatten_parameters): 6.65 MB per step for the fiducial network.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -28,9 +30,12 @@ class Sync:
         self.world_size = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         self.sync_bn = sync_bn
-        self.grad_group = dist.new_group() if (grad_group == "new" and self.world_size > 1) else \
+        # BP_SYNC_FORCE=1: issue every collective even with one rank (a one-GPU box then drives the whole data-parallel
+        # schedule -- both communicators, both streams, the float64 statistics buffers -- through RCCL itself)
+        self.active = self.world_size > 1 or os.environ.get("BP_SYNC_FORCE") == "1"
+        self.grad_group = dist.new_group() if (grad_group == "new" and self.active) else \
             (group if grad_group in ("new", None) else grad_group)
-        self.overlap = self.grad_group is not group and self.world_size > 1
+        self.overlap = self.grad_group is not group and self.active
         self.n_small = self.n_grad = 0
         self.bytes_grad = 0
         self.timing = None           # bench.py: list of (start event, end event, kind) while enabled
@@ -55,14 +60,14 @@ class Sync:
 
     def all_reduce_sum(self, t):
         """Batch-norm statistics (float64 vector of 2*C entries per layer of a level)."""
-        if self.sync_bn and self.world_size > 1:
+        if self.sync_bn and self.active:
             with self._timed("bn"):
                 dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
             self.n_small += 1
 
     def all_reduce_mean(self, flat):
         """A gradient buffer (or a contiguous slice of one), on the CURRENT stream."""
-        if self.world_size > 1:
+        if self.active:
             with self._timed("grad"):
                 dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.grad_group)
                 flat.mul_(1.0 / self.world_size)

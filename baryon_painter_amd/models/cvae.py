@@ -468,7 +468,7 @@ class _Plan:
         communicator of ``dist.Sync`` (the batch-norm statistics keep flowing on the main stream's own).
         Returns the slice it covered, or None."""
         sync, sl = self.model.sync, self.model._early_slice
-        if sync is None or sync.world_size == 1 or not sync.overlap or sl is None or self.side is None \
+        if sync is None or not getattr(sync, "active", sync.world_size > 1) or not sync.overlap or sl is None or self.side is None \
                 or os.environ.get("BP_EARLY_ALLREDUCE", "1") == "0":
             return None
         main = torch.cuda.current_stream(self.device)

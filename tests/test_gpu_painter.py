@@ -132,6 +132,62 @@ def test_two_rank_data_parallel_equals_single_device(tmp_path):
     assert (tmp_path / "dp.ok").exists()
 
 
+_RCCL_ONE_RANK_WORKER = r"""
+import os, sys
+sys.path.insert(0, sys.argv[1])
+os.environ["BP_SYNC_FORCE"] = "1"           # issue every collective although there is one rank
+import numpy as np, torch, torch.distributed as dist
+from baryon_painter_amd.dist import Sync
+from baryon_painter_amd.models import arch as A
+from baryon_painter_amd.models.cvae import CVAE
+from baryon_painter_amd.utils import synthetic as syn
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+size, n = 64, 4
+arch = A.fiducial_architecture(size)
+x, y, aux = syn.synthetic_batch(n, size, size, seed=21)
+eps = syn.synthetic_eps((1, n, *arch["dim_z"]), seed=22)
+def run(sync):
+    m = CVAE(arch, "cuda:0", sync=sync)
+    P = syn.fill_params({k: tuple(p.shape) for k, p in m.named_parameters()}, 7)
+    with torch.no_grad():
+        for k, p in m.named_parameters(): p.copy_(torch.from_numpy(P[k]))
+    m._eps_override = eps
+    e = m(torch.from_numpy(x), torch.from_numpy(y), torch.from_numpy(aux))
+    (-e).backward()
+    torch.cuda.synchronize()
+    return m, float(e.detach())
+sync = Sync()
+assert sync.active and sync.overlap and sync.grad_group is not sync.group
+dp, e_dp = run(sync)
+assert sync.n_small == 44 and sync.n_grad >= 1, (sync.n_small, sync.n_grad)
+ref, e_ref = run(None)
+assert abs(e_dp - e_ref) <= 1e-6 * abs(e_ref), (e_dp, e_ref)
+worst = 0.0
+for (k, a), (_, b) in zip(dp.named_parameters(), ref.named_parameters()):
+    worst = max(worst, float((a.grad.double() - b.grad.double()).abs().max() / b.grad.double().abs().max().clamp_min(1e-30)))
+assert worst < 2e-4, worst
+open(os.path.join(sys.argv[2], "rccl.ok"), "w").write(str(worst))
+dist.destroy_process_group()
+"""
+
+
+def test_data_parallel_schedule_through_rccl_with_one_rank(tmp_path):
+    """What a one-GPU box can check of the N > 1 path: with BP_SYNC_FORCE=1 one rank issues every collective of the
+    data-parallel step through RCCL (backend nccl): float64 statistics on the main stream's communicator, gradient
+    slices on the weight-gradient stream's second communicator; the result is the single-device one."""
+    import socket
+    script = tmp_path / "rccl_worker.py"
+    script.write_text(_RCCL_ONE_RANK_WORKER)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, str(script), ROOT, str(tmp_path)], capture_output=True, text=True, env=env,
+                         timeout=600)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    assert (tmp_path / "rccl.ok").exists()
+
+
 def test_graphed_paint_matches_eager_statistics():
     """The hipGraph-captured eval forward draws its own noise; with the prior variance forced to ~0
     (z_log_var -> very negative is impossible after ReLU, so compare through fixed z instead):
