@@ -58,29 +58,62 @@ __global__ __launch_bounds__(256) void small_conv_kernel(SmallArgs a) {
     if (CI >= 4) {
       const int c4 = tid % CQ;
       const PW4 p4 = pw4_load(a.pw, c0 + c4 * 4, CT);
-      for (int e = tid; e < IH * IW * CQ; e += 256) {
-        const int pix = e / CQ;
-        const int c = pix % IW, r = pix / IW;
-        const int iy = y0 + a.i0 + r, ix = x0 + a.i0 + c;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (iy >= 0 && iy < a.in_h && ix >= 0 && ix < a.in_w) {
-          const float* p = in_n + ((int64_t)iy * a.in_w + ix) * a.in_cs + c0 + c4 * 4;
-          if (a.in_vec) v = *reinterpret_cast<const float4*>(p);
-          else v = make_float4(p[0], p[1], p[2], p[3]);
-          v = pw4_apply4(p4, v);
+      // four units per trip, loaded unconditionally from clamped coordinates before the first is used (a load under
+      // a per-lane condition is waited for on the spot: the staging loop was one HBM round trip per unit)
+      constexpr int NU = IH * IW * CQ;
+      for (int e0 = tid; e0 < NU; e0 += 4 * 256) {
+        float4 v[4];
+        bool ok[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int e = min(e0 + j * 256, NU - 1);
+          const int pix = e / CQ;
+          const int c = pix % IW, r = pix / IW;
+          const int iy = y0 + a.i0 + r, ix = x0 + a.i0 + c;
+          ok[j] = iy >= 0 && iy < a.in_h && ix >= 0 && ix < a.in_w;
+          const int cy = min(max(iy, 0), a.in_h - 1), cx = min(max(ix, 0), a.in_w - 1);
+          const float* p = in_n + ((int64_t)cy * a.in_w + cx) * a.in_cs + c0 + c4 * 4;
+          if (a.in_vec) v[j] = *reinterpret_cast<const float4*>(p);
+          else v[j] = make_float4(p[0], p[1], p[2], p[3]);
         }
-        *reinterpret_cast<float4*>(tile + ((r * CQ + c4) * IW + c) * 4) = v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int e = e0 + j * 256;
+          if (e < NU) {
+            const int pix = e / CQ;
+            const int c = pix % IW, r = pix / IW;
+            const float4 w = pw4_apply4(p4, v[j]);
+            *reinterpret_cast<float4*>(tile + ((r * CQ + c4) * IW + c) * 4) =
+                ok[j] ? w : make_float4(0.f, 0.f, 0.f, 0.f);
+          }
+        }
       }
     } else {
-      for (int e = tid; e < IH * IW * CI; e += 256) {
-        const int ch = e % CI;
-        const int pix = e / CI;
-        const int c = pix % IW, r = pix / IW;
-        const int iy = y0 + a.i0 + r, ix = x0 + a.i0 + c;
-        float v = 0.f;
-        if (iy >= 0 && iy < a.in_h && ix >= 0 && ix < a.in_w)
-          v = pw_apply(a.pw, c0 + ch, in_n[((int64_t)iy * a.in_w + ix) * a.in_cs + c0 + ch]);
-        tile[(r * IW + c) * CI + ch] = v;
+      constexpr int NE = IH * IW * CI;
+      for (int e0 = tid; e0 < NE; e0 += 4 * 256) {      // (four loads in flight, as above)
+        float v[4];
+        bool ok[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int e = min(e0 + j * 256, NE - 1);
+          const int ch = e % CI;
+          const int pix = e / CI;
+          const int c = pix % IW, r = pix / IW;
+          const int iy = y0 + a.i0 + r, ix = x0 + a.i0 + c;
+          ok[j] = iy >= 0 && iy < a.in_h && ix >= 0 && ix < a.in_w;
+          const int cy = min(max(iy, 0), a.in_h - 1), cx = min(max(ix, 0), a.in_w - 1);
+          v[j] = in_n[((int64_t)cy * a.in_w + cx) * a.in_cs + c0 + ch];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int e = e0 + j * 256;
+          if (e < NE) {
+            const int ch = e % CI;
+            const int pix = e / CI;
+            const int c = pix % IW, r = pix / IW;
+            tile[(r * IW + c) * CI + ch] = ok[j] ? pw_apply(a.pw, c0 + ch, v[j]) : 0.f;
+          }
+        }
       }
     }
     __syncthreads();
