@@ -96,30 +96,63 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(WsArgs a) {
       if (CXS >= 4 && a.xvec) {
         constexpr int C4 = CXS >= 4 ? CXS / 4 : 1;
         const int c4 = tid % C4, ch = c4 * 4;
-        for (int e = tid; e < XR * XW * C4; e += 256) {
-          const int pix = e / C4;
-          const int c = pix % XW, r = pix / XW;
-          const int iy = S * qy0 - a.pad + r, ix = S * qx0 - a.pad + c;
-          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (ch < a.cx && iy >= 0 && iy < a.xh && ix >= 0 && ix < a.xw) {
-            v = *reinterpret_cast<const float4*>(Xn + ((int64_t)iy * a.xw + ix) * a.xcs + ch);
-            v = pw4_apply4(px4, v);
-            if (ch + 1 >= a.cx) v.y = 0.f;
-            if (ch + 2 >= a.cx) v.z = 0.f;
-            if (ch + 3 >= a.cx) v.w = 0.f;
+        // four units per trip, loaded unconditionally from clamped coordinates before the first is used (a load
+        // under a per-lane condition is waited for on the spot)
+        constexpr int NUX = XR * XW * C4;
+        const int chs = ch < a.cx ? ch : 0;                  // (a quad past the view is zeroed below: any address inside it)
+        for (int e0 = tid; e0 < NUX; e0 += 4 * 256) {
+          float4 v[4];
+          bool ok[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int e = min(e0 + j * 256, NUX - 1);
+            const int pix = e / C4;
+            const int c = pix % XW, r = pix / XW;
+            const int iy = S * qy0 - a.pad + r, ix = S * qx0 - a.pad + c;
+            ok[j] = ch < a.cx && iy >= 0 && iy < a.xh && ix >= 0 && ix < a.xw;
+            const int cy = min(max(iy, 0), a.xh - 1), cx_ = min(max(ix, 0), a.xw - 1);
+            v[j] = *reinterpret_cast<const float4*>(Xn + ((int64_t)cy * a.xw + cx_) * a.xcs + chs);
           }
-          *reinterpret_cast<float4*>(xs + (r * XWS + c) * CXS + ch) = v;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int e = e0 + j * 256;
+            if (e < NUX) {
+              const int pix = e / C4;
+              const int c = pix % XW, r = pix / XW;
+              float4 w = pw4_apply4(px4, v[j]);
+              if (ch + 1 >= a.cx) w.y = 0.f;
+              if (ch + 2 >= a.cx) w.z = 0.f;
+              if (ch + 3 >= a.cx) w.w = 0.f;
+              *reinterpret_cast<float4*>(xs + (r * XWS + c) * CXS + ch) = ok[j] ? w : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+          }
         }
       } else {
-        for (int e = tid; e < XR * XW * CXS; e += 256) {
-          const int ch = e % CXS;
-          const int pix = e / CXS;
-          const int c = pix % XW, r = pix / XW;
-          const int iy = S * qy0 - a.pad + r, ix = S * qx0 - a.pad + c;
-          float v = 0.f;
-          if (ch < a.cx && iy >= 0 && iy < a.xh && ix >= 0 && ix < a.xw)
-            v = pw_apply(a.pwx, ch, Xn[((int64_t)iy * a.xw + ix) * a.xcs + ch]);
-          xs[(r * XWS + c) * CXS + ch] = v;
+        constexpr int NEX = XR * XW * CXS;
+        for (int e0 = tid; e0 < NEX; e0 += 4 * 256) {
+          float v[4];
+          bool ok[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int e = min(e0 + j * 256, NEX - 1);
+            const int ch = e % CXS;
+            const int pix = e / CXS;
+            const int c = pix % XW, r = pix / XW;
+            const int iy = S * qy0 - a.pad + r, ix = S * qx0 - a.pad + c;
+            ok[j] = ch < a.cx && iy >= 0 && iy < a.xh && ix >= 0 && ix < a.xw;
+            const int cy = min(max(iy, 0), a.xh - 1), cx_ = min(max(ix, 0), a.xw - 1);
+            v[j] = Xn[((int64_t)cy * a.xw + cx_) * a.xcs + (ch < a.cx ? ch : 0)];
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int e = e0 + j * 256;
+            if (e < NEX) {
+              const int ch = e % CXS;
+              const int pix = e / CXS;
+              const int c = pix % XW, r = pix / XW;
+              xs[(r * XWS + c) * CXS + ch] = ok[j] ? pw_apply(a.pwx, ch, v[j]) : 0.f;
+            }
+          }
         }
       }
       // the 3 slack columns of each row are only read by k-steps whose outputs are discarded,
@@ -135,30 +168,59 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(WsArgs a) {
       if (CYS >= 4 && a.yvec) {
         constexpr int C4 = CYS >= 4 ? CYS / 4 : 1;
         const int c4 = tid % C4, ch = c4 * 4;
-        for (int e = tid; e < BH * 32 * C4; e += 256) {
-          const int pix = e / C4;
-          const int c = pix & 31, r = pix >> 5;
-          const int qy = qy0 + r, qx = qx0 + c;
-          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (ch < a.cy && qy < a.yh && qx < a.yw) {
-            v = *reinterpret_cast<const float4*>(Yn + ((int64_t)qy * a.yw + qx) * a.ycs + ch);
-            v = pw4_apply4(py4, v);
-            if (ch + 1 >= a.cy) v.y = 0.f;
-            if (ch + 2 >= a.cy) v.z = 0.f;
-            if (ch + 3 >= a.cy) v.w = 0.f;
+        constexpr int NUY = BH * 32 * C4;
+        const int chs = ch < a.cy ? ch : 0;
+        for (int e0 = tid; e0 < NUY; e0 += 4 * 256) {
+          float4 v[4];
+          bool ok[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int e = min(e0 + j * 256, NUY - 1);
+            const int pix = e / C4;
+            const int c = pix & 31, r = pix >> 5;
+            const int qy = qy0 + r, qx = qx0 + c;
+            ok[j] = ch < a.cy && qy < a.yh && qx < a.yw;
+            v[j] = *reinterpret_cast<const float4*>(Yn + ((int64_t)min(qy, a.yh - 1) * a.yw + min(qx, a.yw - 1)) * a.ycs + chs);
           }
-          *reinterpret_cast<float4*>(ys + ((PADR + r) * YWS + c) * CYS + ch) = v;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int e = e0 + j * 256;
+            if (e < NUY) {
+              const int pix = e / C4;
+              const int c = pix & 31, r = pix >> 5;
+              float4 w = pw4_apply4(py4, v[j]);
+              if (ch + 1 >= a.cy) w.y = 0.f;
+              if (ch + 2 >= a.cy) w.z = 0.f;
+              if (ch + 3 >= a.cy) w.w = 0.f;
+              *reinterpret_cast<float4*>(ys + ((PADR + r) * YWS + c) * CYS + ch) = ok[j] ? w : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+          }
         }
       } else {
-        for (int e = tid; e < BH * 32 * CYS; e += 256) {
-          const int ch = e % CYS;
-          const int pix = e / CYS;
-          const int c = pix & 31, r = pix >> 5;
-          const int qy = qy0 + r, qx = qx0 + c;
-          float v = 0.f;
-          if (ch < a.cy && qy < a.yh && qx < a.yw)
-            v = pw_apply(a.pwy, ch, Yn[((int64_t)qy * a.yw + qx) * a.ycs + ch]);
-          ys[((PADR + r) * YWS + c) * CYS + ch] = v;
+        constexpr int NEY = BH * 32 * CYS;
+        for (int e0 = tid; e0 < NEY; e0 += 4 * 256) {
+          float v[4];
+          bool ok[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int e = min(e0 + j * 256, NEY - 1);
+            const int ch = e % CYS;
+            const int pix = e / CYS;
+            const int c = pix & 31, r = pix >> 5;
+            const int qy = qy0 + r, qx = qx0 + c;
+            ok[j] = ch < a.cy && qy < a.yh && qx < a.yw;
+            v[j] = Yn[((int64_t)min(qy, a.yh - 1) * a.yw + min(qx, a.yw - 1)) * a.ycs + (ch < a.cy ? ch : 0)];
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int e = e0 + j * 256;
+            if (e < NEY) {
+              const int ch = e % CYS;
+              const int pix = e / CYS;
+              const int c = pix & 31, r = pix >> 5;
+              ys[((PADR + r) * YWS + c) * CYS + ch] = ok[j] ? pw_apply(a.pwy, ch, v[j]) : 0.f;
+            }
+          }
         }
       }
     }
