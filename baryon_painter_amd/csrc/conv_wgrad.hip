@@ -10,6 +10,7 @@
 // are summed through LDS at the end.  Partial results per split go to a workspace and a second
 // kernel adds them in a fixed order, so the gradient is bitwise reproducible (no float atomics).
 #include "common.hpp"
+#include <cstdlib>
 
 namespace {
 
@@ -339,8 +340,20 @@ static size_t wgrad_general_workspace(const bp_conv* cv, const bp_view* X, const
   return p.ok ? p.ws_bytes : 0;
 }
 
+void bp_wgrad_tiles_target(int target);      // conv_wgrad_tiles.hip
+namespace {
+struct SharedTarget {                        // for the duration of one bp_wgrad_mfma call on this thread
+  explicit SharedTarget(bool shared) {
+    static const int t = getenv("BP_WT_SHARED_TARGET") ? atoi(getenv("BP_WT_SHARED_TARGET")) : 448;
+    bp_wgrad_tiles_target(shared ? t : 0);
+  }
+  ~SharedTarget() { bp_wgrad_tiles_target(0); }
+};
+}  // namespace
+
 int bp_wgrad_mfma(const bp_conv* cv, const bp_view* X, const PW& pwx, const bp_view* Y, const PW& pwy,
                   float* dst, void* workspace, size_t workspace_bytes, hipStream_t st, bool shared) {
+  const SharedTarget guard(shared);
   if (bp_stem_wgrad_ok(cv, X, Y, pwy, nullptr)) return bp_stem_wgrad(X, pwx, Y, dst, workspace, workspace_bytes, st);
   if (bp_wgrad_flat_ok(cv, X, Y, pwy)) return bp_wgrad_flat(X, pwx, Y, dst, workspace, workspace_bytes, st, shared);
   if (bp_wgrad_flat_s2_ok(cv, X, Y, pwx, pwy))

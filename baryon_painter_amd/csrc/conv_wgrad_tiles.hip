@@ -19,6 +19,13 @@
 #include "common.hpp"
 #include <cstdlib>
 
+// Workgroup-count target of the next launches on this thread (0: the default).  bp_wgrad_mfma sets it for a launch that
+// runs on a side stream beside the data-gradient chain (BP_IMPL_SHARED): measured on the fiducial step, 512 workgroups
+// (two per CU, the best alone) is the WORST choice there -- 320 ... 448 and 640 ... 768 all give a shorter step, 448 the
+// shortest (43.4 -> 42.9 ms): a grid that does not fill every CU twice leaves room for the main chain's workgroups.
+static thread_local int t_wt_target = 0;
+void bp_wgrad_tiles_target(int target) { t_wt_target = target; }
+
 namespace {
 
 typedef float v4f __attribute__((ext_vector_type(4)));
@@ -574,7 +581,10 @@ int launch(const bp_conv* cv, const bp_view* X, const PW& pwx, const bp_view* Y,
   const int kyg = bp_ceil_div(cv->k, KHB);
   const int64_t ntiles = (int64_t)Y->n * a.tiles_x * a.tiles_y;
   const int64_t base = (int64_t)a.ncxb * ncyb * kyg;
-  int64_t ns = (512 + base - 1) / base;      // ~2 workgroups per CU
+  // ~2 workgroups per CU alone; fewer when the launch shares the GPU with the data-gradient chain (bp_wgrad_tiles_target)
+  static const int wt_target = getenv("BP_WT_TARGET") ? atoi(getenv("BP_WT_TARGET")) : 512;
+  const int target = (!dry && t_wt_target > 0 && t_wt_target < wt_target) ? t_wt_target : wt_target;
+  int64_t ns = (target + base - 1) / base;
   if (ns > ntiles) ns = ntiles;
   if (ns < 1) ns = 1;
   if (ns > 65535) ns = 65535;
