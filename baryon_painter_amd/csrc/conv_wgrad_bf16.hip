@@ -386,7 +386,8 @@ int wb_launch(const bp_conv* cv, const bp_view* X, const PW& pwx, const bp_view*
   const int kyg = bp_ceil_div(cv->k, KHB);
   const int64_t ntiles = (int64_t)Y->n * a.tiles_x * a.tiles_y;
   const int64_t base = (int64_t)a.ncxb * ncyb * kyg;
-  int64_t ns = (1024 + base - 1) / base;     // ~4 workgroups per CU
+  static const int wb_target = getenv("BP_WB_TARGET") ? atoi(getenv("BP_WB_TARGET")) : 1024;
+  int64_t ns = (wb_target + base - 1) / base;     // ~4 workgroups per CU
   if (ns > ntiles) ns = ntiles;
   if (ns < 1) ns = 1;
   if (ns > 65535) ns = 65535;

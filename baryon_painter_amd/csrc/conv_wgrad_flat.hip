@@ -191,7 +191,8 @@ int shared_grid(int grid, bool shared) {
         hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256;
     return n > 0 ? n : 256;
   }();
-  return shared && grid > cus ? cus : grid;
+  static const int cap = getenv("BP_WFLAT_SHARED_GRID") ? atoi(getenv("BP_WFLAT_SHARED_GRID")) : cus;
+  return shared && grid > cap ? cap : grid;
 }
 
 int flat_grid(int ntiles) {
