@@ -583,7 +583,10 @@ int launch(const bp_conv* cv, const bp_view* X, const PW& pwx, const bp_view* Y,
   const int64_t base = (int64_t)a.ncxb * ncyb * kyg;
   // ~2 workgroups per CU alone; fewer when the launch shares the GPU with the data-gradient chain (bp_wgrad_tiles_target)
   static const int wt_target = getenv("BP_WT_TARGET") ? atoi(getenv("BP_WT_TARGET")) : 512;
-  const int target = (!dry && t_wt_target > 0 && t_wt_target < wt_target) ? t_wt_target : wt_target;
+  // (only launches of about a millisecond: a long one -- the CGAN's 256 -> 512 layers run 5 - 18 ms -- loses more to the
+  //  uneven grid than the main chain gains: CGAN iteration 345.8 ms at 512, 348.7 at 448)
+  const double flop = 2.0 * (double)Y->n * Y->h * Y->w * cv->k * cv->k * X->c * Y->c;
+  const int target = (!dry && t_wt_target > 0 && t_wt_target < wt_target && flop < 1.5e11) ? t_wt_target : wt_target;
   int64_t ns = (target + base - 1) / base;
   if (ns > ntiles) ns = ntiles;
   if (ns < 1) ns = 1;
