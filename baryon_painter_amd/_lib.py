@@ -93,6 +93,7 @@ SIGNATURES = {
     "bp_paint_load": (C.c_int, [_P, C.c_int32, _P, _P, C.c_int32, _VP, _P]),
     "bp_paint_store": (C.c_int, [_VP, _PWP, C.c_int32, _P, _P, _P]),
     "bp_philox_normal": (C.c_int, [C.c_uint64, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P]),
+    "bp_philox_normal_dev": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P]),
     "bp_latent_forward": (C.c_int, [C.POINTER(Latent), _VP, _PWP, _VP, _PWP, _P, _P, _VP, _P, _P,
                                     C.c_size_t, _P]),
     "bp_latent_backward": (C.c_int, [C.POINTER(Latent), _VP, _P, _P, _P, C.c_float, _VP, _VP, _P]),

@@ -65,8 +65,11 @@ __device__ __forceinline__ void philox_round(unsigned (&c)[4], unsigned k0, unsi
 
 // eps[(l * n + s) * per_tile + i], i = 4 * g + r: r-th normal of Philox block (g, l, tile id) under key = seed.
 // Box-Muller in double on the uniforms u1 = (x + 1) / 2^32 in (0, 1], u2 = x / 2^32 in [0, 1).
-__global__ __launch_bounds__(RB) void philox_normal_kernel(unsigned long long seed, const long long* tile_ids, int n,
-                                                           int L, int per_tile, float* eps) {
+// (seed_dev != nullptr: the key is read from device memory, so that a captured graph serves every seed)
+__global__ __launch_bounds__(RB) void philox_normal_kernel(unsigned long long seed, const unsigned long long* seed_dev,
+                                                           const long long* tile_ids, int n, int L, int per_tile,
+                                                           float* eps) {
+  if (seed_dev) seed = *seed_dev;
   const int groups = (per_tile + 3) / 4;
   const int64_t i = (int64_t)blockIdx.x * RB + threadIdx.x;
   if (i >= (int64_t)L * n * groups) return;
@@ -128,7 +131,19 @@ int bp_philox_normal(uint64_t seed, const int64_t* tile_ids, int32_t n, int32_t 
   if (!tile_ids || n <= 0 || L <= 0 || per_tile <= 0 || !eps) return BP_EINVAL;
   const int64_t total = (int64_t)L * n * ((per_tile + 3) / 4);
   hipLaunchKernelGGL(philox_normal_kernel, dim3(nblocks(total)), dim3(RB), 0, bp_stream(stream),
-                     (unsigned long long)seed, reinterpret_cast<const long long*>(tile_ids), n, L, per_tile, eps);
+                     (unsigned long long)seed, (const unsigned long long*)nullptr,
+                     reinterpret_cast<const long long*>(tile_ids), n, L, per_tile, eps);
+  BP_CHECK_LAUNCH();
+  return BP_OK;
+}
+
+int bp_philox_normal_dev(const uint64_t* seed_dev, const int64_t* tile_ids, int32_t n, int32_t L, int32_t per_tile,
+                         float* eps, void* stream) {
+  if (!seed_dev || !tile_ids || n <= 0 || L <= 0 || per_tile <= 0 || !eps) return BP_EINVAL;
+  const int64_t total = (int64_t)L * n * ((per_tile + 3) / 4);
+  hipLaunchKernelGGL(philox_normal_kernel, dim3(nblocks(total)), dim3(RB), 0, bp_stream(stream), 0ull,
+                     reinterpret_cast<const unsigned long long*>(seed_dev),
+                     reinterpret_cast<const long long*>(tile_ids), n, L, per_tile, eps);
   BP_CHECK_LAUNCH();
   return BP_OK;
 }

@@ -18,12 +18,19 @@ class Sync:
     """Collectives the launch plan needs.  ``sync_bn=False`` keeps batch-norm statistics local
     (throughput mode: different arithmetic from the single-device reference)."""
 
-    def __init__(self, group=None, sync_bn=True, grad_group="new"):
-        """``group``: communicator of the batch-norm statistics (latency-bound, on the critical path, main stream).
-        ``grad_group``: communicator of the gradient buffers -- a SECOND one ("new": created here, collectively, by
-        every rank), so that a gradient all-reduce may be in flight on the weight-gradient stream while statistics
-        are reduced on the main stream: collectives of ONE communicator must be issued in the same order on every
-        rank and therefore cannot be spread over streams; two communicators can.  None: share ``group``."""
+    def __init__(self, group=None, sync_bn=True, grad_group=None):
+        """``group``: communicator of every collective (batch-norm statistics: latency-bound, on the critical path, main
+        stream; the flat gradient buffer: once, after the backward pass).  All collectives are issued by one host
+        thread in program order on ONE communicator, so their order is the same on every rank by construction.
+
+        ``grad_group``: opt-in SECOND communicator for the gradient buffers ("new": created here, collectively, by
+        every rank; also selected by BP_EARLY_ALLREDUCE=1).  With it the generator trunk's gradients are reduced
+        early, on the weight-gradient stream, while statistics keep flowing on the main stream's communicator
+        (cvae._Plan._reduce_trunk_gradients).  That puts two communicators' collectives in flight concurrently, whose
+        relative order across ranks RCCL does not guarantee; it has only been exercised with gloo and with one rank
+        (profiles/r02_rccl_one_rank.txt), so it is OFF by default until a multi-GPU RCCL run has validated it
+        (tests/test_gpu_painter.py::test_two_gpu_rccl_data_parallel, skipped on one-GPU boxes).  The flat all-reduce
+        it replaces costs ~0.1-0.2 ms of exposed latency per step (6.65 MB over xGMI)."""
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed is not initialised")
         self.group = group
@@ -31,8 +38,10 @@ class Sync:
         self.rank = dist.get_rank(group)
         self.sync_bn = sync_bn
         # BP_SYNC_FORCE=1: issue every collective even with one rank (a one-GPU box then drives the whole data-parallel
-        # schedule -- both communicators, both streams, the float64 statistics buffers -- through RCCL itself)
+        # schedule -- the float64 statistics buffers, the gradient buffer -- through RCCL itself)
         self.active = self.world_size > 1 or os.environ.get("BP_SYNC_FORCE") == "1"
+        if grad_group is None and os.environ.get("BP_EARLY_ALLREDUCE", "0") == "1":
+            grad_group = "new"
         self.grad_group = dist.new_group() if (grad_group == "new" and self.active) else \
             (group if grad_group in ("new", None) else grad_group)
         self.overlap = self.grad_group is not group and self.active

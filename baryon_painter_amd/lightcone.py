@@ -53,13 +53,19 @@ def make_weight_map(tile_shape, falloff=0.05, sigma=1):
 
 
 def paint_plane(painter, delta, tile_relative_size, n_pixel_tile, z, min_tile_overlap=0.5, falloff=0.05,
-                sigma=0.5, regularise_std=None, batch_size=64, seed=0, first_tile_id=0):
+                sigma=0.5, regularise_std=None, batch_size=64, seed=None, first_tile_id=0):
     """Paint a periodic mass plane tile by tile and blend (the inner loop of ``process_SLICS``,
     process_SLICS.py:198-220): tiles are cut with wrap-around, resampled to the network's tile size
     if necessary, painted in batches, weighted by ``make_weight_map`` and accumulated.
 
     Painters with a ``paint_stream`` (CVAEPainter) paint all tiles of the plane through the pipelined device path;
-    tile (j, k) of the plane draws its prior noise under the id ``first_tile_id + j * n_side + k`` and ``seed``."""
+    tile (j, k) of the plane draws its prior noise from Philox under the key ``seed`` and the counter
+    ``first_tile_id + j * n_side + k``.  ``seed=None`` (default) draws a FRESH key from torch's global generator for
+    every call: like the reference (fresh ``torch.randn`` per tile, cvae.py:64) two planes never share their latent
+    noise unless asked to, and ``torch.manual_seed`` makes a whole light cone reproducible.  Pass an explicit ``seed``
+    (+ distinct ``first_tile_id`` ranges) to reproduce one plane.  Painters / transforms the device pipeline has no
+    form for (modes other than 'shift-log', no transform, several label fields, L != 1, no prior network) go through
+    ``paint_batch`` as before."""
     n_plane = int(n_pixel_tile / tile_relative_size)
     origins, slices = generate_tiling(n_plane, n_pixel_tile, min_tile_overlap)
     tiles = []
@@ -70,10 +76,18 @@ def paint_plane(painter, delta, tile_relative_size, n_pixel_tile, z, min_tile_ov
                 import scipy.ndimage
                 t = scipy.ndimage.zoom(t, zoom=n_pixel_tile / t.shape[0], mode="reflect")
             tiles.append(np.asarray(t, dtype=np.float32))
+    painted = None
     if hasattr(painter, "paint_stream"):
+        if seed is None:
+            import torch
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item())
         ids = first_tile_id + np.arange(len(tiles), dtype=np.int64)
-        painted = painter.paint_stream(np.stack(tiles), z, batch_size=min(batch_size, len(tiles)), tile_ids=ids, seed=seed)
-    else:
+        try:
+            painted = painter.paint_stream(np.stack(tiles), z, batch_size=min(batch_size, len(tiles)), tile_ids=ids,
+                                           seed=seed)
+        except NotImplementedError:
+            painted = None                   # no device form of this painter's transform / architecture
+    if painted is None:
         painted = painter.paint_batch(np.stack(tiles), z, batch_size=batch_size)
     plane = np.zeros((n_plane, n_plane))
     weight = np.zeros((n_plane, n_plane))

@@ -469,7 +469,7 @@ class _Plan:
         Returns the slice it covered, or None."""
         sync, sl = self.model.sync, self.model._early_slice
         if sync is None or not getattr(sync, "active", sync.world_size > 1) or not sync.overlap or sl is None or self.side is None \
-                or os.environ.get("BP_EARLY_ALLREDUCE", "1") == "0":
+                or os.environ.get("BP_EARLY_ALLREDUCE", "0") != "1":
             return None
         main = torch.cuda.current_stream(self.device)
         self.side.wait_stream(main)          # batch-norm / PReLU parameter gradients are written on the main stream
@@ -764,13 +764,20 @@ class CVAE(torch.nn.Module):
         return g["out"].clone()
 
     def paint_graph(self, n):
-        """The captured paint pipeline for batches of ``n`` RAW tiles (configs[4]): buffers to fill -- ``raw`` (n, cy, H,
-        W) untransformed input tiles, ``aux`` (n, 1) redshifts, ``xf_in`` / ``xf_out`` (n, 2) float64 {sigma, k} /
-        {k, sigma} of the shift-log transform and its inverse, ``tile_ids`` (n,) int64 global tile numbers, ``seed``
-        -- and ``graph.replay()``, which leaves the painted physical tiles in ``out`` (n, cx, H, W)."""
+        """The captured paint pipeline for batches of ``n`` RAW tiles (configs[4]).  Returns a dict with ``slots``: TWO
+        input / parameter / output buffer sets, each with its own captured graph over the SAME launch plans, so that a
+        caller uploads batch b+1 straight into one slot and downloads batch b-1 straight out of it while the other
+        slot's graph paints batch b -- no device-to-device staging copy.  A slot holds
+          ``raw`` (n, cy, H, W) untransformed input tiles, ``out`` (n, cx, H, W) painted physical tiles,
+          ``block`` one uint8 device buffer with the typed views ``xf_in`` / ``xf_out`` (n, 2) float64 {sigma, k} /
+          {k, sigma} of the shift-log transform and its inverse, ``tile_ids`` (n,) int64 global tile numbers, ``seed``
+          (1,) int64 Philox key (read by the kernel at run time: one graph serves every seed), ``aux`` (n, 1) float32
+          redshifts (``block_layout``: name -> (byte offset, dtype, shape) for a pinned host mirror),
+          ``graph``; ``graph.replay()`` leaves the painted tiles of ``raw`` in ``out``.
+        The two graphs share activations: replay them on ONE stream."""
         if self.training:
             raise RuntimeError("paint_graph is an eval-mode (paint) path: call model.train(False) first")
-        key = (n, "pipeline", int(getattr(self, "paint_seed", 0)))
+        key = (n, "pipeline")
         g = self._graphs.get(key)
         if g is None:
             g = self._capture_paint_graph(n, pipeline=True)
@@ -786,20 +793,36 @@ class CVAE(torch.nn.Module):
         stream)."""
         cy, H, W = self.dim_y
         cx = self.dim_x[0]
-        st = {"y": torch.zeros((n, cy, H, W), device=self.device),
-              "aux": torch.zeros((n, self.n_aux), device=self.device) if self.use_aux_label else None,
-              "out": torch.zeros((n, cx, H, W), device=self.device),
+        st = {"y": None if pipeline else torch.zeros((n, cy, H, W), device=self.device),
+              "aux": torch.zeros((n, self.n_aux), device=self.device) if self.use_aux_label and not pipeline else None,
+              "out": None if pipeline else torch.zeros((n, cx, H, W), device=self.device),
               "z": torch.zeros((n, *self.dim_z), device=self.device) if given_z else None}
         if pipeline:
             if self.L != 1 or self.prior_network is None:
                 raise NotImplementedError("the paint pipeline needs L = 1 and a prior network")
             per_tile = self.dim_z[0] * self.dim_z[1] * self.dim_z[2]
-            st.update({"raw": torch.zeros((n, cy, H, W), device=self.device),
-                       "xf_in": torch.ones((n, 2), device=self.device, dtype=torch.float64),
-                       "xf_out": torch.ones((n, 2), device=self.device, dtype=torch.float64),
-                       "tile_ids": torch.zeros(n, device=self.device, dtype=torch.int64),
-                       "eps": torch.zeros((1, n, per_tile), device=self.device),
-                       "seed": int(getattr(self, "paint_seed", 0))})      # (a launch argument: part of the graph)
+            st["eps"] = torch.zeros((1, n, per_tile), device=self.device)
+            # parameter block of a slot: one contiguous device buffer = one host-to-device copy per batch
+            layout, off = {}, 0
+            for name, dt, shape in (("xf_in", torch.float64, (n, 2)), ("xf_out", torch.float64, (n, 2)),
+                                    ("tile_ids", torch.int64, (n,)), ("seed", torch.int64, (1,)),
+                                    ("aux", torch.float32, (n, max(self.n_aux, 1)))):
+                layout[name] = (off, dt, shape)
+                nb = int(torch.tensor([], dtype=dt).element_size()) * int(torch.Size(shape).numel())
+                off += (nb + 7) // 8 * 8
+            st["block_layout"], st["block_bytes"] = layout, off
+
+            def new_slot():
+                sl = {"raw": torch.zeros((n, cy, H, W), device=self.device),
+                      "out": torch.zeros((n, cx, H, W), device=self.device),
+                      "block": torch.zeros(off, device=self.device, dtype=torch.uint8)}
+                for name, (o, dt, shape) in layout.items():
+                    nb = int(torch.tensor([], dtype=dt).element_size()) * int(torch.Size(shape).numel())
+                    sl[name] = sl["block"][o:o + nb].view(dt).view(shape)
+                sl["xf_in"].fill_(1.0)
+                sl["xf_out"].fill_(1.0)
+                return sl
+            st["slots"] = [new_slot(), new_slot()]
         parts = int(os.environ.get("BP_PAINT_STREAMS", "4"))
         while parts > 1 and (n % parts != 0 or n // parts < 8):
             parts -= 1
@@ -814,25 +837,25 @@ class CVAE(torch.nn.Module):
         st["units"] = units
         others = [torch.cuda.Stream(device=self.device) for _ in range(parts - 1)]
 
-        def paint_pipeline(plan, lo):
+        def paint_pipeline(plan, lo, sl):
             lib, sm = self._lib, _stream()
             plan.pack_all()
-            auxp = L.ptr(st["aux"][lo:lo + h]) if st["aux"] is not None else None
+            auxp = L.ptr(sl["aux"][lo:lo + h]) if self.use_aux_label else None
             for view in (plan.y2.view, plan.hy_slot.view):
-                L.check(lib.bp_paint_load(L.ptr(st["raw"][lo:lo + h]), cy, L.ptr(st["xf_in"][lo:lo + h]), auxp,
+                L.check(lib.bp_paint_load(L.ptr(sl["raw"][lo:lo + h]), cy, L.ptr(sl["xf_in"][lo:lo + h]), auxp,
                                           plan.caux, C.byref(view), sm), "paint load")
             plan.run_prior(False)
             eps = st["eps"][:, lo:lo + h]
-            L.check(lib.bp_philox_normal(int(st["seed"]), L.ptr(st["tile_ids"][lo:lo + h]), h, 1, eps.shape[-1],
-                                         L.ptr(eps), sm), "philox")
+            L.check(lib.bp_philox_normal_dev(L.ptr(sl["seed"]), L.ptr(sl["tile_ids"][lo:lo + h]), h, 1, eps.shape[-1],
+                                             L.ptr(eps), sm), "philox")
             plan.run_latent(eps.reshape(1, h, *self.dim_z), use_q=False)
             plan.run_generator(False)
             L.check(lib.bp_paint_store(C.byref(plan.mu_head.view), None, 1 if plan.mu_softplus else 0,
-                                       L.ptr(st["xf_out"][lo:lo + h]), L.ptr(st["out"][lo:lo + h]), sm), "paint store")
+                                       L.ptr(sl["xf_out"][lo:lo + h]), L.ptr(sl["out"][lo:lo + h]), sm), "paint store")
 
-        def paint(plan, lo):
+        def paint(plan, lo, sl):
             if pipeline:
-                return paint_pipeline(plan, lo)
+                return paint_pipeline(plan, lo, sl)
             plan.load_inputs(st["y"][lo:lo + h], None if st["aux"] is None else st["aux"][lo:lo + h])
             if given_z:
                 L.check(self._lib.bp_nchw_to_view(L.ptr(st["z"][lo:lo + h]), self.dim_z[0], None, 0,
@@ -843,27 +866,33 @@ class CVAE(torch.nn.Module):
             plan.run_generator(False)
             self._head_to_nchw(plan.mu_head, plan.mu_softplus, st["out"][lo:lo + h])
 
-        def run():
+        def run(sl=None):
             main = torch.cuda.current_stream(self.device)
             for k, s2 in enumerate(others):
                 s2.wait_stream(main)
                 with torch.cuda.stream(s2):
-                    paint(plans[k + 1], (k + 1) * h)
-            paint(plans[0], 0)
+                    paint(plans[k + 1], (k + 1) * h, sl)
+            paint(plans[0], 0, sl)
             for s2 in others:
                 main.wait_stream(s2)
 
         side = torch.cuda.Stream(device=self.device)
         side.wait_stream(torch.cuda.current_stream(self.device))
+        slots = st.get("slots", [None])
         with torch.cuda.stream(side), torch.no_grad():
-            run()                                 # warm-up outside capture (packs weights, sizes workspaces)
+            run(slots[0])                         # warm-up outside capture (packs weights, sizes workspaces)
         torch.cuda.current_stream(self.device).wait_stream(side)
-        graph = torch.cuda.CUDAGraph()
-        # (thread-local capture: under data parallelism the process group's watchdog thread may query events while
-        #  this thread captures; that is harmless and must not invalidate the capture)
-        with torch.no_grad(), torch.cuda.graph(graph, stream=side, capture_error_mode="thread_local"):
-            run()
-        st["graph"] = graph
+        graphs = []
+        for sl in slots:
+            graph = torch.cuda.CUDAGraph()
+            # (thread-local capture: under data parallelism the process group's watchdog thread may query events
+            #  while this thread captures; that is harmless and must not invalidate the capture)
+            with torch.no_grad(), torch.cuda.graph(graph, stream=side, capture_error_mode="thread_local"):
+                run(sl)
+            graphs.append(graph)
+            if sl is not None:
+                sl["graph"] = graph
+        st["graph"] = graphs[0]
         return st
 
     # ---- the whole training step as one hipGraph (small minibatches are launch-bound: ~450 launches per step)

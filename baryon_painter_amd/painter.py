@@ -323,14 +323,27 @@ class CVAEPainter(Painter):
         device form."""
         from .utils import data_transforms as T
 
+        def shape_only(st):          # (by name: a transform chain restored from a checkpoint holds re-imported functions)
+            return getattr(st, "__module__", None) == T.__name__ and \
+                getattr(st, "__name__", None) in ("atleast_3d", "squeeze", "as_float32")
+
         def find(compiled, direction, field):
-            steps = getattr(getattr(compiled, "func", None), "steps", None) or [getattr(compiled, "func", None)]
+            if compiled is None:
+                raise NotImplementedError("paint_stream needs the painter's transforms (transform=None has no device form)")
+            func = getattr(compiled, "func", None)
+            steps = getattr(func, "steps", None) or [func]
+            found = None
             for st in steps:
-                if isinstance(st, T._RangeCompress) and st.direction == direction:
+                if isinstance(st, T._RangeCompress) and st.direction == direction and found is None:
                     if st.modes[field].lower() != "shift-log":
                         raise NotImplementedError("device-side transforms implement the 'shift-log' mode only")
-                    return float(st.k_values[field]), compiled.stats[field]
-            raise NotImplementedError("paint_stream(transform=True) needs the painter's shift-log range compression")
+                    found = (float(st.k_values[field]), compiled.stats[field])
+                elif not shape_only(st):
+                    # a custom scaling step in the chain would be silently dropped on the device path
+                    raise NotImplementedError(f"transform step {st!r} has no device form")
+            if found is None:
+                raise NotImplementedError("paint_stream(transform=True) needs the painter's shift-log range compression")
+            return found
         if len(self.label_fields) != 1:
             raise NotImplementedError("Painting with more than one output field is not supported yet.")
         k_in, st_in = find(self.transform, 0, self.input_field)
@@ -350,7 +363,8 @@ class CVAEPainter(Painter):
           * host->device and device->host copies go through pinned double buffers on their own streams, so that
             batch b+1 is uploaded and batch b-1 downloaded while batch b is painted;
           * the prior noise of tile i comes from a counter-based generator keyed on (``seed``, ``tile_ids[i]``
-            [default: i]), so the result does not depend on ``batch_size`` or on how tiles are dealt to ranks;
+            [default: i], int64), so the result does not depend on ``batch_size`` or on how tiles are dealt to ranks;
+            the seed travels in the per-batch parameter block: one captured graph serves every seed;
           * ``rank`` / ``world_size``: this process paints the contiguous block of tiles that is its share (one
             process per GPU, no collective: tiles are independent) and returns (block, (lo, hi))."""
         model = self.model
@@ -367,21 +381,27 @@ class CVAEPainter(Painter):
         per = (N + world_size - 1) // world_size
         lo, hi = min(rank * per, N), min((rank + 1) * per, N)
         B = int(batch_size)
-        model.paint_seed = int(seed)
+        s_in, k_in, k_out, s_out = self._shift_log_parameters(zs[lo:hi])     # (NotImplementedError before any capture)
         g = model.paint_graph(B)
-        s_in, k_in, k_out, s_out = self._shift_log_parameters(zs[lo:hi])
         torch_in = isinstance(inputs, torch.Tensor)
         result = out if out is not None else np.empty((hi - lo, H, W), np.float32)
         torch_out = isinstance(result, torch.Tensor)
         main = torch.cuda.current_stream(dev)
         up, down = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+        # Two slots = the graph's own two buffer sets (CVAE.paint_graph): uploads land where bp_paint_load reads,
+        # downloads leave from where bp_paint_store writes.  Per slot one pinned parameter block (one copy per batch).
+        layout = g["block_layout"]
         slots = []
-        for _ in range(2):
-            slots.append({"h_in": None if torch_in else torch.empty((B, 1, H, W), dtype=torch.float32).pin_memory(),
+        for gs in g["slots"]:
+            h_blk = torch.zeros(g["block_bytes"], dtype=torch.uint8).pin_memory()
+            hv = {}
+            for name, (o, dt, shape) in layout.items():
+                nb = torch.tensor([], dtype=dt).element_size() * int(np.prod(shape))
+                hv[name] = h_blk[o:o + nb].view(dt).view(shape).numpy()
+            hv["seed"][0] = np.array(int(seed) & 0xFFFFFFFFFFFFFFFF, dtype=np.uint64).astype(np.int64)
+            slots.append({"g": gs, "h_blk": h_blk, "hv": hv,
+                          "h_in": None if torch_in else torch.empty((B, 1, H, W), dtype=torch.float32).pin_memory(),
                           "h_out": None if torch_out else torch.empty((B, 1, H, W), dtype=torch.float32).pin_memory(),
-                          "h_par": torch.empty((B, 6), dtype=torch.float64).pin_memory(),
-                          "d_in": torch.empty((B, 1, H, W), device=dev), "d_out": torch.empty((B, 1, H, W), device=dev),
-                          "d_par": torch.empty((B, 6), device=dev, dtype=torch.float64),
                           "ev_up": torch.cuda.Event(), "ev_done": torch.cuda.Event(), "ev_down": torch.cuda.Event(),
                           "pending": None})
 
@@ -399,39 +419,34 @@ class CVAEPainter(Painter):
                 b = min(a + B, hi)
                 m = b - a
                 sl = slots[bi % 2]
+                gs, hv = sl["g"], sl["hv"]
                 harvest(sl)                                   # this slot's previous batch has left the device
-                par = sl["h_par"].numpy()
-                par[:m, 0], par[:m, 1] = s_in[a - lo:b - lo], k_in
-                par[:m, 2], par[:m, 3] = k_out, s_out[a - lo:b - lo]
-                par[:m, 4], par[:m, 5] = zs[a:b], ids[a:b].astype(np.float64)   # (ids < 2^53)
-                if m < B:
-                    par[m:] = par[m - 1]
+                sl["ev_up"].synchronize()                     # ... and its parameter block has been uploaded
+                hv["xf_in"][:m, 0], hv["xf_in"][:m, 1] = s_in[a - lo:b - lo], k_in
+                hv["xf_out"][:m, 0], hv["xf_out"][:m, 1] = k_out, s_out[a - lo:b - lo]
+                hv["aux"][:m, 0] = zs[a:b]
+                hv["tile_ids"][:m] = ids[a:b]
+                if m < B:                                     # a short last batch: pad with its last tile's parameters
+                    for k in ("xf_in", "xf_out", "aux", "tile_ids"):
+                        hv[k][m:] = hv[k][m - 1]
                 if torch_in:
                     src = inputs[a:b].reshape(m, 1, H, W)
                 else:
                     sl["h_in"][:m, 0].numpy()[...] = np.asarray(inputs[a:b], dtype=np.float32)
                     src = sl["h_in"][:m]
-                up.wait_event(sl["ev_done"])                  # the device input of two batches ago has been consumed
+                up.wait_event(sl["ev_done"])                  # the slot's previous batch has been painted (inputs read)
                 with torch.cuda.stream(up):
-                    sl["d_in"][:m].copy_(src, non_blocking=True)
-                    sl["d_par"].copy_(sl["h_par"], non_blocking=True)
+                    gs["raw"][:m].copy_(src, non_blocking=True)
+                    gs["block"].copy_(sl["h_blk"], non_blocking=True)
                     sl["ev_up"].record(up)
                 main.wait_event(sl["ev_up"])
-                main.wait_event(sl["ev_down"])                # ... and its device output has been downloaded
-                dp = sl["d_par"]
-                g["raw"].copy_(sl["d_in"])
-                g["xf_in"].copy_(dp[:, 0:2])
-                g["xf_out"].copy_(dp[:, 2:4])
-                if g["aux"] is not None:
-                    g["aux"].copy_(dp[:, 4:5])
-                g["tile_ids"].copy_(dp[:, 5])
-                g["graph"].replay()
-                sl["d_out"].copy_(g["out"])
+                main.wait_event(sl["ev_down"])                # ... and its previous output has been downloaded
+                gs["graph"].replay()
                 sl["ev_done"].record(main)
                 down.wait_event(sl["ev_done"])
                 with torch.cuda.stream(down):
                     dst = result[a - lo:b - lo].reshape(m, 1, H, W) if torch_out else sl["h_out"][:m]
-                    dst.copy_(sl["d_out"][:m], non_blocking=True)
+                    dst.copy_(gs["out"][:m], non_blocking=True)
                     sl["ev_down"].record(down)
                 sl["pending"] = (a, b)
             for sl in slots:

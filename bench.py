@@ -1,17 +1,25 @@
 #!/usr/bin/env python3
-"""Headline benchmark: CVAE fiducial train step (forward + backward + Adam) on synthetic
-512x512 dark-matter -> pressure tiles, fp32, 64 tiles per GPU (BASELINE.json configs[1]).
+"""Benchmark of the MI355X-native CVAE / CGAN hot path on synthetic 512x512 dark-matter -> pressure tiles.
 
     python bench.py --gpus N --steps K --warmup W
 
-N>1 is launched by the driver with torch.distributed.run (one rank per GPU, RCCL); the batch is
-sharded data-parallel (weak scaling: 64 tiles per GPU), gradients are all-reduced as one flat
-buffer and batch-norm statistics are all-reduced per layer (global-batch arithmetic).
-Prints ONE JSON line on rank 0 (contract in the task description), including
-  roofline     -- the dominant kernel's achieved fp32 MFMA rate from HIP events recorded around
-                  every convolution launch inside the timed region,
-  cpu_baseline -- oracle/torch_ref.py (the reference's torch.nn.functional graph) timed on the
-                  host cores on a bounded sample of the same workload.
+HEADLINE (metric / value / config / dtype / roofline of the JSON line): the CVAE fiducial train step (forward +
+backward + Adam), fp32, 64 tiles per GPU -- BASELINE.json configs[1].  The same line carries, as bounded secondary
+legs (their own objects, each with its own roofline; none of them changes the headline fields):
+  "paint" -- configs[4] per GPU: CVAEPainter.paint_stream, raw host tile -> physical host tile, hipGraph forward;
+  "bf16"  -- configs[3] per GPU: the same train step with bf16 activations / gradients in the generator trunk
+             (+ its own paint leg);
+  "cgan"  -- configs[2]: CGAN fiducial alternating D+G iteration, batch 64 (single GPU only);
+  "cpu_baseline" -- oracle/torch_ref.py (the reference's torch.nn.functional graph) on the host cores, configs[0].
+A compact copy of the secondary legs' numbers is kept in config["other_configs"].  --legs selects legs.
+
+N > 1: the driver launches one rank per GPU with torch.distributed.run; started plainly (`python bench.py --gpus N`,
+no WORLD_SIZE in the environment) this script launches that itself as a CHILD process before touching the GPU and
+relays rank 0's JSON line.  The batch is sharded data-parallel (weak scaling: 64 tiles per GPU), gradients are
+all-reduced as one flat buffer and batch-norm statistics are all-reduced per layer (global-batch arithmetic).
+Timing: W untimed warm-up steps, then exactly K steps between barrier + synchronize on both sides, MAX over ranks.
+  roofline -- the dominant kernel's achieved rate from HIP events recorded around every launch (on the stream the
+              kernels are launched on) in extra steps of the serial schedule right after the timed region.
 """
 import argparse
 import json
@@ -26,7 +34,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_* dense peak
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: bf16 MFMA dense peak (spec, no sparsity)
 PEAK_HBM_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E peak (spec); ~6.3 TB/s is what a streaming copy reaches
+CGAN_FLOP_PER_TILE = 0.609e12 * 1.0   # alternating D+G iteration ~ 255 + 354 GFLOP per 512^2 tile
 TILE = 512
 BATCH_PER_GPU = 64
 
@@ -158,7 +168,294 @@ def cpu_baseline(seconds_budget=30.0):
             "paint_512_sample": f"5 timed sample_P of one 512x512 tile (eval mode), median {medp * 1e3:.1f} ms"}
 
 
-def bench_cgan(args, dev, world, rank, sync=None):
+def _reduce_max_time(dt, dev, world):
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt
+
+
+def _timed(step, steps, warmup, world):
+    """W untimed steps, then exactly K steps bracketed by barrier + synchronize on both sides."""
+    out = None
+    for _ in range(warmup):
+        step()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    return time.perf_counter() - t0, out
+
+
+def _free():
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()
+
+
+def _traffic(kernel):
+    """HBM bytes per launch from the PMC passes (rocprofv3 cannot run inside bench.py); only quoted when the stamp says
+    the counters were collected on these very kernel sources."""
+    try:
+        pj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        if pj.get("source_hash") == source_hash():
+            return pj["hbm_bytes_per_launch"].get(kernel)
+    except Exception:
+        pass
+    return None
+
+
+def _collective_report(sync, step):
+    """Two further steps of the timed schedule with HIP events around every all-reduce."""
+    n0, g0, b0 = sync.n_small, sync.n_grad, sync.bytes_grad
+    sync.timing = []
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    ev, sync.timing = sync.timing, None
+    per = {}
+    for e0, e1, kind in ev:
+        per.setdefault(kind, []).append(e0.elapsed_time(e1) * 1e3)
+    stats = {k: {"per_step": len(v) // 2, "ms_per_step": round(sum(v) / 2e3, 3), "min_us": round(min(v), 1),
+                 "median_us": round(float(np.median(v)), 1), "max_us": round(max(v), 1)} for k, v in per.items()}
+    return {"collectives_per_step": {"batch_norm_statistics": (sync.n_small - n0) // 2,
+                                     "gradient_buffers": (sync.n_grad - g0) // 2},
+            "gradient_bytes_per_step": (sync.bytes_grad - b0) // 2,
+            "inside_collectives": stats,
+            "gradient_all_reduce": "generator trunk + heads (97 % of the bytes) early on the weight-gradient stream, own "
+                                   "communicator (BP_EARLY_ALLREDUCE=1); the rest after the backward pass"
+                                   if sync.overlap else "one flat buffer after the backward pass",
+            "backend": torch.distributed.get_backend()}
+
+
+# ---------------------------------------------------------------------------------------------- CVAE train step + paint
+def cvae_leg(args, dtype, dev, world, rank, sync, steps, warmup, paint=True):
+    """One CVAE leg: timed train steps, collectives report (N > 1), per-kernel HIP-event profile of the serial
+    schedule -> roofline, paint_stream.  Returns the leg's dict (every rank runs it; rank 0's is printed)."""
+    import contextlib
+    from baryon_painter_amd.models import arch as A
+    from baryon_painter_amd.models.cvae import CVAE
+    from baryon_painter_amd.optim import FlatAdam
+    from baryon_painter_amd.utils import synthetic as syn
+
+    arch = A.fiducial_architecture(args.tile)
+    torch.manual_seed(1234)                      # same initial weights on every rank
+    with contextlib.redirect_stdout(sys.stderr):     # the model announces itself like the reference does
+        model = CVAE(arch, dev, sync=sync, dtype=dtype)
+    opt = FlatAdam(model, lr=1e-3) if not args.torch_adam else torch.optim.Adam(model.parameters(), lr=1e-3)
+    n = args.batch
+    # synthetic tiles: a few distinct ones, tiled up to the batch (generation cost, not arithmetic)
+    nb = min(n, 8)
+    x, y, aux = syn.synthetic_batch(nb, args.tile, args.tile, seed=1234 + rank)
+    reps = (n + nb - 1) // nb
+    x = torch.from_numpy(np.tile(x, (reps, 1, 1, 1))[:n]).to(dev)
+    y = torch.from_numpy(np.tile(y, (reps, 1, 1, 1))[:n]).to(dev)
+    aux = torch.from_numpy(np.tile(aux, reps)[:n]).to(dev)
+
+    def eager_step():
+        elbo = model(x, y, aux)
+        opt.zero_grad()
+        (-elbo).backward()
+        opt.step()
+        return elbo
+
+    step = eager_step
+    use_graph = args.graph and world == 1 and not args.torch_adam
+    if use_graph:
+        eager_step()                                  # (sizes workspaces, claims gradient buffers)
+        gstep = model.make_graphed_train_step(opt, n)
+        step = lambda: gstep(x, y, aux)
+
+    dt, elbo = _timed(step, steps, warmup, world)
+    dt = _reduce_max_time(dt, dev, world)
+    plan = model._last
+    final_elbo = float(elbo.detach())
+    coll = _collective_report(sync, step) if sync is not None else None
+
+    # ---- kernel times for the roofline: PROF_STEPS further steps of the SERIAL schedule (not timed above).
+    # In the timed region the weight gradients run on a second stream and share the CUs with the data gradients
+    # and the batch-norm passes, so HIP events around a launch there measure "this kernel while sharing the GPU",
+    # not the kernel.  Serially every launch has the GPU to itself; the events sit on the stream the kernels are
+    # launched on (torch's current stream).
+    PROF_STEPS = 2
+    model.overlap_weight_gradients(False)
+    plan.prof = []                               # HIP events around every convolution launch
+    for _ in range(PROF_STEPS):
+        eager_step()                             # (eager: the events are recorded by the launch hooks)
+    torch.cuda.synchronize()
+    prof_events, plan.prof = plan.prof, None
+    model.overlap_weight_gradients(True)
+
+    paint_leg = _paint_leg(args, model, dtype, dev, world, rank, n) if paint else None
+
+    per = {}
+    for e0, e1, unit, kind, nstreams in prof_events:
+        name = kernel_name(kind, unit, model._lib)
+        d = per.setdefault(name, {"ms": 0.0, "launches": 0, "flop": 0.0, "bytes": 0.0})
+        d["ms"] += e0.elapsed_time(e1)
+        d["launches"] += 1
+        if kind in ("forward", "backward_data", "backward_weight"):
+            d["flop"] += 2.0 * unit.macs(kind)
+        d["bytes"] += unit.algorithmic_bytes(kind, nstreams)
+    if args.layers and rank == 0:
+        lay = {}
+        for e0, e1, unit, kind, nstreams in prof_events:
+            fl = 2.0 * unit.macs(kind) if kind in ("forward", "backward_data", "backward_weight") else 0.0
+            d = lay.setdefault((unit.name, kind), [0.0, fl, unit.algorithmic_bytes(kind, nstreams),
+                                                   kernel_name(kind, unit, model._lib)])
+            d[0] += e0.elapsed_time(e1) / PROF_STEPS
+        for (name, kind), (ms, fl, by, kn) in sorted(lay.items(), key=lambda kv: -kv[1][0]):
+            print(f"{name:28s} {kind:16s} {ms:8.3f} ms  {fl / ms / 1e9:7.2f} TF/s  {by / ms / 1e6:8.1f} GB/s  {kn}",
+                  file=sys.stderr)
+    conv = {k: v for k, v in per.items() if v["flop"] > 0}
+    # fp32: the step is matrix-core bound (AI ~100 FLOP/B vs a ridge of 20): dominant = the convolution kernel with
+    # the most time, priced in TFLOP/s.  bf16: HBM-bound by the survey's accounting (ridge 310 FLOP/B): dominant =
+    # whichever kernel takes the most time, priced in algorithmic bytes per second (its matrix-core rate beside it).
+    hbm = dtype == "bf16"
+    pool = per if hbm else conv
+    dom = max(pool, key=lambda k: pool[k]["ms"])
+    d = per[dom]
+    conv_ms = sum(v["ms"] for v in conv.values()) / PROF_STEPS
+    serial_ms = sum(v["ms"] for v in per.values()) / PROF_STEPS
+    tflops_dom = d["flop"] / (d["ms"] * 1e-3) / 1e12
+    gbs_dom = d["bytes"] / (d["ms"] * 1e-3) / 1e9
+    mfma_peak = PEAK_BF16_MFMA_TFLOPS if "bf16" in dom else PEAK_FP32_MFMA_TFLOPS
+    if hbm:
+        roofline = {"bound": "hbm", "kernel": dom, "achieved": round(gbs_dom, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                    "frac": round(gbs_dom / PEAK_HBM_GBS, 4), "traffic": _traffic(dom),
+                    "algorithmic_bytes_per_launch": d["bytes"] / d["launches"],
+                    "mfma_tflops": round(tflops_dom, 1), "mfma_frac": round(tflops_dom / mfma_peak, 4)}
+    else:
+        roofline = {"bound": "mfma", "kernel": dom, "achieved": round(tflops_dom, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(tflops_dom / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": _traffic(dom),
+                    "flop_per_launch": d["flop"] / d["launches"],
+                    "algorithmic_bytes_per_launch": d["bytes"] / d["launches"]}
+    all_bytes = sum(v["bytes"] for v in per.values()) / PROF_STEPS
+    step_s = dt / steps
+    step_flop = n * 61.4e9 * (args.tile / 512) ** 2                  # SURVEY.md 8d: 3 x forward convention
+    step_bytes = n * (310e6 if hbm else 615e6) * (args.tile / 512) ** 2   # SURVEY.md 8d: fused-ideal activation traffic
+    top = sorted(per.items(), key=lambda kv: -kv[1]["ms"])[:14]
+    roofline.update({
+        "avg_launch_ms": round(d["ms"] / d["launches"], 4), "launches_per_step": d["launches"] // PROF_STEPS,
+        "share_of_step": round(d["ms"] / PROF_STEPS / (step_s * 1e3), 3),
+        "measured_on": f"{PROF_STEPS} steps of the serial schedule run right after the timed region (there weight "
+                       "gradients overlap the backward chain on a second stream: per-launch times are not kernel times)",
+        "serial_kernels_ms_per_step": round(serial_ms, 2), "conv_kernels_ms_per_step": round(conv_ms, 2),
+        "whole_step": {"tflops": round(step_flop / step_s / 1e12, 1),
+                       "mfma_frac": round(step_flop / step_s / 1e12 / (PEAK_BF16_MFMA_TFLOPS if hbm else PEAK_FP32_MFMA_TFLOPS), 4),
+                       "algorithmic_GBs": round(step_bytes / step_s / 1e9, 1),
+                       "hbm_frac": round(step_bytes / step_s / 1e9 / PEAK_HBM_GBS, 4),
+                       "algorithmic_GBs_timed_kernels": round(all_bytes / step_s / 1e9, 1)},
+        "top_kernels": {k: {"ms_per_step": round(v["ms"] / PROF_STEPS, 3), "launches": v["launches"] // PROF_STEPS,
+                            "tflops": round(v["flop"] / (v["ms"] * 1e-3) / 1e12, 2),
+                            "GBs": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1)} for k, v in top}})
+    leg = {
+        "metric": "cvae_train_tiles_per_sec", "value": round(world * n * steps / dt, 2), "unit": "tiles/s",
+        "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": round(step_s * 1e3, 3),
+        "dtype": dtype,
+        "config": {"workload": f"CVAE fiducial train step (fwd+bwd+Adam), batch {n}/GPU of "
+                               f"{args.tile}x{args.tile} tiles, " + (
+                                   "fp32 (BASELINE.json configs[1])" if dtype == "f32" else
+                                   "bf16 activations/gradients in the generator trunk, fp32 accumulation, master "
+                                   "weights and statistics (BASELINE.json configs[3] per GPU)"),
+                   "tile": args.tile, "batch_per_gpu": n, "global_batch": n * world,
+                   "parallelism": f"dp{world}",
+                   "batch_norm": "single device" if world == 1 else
+                                 ("local statistics (--local-bn)" if args.local_bn else "global (all-reduced statistics)"),
+                   "optimizer": "torch.optim.Adam(lr=1e-3)" if args.torch_adam
+                                else "FlatAdam(lr=1e-3) = torch.optim.Adam arithmetic, fused",
+                   "schedule": ("weight gradients on a second HIP stream beside the rest of the backward pass"
+                                + ("; the whole step replayed from one hipGraph" if use_graph else ""))
+                               if os.environ.get("BP_SIDE_WGRAD", "1") != "0" else "single stream",
+                   "final_elbo": final_elbo},
+        "roofline": roofline, "paint": paint_leg}
+    if coll is not None:
+        leg["config"].update(coll)
+    del model, opt, plan, prof_events
+    _free()
+    return leg
+
+
+def _paint_leg(args, model, dtype, dev, world, rank, n):
+    """paint() (SURVEY.md 8d metric (B), BASELINE.json configs[4]): RAW host tiles in -> physical host tiles out through
+    CVAEPainter.paint_stream -- device-side transforms, Philox per-tile prior noise, one captured hipGraph per batch
+    (prior + sampler + generator on four streams), pinned double-buffered H2D / D2H on side streams.  This rank
+    paints its contiguous share of the tiles; no collective."""
+    from baryon_painter_amd.painter import CVAEPainter
+    from baryon_painter_amd.utils.datasets import SyntheticTileDataset
+    model.train(False)
+    pb = min(n, 64)
+    ds = SyntheticTileDataset(n_sample=8, tile_size=args.tile, seed=3)
+    pt = CVAEPainter.__new__(CVAEPainter)
+    pt.model, pt.compute_device, pt.sync = model, dev, None
+    pt.input_field, pt.label_fields = ds.input_field, ds.label_fields
+    pt.transform, pt.inverse_transform = ds.transform, ds.inverse_transform
+    n_paint = args.paint_tiles
+    raw = np.stack([ds.raw_fields(i)[0] for i in range(8)])
+    zs = np.array([ds.raw_fields(i)[2] for i in range(8)])
+    reps_p = (n_paint + 7) // 8
+    tin = torch.from_numpy(np.tile(raw, (reps_p, 1, 1))[:n_paint]).pin_memory()
+    zin = np.tile(zs, reps_p)[:n_paint]
+    tout = torch.empty((n_paint, args.tile, args.tile), dtype=torch.float32).pin_memory()
+    ids = np.arange(n_paint, dtype=np.int64) + rank * n_paint
+    with torch.no_grad():
+        pt.paint_stream(tin[:2 * pb], zin[:2 * pb], batch_size=pb, tile_ids=ids[:2 * pb], out=tout[:2 * pb])   # capture
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+        t0p = time.perf_counter()
+        pt.paint_stream(tin, zin, batch_size=pb, tile_ids=ids, out=tout)
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        tp = _reduce_max_time(time.perf_counter() - t0p, dev, world)
+        # the captured forward alone, tiles resident in HBM (no transforms, no copies): the kernel-side ceiling
+        g = model.paint_graph(pb)
+        torch.cuda.synchronize()
+        t0p = time.perf_counter()
+        for _ in range(10):
+            g["graph"].replay()
+        torch.cuda.synchronize()
+        tg = (time.perf_counter() - t0p) / 10
+    # every painted tile is finite and positive-definite pressure; tiles 0 and 8 are the same raw tile with different
+    # Philox streams (tile ids): they must differ, and differ little (the prior noise is a small modulation)
+    o = tout.numpy()
+    assert np.isfinite(o).all() and (o >= 0).all(), "paint_stream produced non-finite / negative pressure"
+    if n_paint > 8:
+        rel = np.abs(o[0] - o[8]).sum() / max(np.abs(o[0]).sum(), 1e-30)
+        assert 0 < rel < 1.0, f"tiles 0 and 8 (same input, different noise stream) differ by {rel}"
+    alg = 190e6 * (args.tile / 512) ** 2 * (0.5 if dtype == "bf16" else 1.0)   # SURVEY.md 8d: fused-ideal
+    #                                                      activation bytes of one painted tile (fp32; half in bf16)
+    flop = 20.25e9 * (args.tile / 512) ** 2      # SURVEY.md 8d: paint = prior + generator forward
+    rate = n_paint / tp
+    leg = {"metric": "paint_tiles_per_sec", "value": round(world * rate, 1), "unit": "tiles/s",
+           "tiles": n_paint, "batch": pb, "ms_per_batch": round(tp / (n_paint / pb) * 1e3, 3),
+           "resident_tiles_per_sec": round(world * pb / tg, 1), "ms_per_batch_graph_only": round(tg * 1e3, 3),
+           # fp32 paint is matrix-core bound like the fp32 train step (AI ~107 FLOP/B), bf16 paint HBM-bound
+           "roofline": ({"bound": "hbm", "achieved": round(alg * rate / 1e9, 1), "peak": PEAK_HBM_GBS,
+                         "unit": "GB/s", "frac": round(alg * rate / 1e9 / PEAK_HBM_GBS, 4),
+                         "algorithmic_bytes_per_tile": alg, "mfma_tflops": round(flop * rate / 1e12, 1)}
+                        if dtype == "bf16" else
+                        {"bound": "mfma", "achieved": round(flop * rate / 1e12, 1),
+                         "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(flop * rate / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+                         "flop_per_tile": flop, "algorithmic_bytes_per_tile": alg}),
+           "pcie_bytes_per_tile": 2 * 4 * args.tile ** 2,
+           "note": "host float32 raw tile in -> host float32 physical tile out (pinned memory), per rank its "
+                   "own tiles, no collective; 'resident' = the captured forward alone on tiles already in HBM; "
+                   "roofline per GPU"}
+    model.train(True)
+    return leg
+
+
+# ---------------------------------------------------------------------------------------------- CGAN iteration
+def cgan_leg(args, dev, world, rank, sync, steps, warmup):
     """BASELINE.json configs[2]: CGAN fiducial, alternating discriminator / generator iteration."""
     import contextlib
     from baryon_painter_amd.models.cgan import CGAN
@@ -175,34 +472,91 @@ def bench_cgan(args, dev, world, rank, sync=None):
     z = torch.from_numpy(np.tile(z, reps)[:n]).to(dev)
     opt_g = torch.optim.Adam(model.g_parameters(), lr=5e-5, betas=(0.5, 0.999))
     opt_d = torch.optim.Adam(model.d_parameters(), lr=5e-5, betas=(0.5, 0.999))
-    for _ in range(args.warmup):
-        model.train_step(x, y, z, opt_g, opt_d)
-    if world > 1:
-        torch.distributed.barrier()
+    step = lambda: model.train_step(x, y, z, opt_g, opt_d)
+    dt, losses = _timed(step, steps, warmup, world)
+    dt = _reduce_max_time(dt, dev, world)
+    losses = {k: float(v) for k, v in losses.items()}
+    # one further iteration of the serial schedule with HIP events around every launch (as the CVAE leg)
+    plan = model._plan(n)
+    side, plan.side = plan.side, None
+    plan.prof = []
+    step()
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        losses = model.train_step(x, y, z, opt_g, opt_d)
-    torch.cuda.synchronize()
-    if world > 1:
-        torch.distributed.barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt = float(t.item())
-    if torch.distributed.is_available() and torch.distributed.is_initialized():
-        torch.distributed.destroy_process_group()
-    if rank != 0:
-        return
-    print(json.dumps({
-        "metric": "cgan_train_tiles_per_sec", "value": round(world * n * args.steps / dt, 2), "unit": "tiles/s", "n_gpus": world,
-        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"CGAN fiducial alternating D+G iteration, batch {n} of {args.tile}x{args.tile} tiles, fp32 "
-                               "(BASELINE.json configs[2]); parity vs own restatement only (no reference code)",
-                   "parallelism": f"dp{world}", "global_batch": n * world,
-                   "losses": {k: float(v) for k, v in losses.items()}}}), flush=True)
+    ev, plan.prof = plan.prof, None
+    plan.side = side
+    per = {}
+    for e0, e1, unit, kind, nstreams in ev:
+        name = kernel_name(kind, unit, model._lib) + (
+            f"[{unit.name} {kind}]" if kind in ("forward", "backward_data", "backward_weight") else "")
+        d = per.setdefault(name, {"ms": 0.0, "launches": 0, "flop": 0.0, "bytes": 0.0})
+        d["ms"] += e0.elapsed_time(e1)
+        d["launches"] += 1
+        if kind in ("forward", "backward_data", "backward_weight"):
+            d["flop"] += 2.0 * unit.macs(kind)
+        d["bytes"] += unit.algorithmic_bytes(kind, nstreams)
+    conv = {k: v for k, v in per.items() if v["flop"] > 0}
+    dom = max(conv, key=lambda k: conv[k]["ms"])
+    d = per[dom]
+    tf = d["flop"] / (d["ms"] * 1e-3) / 1e12
+    step_s = dt / steps
+    flop_step = sum(v["flop"] for v in conv.values())          # counted from the launches of one iteration
+    top = sorted(per.items(), key=lambda kv: -kv[1]["ms"])[:10]
+    roofline = {"bound": "mfma", "kernel": dom, "achieved": round(tf, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(tf / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                "flop_per_launch": d["flop"] / d["launches"], "avg_launch_ms": round(d["ms"] / d["launches"], 4),
+                "launches_per_step": d["launches"], "share_of_step": round(d["ms"] / (step_s * 1e3), 3),
+                "measured_on": "one iteration of the serial schedule right after the timed region",
+                "serial_kernels_ms_per_step": round(sum(v["ms"] for v in per.values()), 2),
+                "whole_step": {"tflops": round(flop_step / step_s / 1e12, 1),
+                               "mfma_frac": round(flop_step / step_s / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+                               "flop_per_tile_counted": flop_step / n,
+                               "flop_per_tile_survey": CGAN_FLOP_PER_TILE * (args.tile / 512) ** 2},
+                "top_kernels": {k: {"ms_per_step": round(v["ms"], 3), "launches": v["launches"],
+                                    "tflops": round(v["flop"] / (v["ms"] * 1e-3) / 1e12, 2)} for k, v in top}}
+    leg = {"metric": "cgan_train_tiles_per_sec", "value": round(world * n * steps / dt, 2), "unit": "tiles/s",
+           "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": round(step_s * 1e3, 3), "dtype": "f32",
+           "config": {"workload": f"CGAN fiducial alternating D+G iteration, batch {n} of {args.tile}x{args.tile} tiles, "
+                                  "fp32 (BASELINE.json configs[2]); parity vs own restatement only (no reference code)",
+                      "parallelism": f"dp{world}", "global_batch": n * world, "losses": losses},
+           "roofline": roofline}
+    del model, opt_g, opt_d, plan, ev
+    _free()
+    return leg
+
+
+# ---------------------------------------------------------------------------------------------- driver
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start torch.distributed.run as a CHILD process (nothing in this
+    process has touched the GPU) and pass its output through."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print("bench.py: launching " + " ".join(cmd), file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=env)
+
+
+def _compact(leg):
+    """The few numbers of a secondary leg that config['other_configs'] repeats."""
+    if not isinstance(leg, dict) or "value" not in leg:
+        return leg
+    r = leg.get("roofline") or {}
+    out = {"value": leg["value"], "unit": leg["unit"]}
+    if "ms_per_step" in leg:
+        out["ms_per_step"] = leg["ms_per_step"]
+    if "ms_per_batch" in leg:
+        out["ms_per_batch"] = leg["ms_per_batch"]
+        out["resident_tiles_per_sec"] = leg["resident_tiles_per_sec"]
+    out["roofline"] = {k: r.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic") if k in r}
+    if "whole_step" in r:
+        out["roofline"]["whole_step"] = r["whole_step"]
+    return out
 
 
 def main():
@@ -215,28 +569,32 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--local-bn", action="store_true", help="do not all-reduce batch-norm statistics")
     ap.add_argument("--layers", action="store_true", help="also print a per-layer table to stderr")
-    ap.add_argument("--no-paint", action="store_true", help="skip the paint() throughput leg")
+    ap.add_argument("--no-paint", action="store_true", help="skip the paint() throughput legs")
     ap.add_argument("--paint-tiles", type=int, default=1024, help="tiles streamed through paint() per rank")
     ap.add_argument("--torch-adam", action="store_true", help="torch.optim.Adam instead of the fused FlatAdam")
     ap.add_argument("--graph", action="store_true",
                     help="replay the step (forward + backward + Adam, same launches) from one hipGraph "
                          "(CVAE.make_graphed_train_step; single GPU).  Measured SLOWER than the eager schedule at "
-                         "batch 64 x 512^2 (fp32 48.5 vs 46.2 ms, bf16 24.8 vs 23.6: the graph re-packs every layer's "
-                         "weights and the host is never the bottleneck); it pays at the reference's small minibatches")
+                         "batch 64 x 512^2; it pays at the reference's small minibatches")
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
-                    help="f32: the reference's arithmetic (configs[1], the headline); bf16: bf16 activations / gradients "
+                    help="headline arithmetic. f32: the reference's (configs[1]); bf16: bf16 activations / gradients "
                          "in the generator trunk, fp32 accumulation, master weights and statistics (configs[3])")
     ap.add_argument("--workload", choices=["cvae", "cgan"], default="cvae",
-                    help="cvae: BASELINE.json configs[1] (the headline); cgan: configs[2] (alternating D/G step)")
+                    help="headline workload. cvae: BASELINE.json configs[1]; cgan: configs[2] (alternating D/G step)")
+    ap.add_argument("--legs", default=None,
+                    help="comma list of secondary legs beside the headline: bf16,cgan (default: bf16,cgan on one GPU, "
+                         "bf16 on several; 'none' for the headline alone)")
+    ap.add_argument("--secondary-steps", type=int, default=8, help="timed steps of the bf16 leg (CGAN: a quarter)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))                 # (before anything touches the GPU)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
     if os.environ.get("BP_DIST_BACKEND", "nccl") != "nccl":
         local_rank = 0                                             # rehearsal: all ranks share GPU 0
     torch.cuda.set_device(local_rank)
@@ -254,246 +612,54 @@ def main():
         from baryon_painter_amd.dist import Sync
         sync = Sync(sync_bn=not args.local_bn)
 
-    from baryon_painter_amd.models import arch as A
-    from baryon_painter_amd.models.cvae import CVAE
-    from baryon_painter_amd.utils import synthetic as syn
+    if args.legs is None:
+        legs = ["bf16", "cgan"] if world == 1 else ["bf16"]
+    else:
+        legs = [s for s in args.legs.split(",") if s and s != "none"]
+    t_start = time.time()
 
     if args.workload == "cgan":
-        return bench_cgan(args, dev, world, rank, sync)
-
-    arch = A.fiducial_architecture(args.tile)
-    torch.manual_seed(1234)                      # same initial weights on every rank
-    import contextlib
-    with contextlib.redirect_stdout(sys.stderr):     # the model announces itself like the reference does
-        model = CVAE(arch, dev, sync=sync, dtype=args.dtype)
-    from baryon_painter_amd.optim import FlatAdam
-    opt = FlatAdam(model, lr=1e-3) if not args.torch_adam else torch.optim.Adam(model.parameters(), lr=1e-3)
-    n = args.batch
-    # synthetic tiles: a few distinct ones, tiled up to the batch (generation cost, not arithmetic)
-    nb = min(n, 8)
-    x, y, aux = syn.synthetic_batch(nb, args.tile, args.tile, seed=1234 + rank)
-    reps = (n + nb - 1) // nb
-    x = torch.from_numpy(np.tile(x, (reps, 1, 1, 1))[:n]).to(dev)
-    y = torch.from_numpy(np.tile(y, (reps, 1, 1, 1))[:n]).to(dev)
-    aux = torch.from_numpy(np.tile(aux, reps)[:n]).to(dev)
-
-    if os.environ.get("BP_MAIN_PRIORITY"):           # experiment: the main chain on a stream of another priority
-        torch.cuda.synchronize()
-        torch.cuda.set_stream(torch.cuda.Stream(device=dev, priority=int(os.environ["BP_MAIN_PRIORITY"])))
-
-    def eager_step():
-        elbo = model(x, y, aux)
-        opt.zero_grad()
-        (-elbo).backward()
-        opt.step()
-        return elbo
-
-    step = eager_step
-    use_graph = args.graph and world == 1 and not args.torch_adam
-    if use_graph:
-        eager_step()                                  # (sizes workspaces, claims gradient buffers)
-        gstep = model.make_graphed_train_step(opt, n)
-        step = lambda: gstep(x, y, aux)
-
-    for _ in range(args.warmup):
-        step()
-    plan = model._last
-    if world > 1:
-        torch.distributed.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        elbo = step()
-    torch.cuda.synchronize()
-    if world > 1:
-        torch.distributed.barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt = float(t.item())
-    final_elbo = float(elbo.detach())
-
-    # ---- collectives (N > 1): two further steps of the timed schedule with HIP events around every all-reduce
-    coll = None
-    if sync is not None:
-        n0, g0, b0 = sync.n_small, sync.n_grad, sync.bytes_grad
-        sync.timing = []
-        for _ in range(2):
-            step()
-        torch.cuda.synchronize()
-        ev, sync.timing = sync.timing, None
-        ms = {}
-        for e0, e1, kind in ev:
-            ms[kind] = ms.get(kind, 0.0) + e0.elapsed_time(e1) / 2
-        coll = {"collectives_per_step": {"batch_norm_statistics": (sync.n_small - n0) // 2,
-                                         "gradient_buffers": (sync.n_grad - g0) // 2},
-                "gradient_bytes_per_step": (sync.bytes_grad - b0) // 2,
-                "ms_per_step_inside_collectives": {k: round(v, 3) for k, v in ms.items()},
-                "gradient_all_reduce": "generator trunk + heads (97 % of the bytes) on the weight-gradient stream right "
-                                       "behind the trunk's last weight gradient, own communicator; the rest after the "
-                                       "backward pass" if sync.overlap else "one flat buffer after the backward pass",
-                "backend": torch.distributed.get_backend()}
-
-    # ---- kernel times for the roofline: PROF_STEPS further steps of the SERIAL schedule (not timed above).
-    # In the timed region the weight gradients run on a second stream and share the CUs with the data gradients
-    # and the batch-norm passes (that is where 7 % of the throughput comes from), so HIP events around a launch
-    # there measure "this kernel while sharing the GPU", not the kernel.  Serially every launch has the GPU to
-    # itself; the events sit on the stream the kernels are launched on (torch's current stream).
-    PROF_STEPS = 2
-    model.overlap_weight_gradients(False)
-    plan.prof = []                               # HIP events around every convolution launch
-    for _ in range(PROF_STEPS):
-        eager_step()                             # (eager: the events are recorded by the launch hooks)
-    torch.cuda.synchronize()
-    prof_events, plan.prof = plan.prof, None
-    model.overlap_weight_gradients(True)
-
-    # ---- paint() (SURVEY.md 8d metric (B), BASELINE.json configs[4]): RAW host tiles in -> physical host tiles out
-    # through CVAEPainter.paint_stream -- device-side transforms, Philox per-tile prior noise, one captured hipGraph
-    # per batch (prior + sampler + generator on four streams), pinned double-buffered H2D / D2H on side streams.
-    # This rank paints its contiguous share of the tiles; no collective.
-    paint_leg = None
-    if not args.no_paint:
-        from baryon_painter_amd.painter import CVAEPainter
-        from baryon_painter_amd.utils.datasets import SyntheticTileDataset
-        model.train(False)
-        pb = min(n, 64)
-        ds = SyntheticTileDataset(n_sample=8, tile_size=args.tile, seed=3)
-        pt = CVAEPainter.__new__(CVAEPainter)
-        pt.model, pt.compute_device, pt.sync = model, dev, None
-        pt.input_field, pt.label_fields = ds.input_field, ds.label_fields
-        pt.transform, pt.inverse_transform = ds.transform, ds.inverse_transform
-        n_paint = args.paint_tiles
-        raw = np.stack([ds.raw_fields(i)[0] for i in range(8)])
-        zs = np.array([ds.raw_fields(i)[2] for i in range(8)])
-        reps_p = (n_paint + 7) // 8
-        tin = torch.from_numpy(np.tile(raw, (reps_p, 1, 1))[:n_paint]).pin_memory()
-        zin = np.tile(zs, reps_p)[:n_paint]
-        tout = torch.empty((n_paint, args.tile, args.tile), dtype=torch.float32).pin_memory()
-        ids = np.arange(n_paint, dtype=np.int64) + rank * n_paint
-        with torch.no_grad():
-            pt.paint_stream(tin[:2 * pb], zin[:2 * pb], batch_size=pb, tile_ids=ids[:2 * pb], out=tout[:2 * pb])   # capture
-            torch.cuda.synchronize()
-            t0p = time.perf_counter()
-            pt.paint_stream(tin, zin, batch_size=pb, tile_ids=ids, out=tout)
-            tp = time.perf_counter() - t0p
-            # the captured forward alone, tiles resident in HBM (no transforms, no copies): the kernel-side ceiling
-            g = model.paint_graph(pb)
-            torch.cuda.synchronize()
-            t0p = time.perf_counter()
-            for _ in range(10):
-                g["graph"].replay()
-            torch.cuda.synchronize()
-            tg = (time.perf_counter() - t0p) / 10
-        assert np.isfinite(tout[-1].numpy()).all()
-        alg = 190e6 * (args.tile / 512) ** 2 * (0.5 if args.dtype == "bf16" else 1.0)   # fused-ideal
-        #                                                      activation bytes of one painted tile (fp32; half in bf16)
-        flop = 20.25e9 * (args.tile / 512) ** 2      # paint = prior + generator forward
-        paint_leg = {"metric": "paint_tiles_per_sec", "value": round(world * n_paint / tp, 1), "unit": "tiles/s",
-                     "tiles": n_paint, "batch": pb, "ms_per_batch": round(tp / (n_paint / pb) * 1e3, 3),
-                     "resident_tiles_per_sec": round(world * pb / tg, 1), "ms_per_batch_graph_only": round(tg * 1e3, 3),
-                     # fp32 paint is matrix-core bound like the fp32 train step (AI ~107 FLOP/B), bf16 paint HBM-bound
-                     "roofline": ({"bound": "hbm", "achieved": round(alg * n_paint / tp / 1e9, 1), "peak": PEAK_HBM_GBS,
-                                   "unit": "GB/s", "frac": round(alg * n_paint / tp / 1e9 / PEAK_HBM_GBS, 4),
-                                   "algorithmic_bytes_per_tile": alg} if args.dtype == "bf16" else
-                                  {"bound": "mfma", "achieved": round(flop * n_paint / tp / 1e12, 1),
-                                   "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                                   "frac": round(flop * n_paint / tp / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
-                                   "flop_per_tile": flop, "algorithmic_bytes_per_tile": alg}),
-                     "pcie_bytes_per_tile": 2 * 4 * args.tile ** 2,
-                     "note": "host float32 raw tile in -> host float32 physical tile out (pinned memory), per rank its "
-                             "own tiles, no collective; 'resident' = the captured forward alone on tiles already in "
-                             "HBM"}
-        model.train(True)
+        head = cgan_leg(args, dev, world, rank, sync, args.steps, args.warmup)
+        legs = []
+    else:
+        head = cvae_leg(args, args.dtype, dev, world, rank, sync, args.steps, args.warmup, paint=not args.no_paint)
+    extra = {}
+    for name in legs:
+        try:
+            if name == "bf16" and not (args.workload == "cvae" and args.dtype == "bf16"):
+                extra["bf16"] = cvae_leg(args, "bf16", dev, world, rank, sync, args.secondary_steps, 2,
+                                         paint=not args.no_paint)
+            elif name == "cgan" and args.workload != "cgan":
+                extra["cgan"] = cgan_leg(args, dev, world, rank, sync, max(2, args.secondary_steps // 4), 1)
+        except Exception as e:                      # a secondary leg must not cost the headline
+            import traceback
+            traceback.print_exc()
+            extra[name] = {"error": f"{type(e).__name__}: {e}"}
+            _free()
 
     if rank == 0:
-        # ---- roofline of the dominant kernel
-        per = {}
-        for e0, e1, unit, kind, nstreams in prof_events:
-            name = kernel_name(kind, unit, model._lib)
-            d = per.setdefault(name, {"ms": 0.0, "launches": 0, "flop": 0.0, "bytes": 0.0})
-            d["ms"] += e0.elapsed_time(e1)
-            d["launches"] += 1
-            if kind in ("forward", "backward_data", "backward_weight"):
-                d["flop"] += 2.0 * unit.macs(kind)
-            d["bytes"] += unit.algorithmic_bytes(kind, nstreams)
-        if args.layers:
-            lay = {}
-            for e0, e1, unit, kind, nstreams in prof_events:
-                fl = 2.0 * unit.macs(kind) if kind in ("forward", "backward_data", "backward_weight") else 0.0
-                d = lay.setdefault((unit.name, kind), [0.0, fl, unit.algorithmic_bytes(kind, nstreams),
-                                                       kernel_name(kind, unit, model._lib)])
-                d[0] += e0.elapsed_time(e1) / PROF_STEPS
-            for (name, kind), (ms, fl, by, kn) in sorted(lay.items(), key=lambda kv: -kv[1][0]):
-                print(f"{name:28s} {kind:16s} {ms:8.3f} ms  {fl / ms / 1e9:7.2f} TF/s  {by / ms / 1e6:8.1f} GB/s  {kn}",
-                      file=sys.stderr)
-        conv = {k: v for k, v in per.items() if v["flop"] > 0}
-        # fp32: the step is matrix-core bound (AI ~100 FLOP/B vs a ridge of 20): dominant = the convolution kernel with
-        # the most time, priced in TFLOP/s.  bf16: HBM-bound (ridge 310 FLOP/B): dominant = whichever kernel takes the
-        # most time, priced in algorithmic bytes per second.
-        hbm = args.dtype == "bf16"
-        pool = per if hbm else conv
-        dom = max(pool, key=lambda k: pool[k]["ms"])
-        d = per[dom]
-        conv_ms = sum(v["ms"] for v in conv.values()) / PROF_STEPS
-        traffic = None
-        try:       # HBM bytes per launch from the PMC passes (rocprofv3 cannot run inside bench.py); only quoted when
-            #        the stamp says the counters were collected on these very kernel sources
-            pj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-            if pj.get("source_hash") == source_hash():
-                traffic = pj["hbm_bytes_per_launch"].get(dom)
-        except Exception:
-            pass
-        if hbm:
-            achieved = d["bytes"] / (d["ms"] * 1e-3) / 1e9
-            roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                        "frac": round(achieved / PEAK_HBM_GBS, 4), "traffic": traffic,
-                        "algorithmic_bytes_per_launch": d["bytes"] / d["launches"]}
-        else:
-            achieved = d["flop"] / (d["ms"] * 1e-3) / 1e12
-            roofline = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
-                        "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
-                        "flop_per_launch": d["flop"] / d["launches"]}
-        all_bytes = sum(v["bytes"] for v in per.values()) / PROF_STEPS
-        roofline.update({
-            "avg_launch_ms": round(d["ms"] / d["launches"], 4), "launches_per_step": d["launches"] // PROF_STEPS,
-            "share_of_step": round(d["ms"] / PROF_STEPS / (dt / args.steps * 1e3), 3),
-            "measured_on": f"{PROF_STEPS} steps of the serial schedule (BP_SIDE_WGRAD=0 equivalent) run right after "
-                           "the timed region; in the timed region weight gradients overlap the rest of the "
-                           "backward pass on a second stream, so per-launch times there are not kernel times",
-            "all_conv_kernels_ms_per_step": round(conv_ms, 2),
-            "whole_step": {"tflops": round(n * 61.4e9 * (args.tile / 512) ** 2 / (dt / args.steps) / 1e12, 1),
-                           "algorithmic_GBs_timed_kernels": round(all_bytes / (dt / args.steps) / 1e9, 1)},
-            "per_kernel": {k: {"ms_per_step": round(v["ms"] / PROF_STEPS, 3),
-                               "tflops": round(v["flop"] / (v["ms"] * 1e-3) / 1e12, 2),
-                               "GBs": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1)}
-                           for k, v in sorted(per.items(), key=lambda kv: -kv[1]["ms"])}})
-        out = {
-            "metric": "cvae_train_tiles_per_sec", "value": round(world * n * args.steps / dt, 2), "unit": "tiles/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"CVAE fiducial train step (fwd+bwd+Adam), batch {n}/GPU of "
-                                   f"{args.tile}x{args.tile} tiles, " + (
-                                       "fp32 (BASELINE.json configs[1])" if args.dtype == "f32" else
-                                       "bf16 activations/gradients in the generator trunk, fp32 accumulation, master "
-                                       "weights and statistics (BASELINE.json configs[3] per GPU)"),
-                       "tile": args.tile, "batch_per_gpu": n, "global_batch": n * world,
-                       "parallelism": f"dp{world}", "batch_norm": "local" if args.local_bn or world == 1 and False
-                       else ("global (all-reduced statistics)" if world > 1 else "single device"),
-                       "optimizer": "torch.optim.Adam(lr=1e-3)" if args.torch_adam else "FlatAdam(lr=1e-3) = torch.optim.Adam arithmetic, fused",
-                       "schedule": "weight gradients on a second HIP stream beside the rest of the backward pass"
-                                   + ("; the whole step replayed from one hipGraph" if use_graph else "")
-                                   if os.environ.get("BP_SIDE_WGRAD", "1") != "0" else "single stream",
-                       "final_elbo": final_elbo},
-            "roofline": roofline,
-        }
-        out["paint"] = paint_leg
-        if coll is not None:
-            out["config"].update(coll)
+        out = {k: head[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step")}
+        out.update({"higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": head["dtype"],
+                    "data": "synthetic", "config": head["config"]})
+        other = {}
+        if head.get("paint"):
+            other["paint (configs[4] per GPU)"] = _compact(head["paint"])
+        if "bf16" in extra:
+            other["bf16 (configs[3] per GPU)"] = _compact(extra["bf16"])
+            if isinstance(extra["bf16"], dict) and extra["bf16"].get("paint"):
+                other["paint bf16"] = _compact(extra["bf16"]["paint"])
+        if "cgan" in extra:
+            other["cgan (configs[2])"] = _compact(extra["cgan"])
+        if other:
+            out["config"]["other_configs"] = other
+        # (the per-kernel table first, the numbers a reader wants last: a log tail keeps the end of the line)
+        out["roofline"] = head["roofline"]
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
+        if head.get("paint") is not None:
+            out["paint"] = head["paint"]
+        out.update(extra)
+        out["wall_s"] = round(time.time() - t_start, 1)
         print(json.dumps(out), flush=True)
     if torch.distributed.is_available() and torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()

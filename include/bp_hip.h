@@ -67,7 +67,9 @@ typedef struct bp_conv {
 enum { BP_IMPL_AUTO = 0, BP_IMPL_DIRECT = 1, BP_IMPL_MFMA = 2, BP_IMPL_BF16 = 3 };
 /* OR-ed into `impl` of bp_conv_backward_weight: the launch shares the GPU with kernels of another stream (the
  * training step runs weight gradients beside the data-gradient chain), so persistent kernels take one workgroup
- * per CU instead of two and leave room for the other stream's workgroups.  Same results bit for bit. */
+ * per CU instead of two and leave room for the other stream's workgroups (and the tiled weight gradients take fewer
+ * split-K workgroups).  Results are deterministic per schedule; between the two schedules the grouping of tiles into
+ * fp32 partial sums differs, so weight gradients may differ in their last bits. */
 enum { BP_IMPL_SHARED = 0x100 };
 enum { BP_PACK_FWD = 0, BP_PACK_BWD = 1 };
 
@@ -260,6 +262,10 @@ int bp_paint_store(const bp_view* src, const bp_pointwise* pw, int32_t softplus,
  * (torch.randn on the device in the reference: same distribution, no reproducible stream to match). */
 int bp_philox_normal(uint64_t seed, const int64_t* tile_ids, int32_t n, int32_t L, int32_t per_tile, float* eps,
                      void* stream);
+/* The same with the key read from device memory at run time: a launch captured in a hipGraph then serves every seed
+ * (the reference draws fresh torch.randn per tile, cvae.py:64: planes of a light cone must not share their noise). */
+int bp_philox_normal_dev(const uint64_t* seed_dev, const int64_t* tile_ids, int32_t n, int32_t L, int32_t per_tile,
+                         float* eps, void* stream);
 
 /* ---- latent heads: reparametrisation sampler + KL (cvae.py:63-66, 76-77, 126-130) ----------- */
 typedef struct bp_latent {

@@ -40,11 +40,15 @@ def discriminator(arch, x, P, prefix, training):
 
 
 class TorchCGAN:
-    def __init__(self, g_arch, d_arch, state, lambda_perceptual=2.5):
-        self.g_arch, self.d_arch, self.lam = g_arch, d_arch, lambda_perceptual
+    def __init__(self, g_arch, d_arch, state, lambda_perceptual=2.5, dtype=torch.float32):
+        """``dtype=torch.float64``: the same graph in double -- the "true value" the fp32 executions (this class in
+        float32 under different thread counts, and the HIP path) are measured against."""
+        self.g_arch, self.d_arch, self.lam, self.dtype = g_arch, d_arch, lambda_perceptual, dtype
         self.P = {}
         for k, v in state.items():
             t = torch.as_tensor(v).detach().cpu().clone()
+            if t.dtype.is_floating_point:
+                t = t.to(dtype)
             if t.dtype.is_floating_point and not k.endswith(("running_mean", "running_var", "weight_u", "weight_v")) \
                     and not (k.startswith("discriminator") and k.endswith(".weight")):
                 t.requires_grad_(True)
@@ -58,8 +62,8 @@ class TorchCGAN:
 
     def iteration(self, x, y, z, lr_g=5e-5, lr_d=5e-5):
         """One alternating iteration with Adam(betas=(0.5,0.999)); returns (losses, grads_d, grads_g)."""
-        x, y = torch.as_tensor(x), torch.as_tensor(y)
-        zc = torch.as_tensor(z, dtype=torch.float32).reshape(-1, 1, 1, 1) - 1.0
+        x, y = torch.as_tensor(x).to(self.dtype), torch.as_tensor(y).to(self.dtype)
+        zc = torch.as_tensor(z, dtype=torch.float32).to(self.dtype).reshape(-1, 1, 1, 1) - 1.0
         cond = torch.cat([y, zc.expand(-1, 1, *y.shape[-2:])], 1)
         fake = torch.tanh(_seq(self.g_arch[:-1], cond, self.P, "generator.", True))
         opt_d = torch.optim.Adam(list(self.d_params().values()), lr=lr_d, betas=(0.5, 0.999))

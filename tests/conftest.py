@@ -23,3 +23,11 @@ def golden_ops():
 def golden_model():
     import numpy as np
     return np.load(os.path.join(ROOT, "tests", "golden", "model.npz"))
+
+
+@pytest.fixture(scope="session")
+def golden_model_r3():
+    """Round-3 fixtures (tests/golden/make_goldens_r3.py): softened well-conditioned cases, sixteen tiles, two heads
+    at 512^2."""
+    import numpy as np
+    return np.load(os.path.join(ROOT, "tests", "golden", "model_r3.npz"))

@@ -10,19 +10,23 @@ from baryon_painter_amd.utils import synthetic as syn
 pytestmark = pytest.mark.gpu
 
 
-# gtol at 512^2: two fp32 executions of one graph differ by up to ~1e-2 in single gradients at this size (LeakyReLU /
-# batch-norm cancellation; measured for the CVAE against its float64 truth, tests/golden grad_variant_dist)
-@pytest.mark.parametrize("size,n_res,n,gtol", [(64, 2, 2, 2e-3), (512, 9, 2, 2e-2)])
-def test_cgan_iteration_matches_torch_restatement(size, n_res, n, gtol):
+@pytest.mark.parametrize("size,n_res,n", [(64, 2, 2), (512, 9, 2)])
+def test_cgan_iteration_matches_torch_restatement(size, n_res, n):
     """(64, 2 blocks): quick case.  (512, 9 blocks): the fiducial CGAN of BASELINE.json configs[2] at its real
     geometry -- the k9 stem / head at 512^2, nine residual blocks at 128^2, the 256- and 512-channel PatchGAN
-    layers -- one alternating D + G iteration, every loss and gradient."""
+    layers -- one alternating D + G iteration, every loss and gradient.
+
+    Gradient criterion (the CVAE's, tests/test_gpu_model.py): the restatement evaluated in FLOAT64 is the true value;
+    the float32 noise floor of each gradient is how far float32 executions of the same restatement (default / 4 / 2
+    threads: nothing but the summation order inside ATen changes) land from it; the HIP gradient may be at most
+    4x that far away, and never needs to be closer than 2e-3 of the tensor's scale."""
     from baryon_painter_amd.models.cgan import CGAN
     from oracle.cgan_torch import TorchCGAN
     torch.manual_seed(0)
     m = CGAN(tile_size=size, device="cuda:0", n_res=n_res)
     m.train(True)
-    ref = TorchCGAN(m.g_arch, m.d_arch, {k: v for k, v in m.state_dict().items()}, m.lambda_perceptual)
+    state = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    ref = TorchCGAN(m.g_arch, m.d_arch, state, m.lambda_perceptual)
     x, y, z = syn.synthetic_batch(n, size, size, seed=5)
     x = np.tanh(3 * x - 0.5).astype(np.float32)            # real field in the tanh domain
     opt_g = torch.optim.Adam(m.g_parameters(), lr=5e-5, betas=(0.5, 0.999))
@@ -32,17 +36,31 @@ def test_cgan_iteration_matches_torch_restatement(size, n_res, n, gtol):
     rl, gd, gg, fake = ref.iteration(x, y, z)
     for k in ("D", "G_adv", "G_perceptual"):
         assert abs(float(losses[k]) - rl[k]) <= 2e-5 * max(1.0, abs(rl[k])), (k, float(losses[k]), rl[k])
+    truth = TorchCGAN(m.g_arch, m.d_arch, state, m.lambda_perceptual, dtype=torch.float64)
+    _, td, tg, _ = truth.iteration(x, y, z)
+    variants = [(gd, gg)]
+    threads = torch.get_num_threads()
+    for t in (4, 2):
+        torch.set_num_threads(t)
+        v = TorchCGAN(m.g_arch, m.d_arch, state, m.lambda_perceptual)
+        _, vd, vg, _ = v.iteration(x, y, z)
+        variants.append((vd, vg))
+    torch.set_num_threads(threads)
     errs = []
-    for net, got, want in (("discriminator.", cap["d"], gd), ("generator.", cap["g"], gg)):
+    for idx, (net, got, want) in enumerate((("discriminator.", cap["d"], td), ("generator.", cap["g"], tg))):
         # a conv bias in front of a batch-norm has an exactly-zero gradient (rounding noise on both
         # sides): errors are measured against the larger of the tensor's and 1e-4 of the net's scale
-        floor = 1e-4 * max(float(v.abs().max()) for v in want.values() if v.numel() > 1)
+        scale0 = 1e-4 * max(float(v.abs().max()) for v in want.values() if v.numel() > 1)
+
+        def dist(a, w):
+            return float((a.cpu().double() - w).abs().max() / max(float(w.abs().max()), scale0))
         for k, g in got.items():
             w = want[net + k].double()
-            errs.append((float((g.cpu().double() - w).abs().max() / max(float(w.abs().max()), floor)), net + k))
+            floor = max(dist(var[idx][net + k], w) for var in variants)
+            errs.append((dist(g, w) / max(4 * floor, 2e-3), dist(g, w), floor, net + k))
     errs.sort(reverse=True)
-    print("worst CGAN gradient errors vs torch restatement:", errs[:4])
-    assert errs[0][0] < gtol, errs[:6]
+    print("worst CGAN gradients (distance from float64 / limit, distance, fp32 floor):", errs[:4])
+    assert errs[0][0] < 1.0, errs[:6]
     # spectral-norm power-iteration state after the two discriminator forwards
     after = m.state_dict()
     for k, t in ref.P.items():
@@ -136,3 +154,4 @@ def test_cgan_painter_api(tmp_path):
     assert raw.shape == (1, 1, tile, tile)
     with pytest.raises(ValueError):
         p.paint(dm[:10], z=z)
+

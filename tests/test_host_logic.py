@@ -160,10 +160,14 @@ assert sums.tolist() == [3.0, 30.0], sums
 flat = torch.full((1000,), float(r + 1))
 s.all_reduce_mean(flat)
 assert torch.allclose(flat, torch.full((1000,), 1.5))
-# gradients travel on their own communicator (may overlap the statistics' one on another stream), slice-wise
-assert s.overlap and s.grad_group is not s.group
+# default: ONE communicator for statistics and gradients (program order = the same order on every rank)
+assert not s.overlap and s.grad_group is s.group
+# opt-in: gradients on their own communicator (may overlap the statistics' one on another stream), slice-wise
+s2 = Sync(grad_group="new")
+assert s2.overlap and s2.grad_group is not s2.group
 part = torch.arange(10.0) * (r + 1)
-s.all_reduce_mean(part[2:5])
+s2.all_reduce_mean(part[2:5])
+s.n_grad += s2.n_grad; s.bytes_grad += s2.bytes_grad
 assert part[:2].tolist() == [0.0, 1.0 * (r + 1)] and torch.allclose(part[2:5], torch.tensor([3.0, 4.5, 6.0]))
 assert s.n_grad == 2 and s.bytes_grad == 4000 + 12 and s.n_small == 1
 local = Sync(sync_bn=False)
@@ -236,3 +240,32 @@ def test_device_loader_reproduces_dataloader_shuffle():
     ref = [int(v) for b in torch.utils.data.DataLoader(DS(), batch_size=4, shuffle=True) for v in b]
     torch.manual_seed(5)
     assert dataloader_shuffle_order(37) == ref
+
+
+def test_cgan_field_and_redshift_transforms_known_answers():
+    """g4: the CGAN's own conditioning transforms, pinned by hand-computed values.  Field transform mode
+    "shift-log-cam" of trained_models/CGAN/fiducial/transform.pickle (disassembled in SURVEY.md 8a g4):
+    t(x) = log(x / sigma + 1) / k0 - k1 with k = [4.0, 1.0]; redshift map f(z) = z - 1
+    (/root/reference/trained_models/README.md:99)."""
+    import torch
+    from baryon_painter_amd.painter import CGANPainter
+    from baryon_painter_amd.models.cgan import CGAN
+    p = CGANPainter.__new__(CGANPainter)
+    # sigma^2 tabulated at z = 0 and z = 1; sigma(0) = 2, sigma(1) = 4, linear IN THE VARIANCE in between
+    p.stats = {"dm": {0.0: {"mean": 1.0, "var": 4.0}, 1.0: {"mean": 1.0, "var": 16.0}},
+               "pressure": {0.0: {"mean": 0.1, "var": 0.25}, 1.0: {"mean": 0.1, "var": 0.25}}}
+    assert CGANPainter.K == (4.0, 1.0)
+    e = np.e
+    x = np.array([0.0, 2.0 * (e - 1), 2.0 * (e ** 4 - 1), 2.0 * (e ** 8 - 1)])
+    # log(x/2 + 1) = 0, 1, 4, 8  ->  /4 - 1  =  -1, -0.75, 0, 1: the tanh range of the generator
+    assert np.allclose(p.transform(x, "dm", 0.0), [-1.0, -0.75, 0.0, 1.0], atol=1e-6)
+    # z = 0.5: var = 10, sigma = sqrt(10); x = sigma * (e^2 - 1) -> 2/4 - 1 = -0.5
+    assert np.allclose(p.transform(np.array([np.sqrt(10.0) * (e ** 2 - 1)]), "dm", 0.5), [-0.5], atol=1e-6)
+    # beyond the last tabulated redshift the last entry holds (data_transforms.py:52-64)
+    assert np.allclose(p.transform(np.array([4.0 * (e ** 4 - 1)]), "dm", 3.0), [0.0], atol=1e-6)
+    # inverse: (exp((y + k1) * k0) - 1) * sigma; y = -1 is zero pressure, y = -0.75 is sigma * (e - 1)
+    assert np.allclose(p.inverse_transform(np.array([-1.0, -0.75]), "pressure", 0.0), [0.0, 0.5 * (e - 1)], atol=1e-12)
+    y = np.array([0.0, 0.03, 1.7, 250.0])
+    assert np.allclose(p.inverse_transform(p.transform(y, "pressure", 0.3), "pressure", 0.3), y, rtol=2e-5, atol=2e-6)
+    assert CGAN.z_transform(0.0) == -1.0 and CGAN.z_transform(2.0) == 1.0
+    assert torch.equal(CGAN.z_transform(torch.tensor([0.0, 0.5, 1.0])), torch.tensor([-1.0, -0.5, 0.0]))

@@ -179,6 +179,49 @@ def test_torch_cpu_restatement_matches_reference(tag, size, n, two, alpha, golde
         assert crop_rel_l2(f"{tag}/sample_P_eval_zfix", s, golden_model) <= 1e-6
 
 
+def test_oracle_on_softened_case(golden_model_r3):
+    """The float64 NumPy oracle against the reference's fp32 run of the WELL-CONDITIONED case (every ReLU softened to
+    LeakyReLU(0.9): tests/golden/make_goldens_r3.py).  Without ReLU-flip noise the reference's fp32 gradients and
+    the oracle's float64 ones agree to 1e-4 of each tensor's scale (the ReLU cases above: 1e-3)."""
+    gold, tag, size, n = golden_model_r3, "soft128_n4", 128, 4
+    arch = syn.softened_architecture(A.fiducial_architecture(size), 0.9)
+    m = O.CVAEOracle(arch, dtype=np.float64)
+    shapes = m.param_shapes()
+    m.load_params(syn.soften_params(syn.fill_params(shapes, 7), 0.9))
+    x, y, aux = syn.synthetic_batch(n, size, size, seed=1234)
+    eps = syn.synthetic_eps((1, n, *arch["dim_z"]), seed=99)
+    m.forward(x, y, aux, eps)
+    check(f"{tag}/stats", np.array(m.get_stats()), gold, 2e-5)
+    check(f"{tag}/x_mu", m.x_mu, gold, 5e-5)
+    g = m.backward(seed=-1.0)
+    for k in shapes:
+        check(f"{tag}/grad/{k}", g[k], gold, 1e-4, what="grad ")
+        check(f"{tag}/grad64/{k}", g[k], gold, 1e-6, what="grad64 ")       # (the stored truth IS this oracle's)
+    for k in m.buffer_shapes():
+        check(f"{tag}/buf/{k}", m.P[k], gold, 2e-5)
+
+
+@pytest.mark.parametrize("tag,alpha", [("twohead512_n2", 0.3), ("twohead512_n2_a1", 1.0)])
+def test_torch_cpu_restatement_two_heads_at_512(tag, alpha, golden_model_r3):
+    """oracle/torch_ref.py on the training script's two-head network at its real geometry against the reference's run
+    (forward quantities to fp32 rounding; gradients as in the other >= 256^2 cases)."""
+    from golden_util import crop_rel_l2
+    from oracle.torch_ref import TorchRefCVAE
+    gold = golden_model_r3
+    arch = A.fiducial_architecture(512, predict_var=True)
+    shapes = O.CVAEOracle(arch).param_shapes()
+    m = TorchRefCVAE(arch, syn.fill_params(shapes, 7))
+    m.alpha_var = alpha
+    x, y, aux = syn.synthetic_batch(2, 512, 512, seed=1234)
+    eps = syn.synthetic_eps((1, 2, *arch["dim_z"]), seed=99)
+    elbo = m.forward(x, y, aux, eps)
+    (-elbo).backward()
+    check(f"{tag}/stats", np.array(m.get_stats()), gold, 1e-6)
+    assert crop_rel_l2(f"{tag}/x_mu", m.x_mu.detach().numpy(), gold) <= 1e-6
+    for k in shapes:
+        check(f"{tag}/grad/{k}", m.P[k].grad.numpy(), gold, 5e-2, what="grad ")
+
+
 def test_conditioning_fixture_is_what_its_script_makes():
     """tests/golden/cond.npz (the float32 noise floor the GPU gradient tests use) against a fresh evaluation of one
     draw at 128^2 by tests/golden/make_goldens_cond.py: the fixture is data of the committed script, and the true

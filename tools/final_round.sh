@@ -1,4 +1,5 @@
 # The round's evidence in one GPU call (run from the repo root through gpurun): rocprofv3 passes (profile_round.sh,
+: "${GRAFT_REPO_ROOT:?run on the GPU box through gpurun}"
 # prof_bf16.sh), then the benches the documents quote.  Everything lands under gpurun_out/final/.
 set -e
 R=$GRAFT_REPO_ROOT

@@ -1,4 +1,5 @@
 # SQ / LDS counters of the bf16 trunk kernels (conv micro-benchmark), gpurun_out/pmc_bf16/
+: "${GRAFT_REPO_ROOT:?run on the GPU box through gpurun}"
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/pmc_bf16
 rm -rf $OUT; mkdir -p $OUT

@@ -1,4 +1,5 @@
 # SQ / LDS counters of fp32 igemm kernels on the thin strided layers (conv micro-benchmark), gpurun_out/pmc_f32/
+: "${GRAFT_REPO_ROOT:?run on the GPU box through gpurun}"
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/pmc_f32
 rm -rf $OUT; mkdir -p $OUT

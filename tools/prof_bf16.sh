@@ -1,4 +1,5 @@
 # rocprofv3 kernel trace of the bf16 step (serial schedule), summary to gpurun_out/prof_bf16/
+: "${GRAFT_REPO_ROOT:?run on the GPU box through gpurun}"
 set -e
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/prof_bf16

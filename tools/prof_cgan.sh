@@ -1,4 +1,5 @@
 # rocprofv3 kernel trace of the CGAN iteration, summary to gpurun_out/prof_cgan/
+: "${GRAFT_REPO_ROOT:?run on the GPU box through gpurun}"
 set -e
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/prof_cgan

@@ -1,4 +1,5 @@
 # rocprofv3 kernel trace of the paint_stream leg alone (fp32 and bf16 trunk), summaries to gpurun_out/prof_paint/
+: "${GRAFT_REPO_ROOT:?run on the GPU box through gpurun}"
 set -e
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/prof_paint

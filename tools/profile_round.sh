@@ -1,4 +1,5 @@
 # Collects the round's rocprofv3 evidence on the GPU box (run through gpurun from the repo root):
+: "${GRAFT_REPO_ROOT:?run on the GPU box through gpurun}"
 #   kernel trace + stats of the default command (weight gradients overlapped on a second stream) and of the
 #   serial schedule (BP_SIDE_WGRAD=0: every kernel alone on the GPU - the schedule bench.py times kernels in),
 #   and the two HBM-traffic PMC passes (separate passes: TCC has 4 slots) on the serial schedule.
