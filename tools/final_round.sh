@@ -19,12 +19,12 @@ cp $R/gpurun_out/prof_bf16/summary.txt $F/bf16_serial_kernel_stats_summary.txt
 cp $(ls $R/gpurun_out/prof_bf16/stats/*kernel_stats.csv | head -1) $F/bf16_serial_kernel_stats.csv
 echo "prof_bf16 done"
 cd $R
-python bench.py > $F/bench_f32.json 2> $F/bench_f32.err
+python bench.py --legs none > $F/bench_f32.json 2> $F/bench_f32.err
 echo "bench f32 done"; cut -c1-160 $F/bench_f32.json
-python bench.py --dtype bf16 > $F/bench_bf16.json 2> $F/bench_bf16.err
+python bench.py --legs none --dtype bf16 > $F/bench_bf16.json 2> $F/bench_bf16.err
 echo "bench bf16 done"; cut -c1-160 $F/bench_bf16.json
-python bench.py --layers --no-cpu-baseline --no-paint > $F/f32_layers.txt 2>&1
-python bench.py --layers --no-cpu-baseline --no-paint --dtype bf16 > $F/bf16_layers.txt 2>&1
+python bench.py --legs none --layers --no-cpu-baseline --no-paint > $F/f32_layers.txt 2>&1
+python bench.py --legs none --layers --no-cpu-baseline --no-paint --dtype bf16 > $F/bf16_layers.txt 2>&1
 echo "layers done"
-python bench.py --workload cgan --steps 4 --warmup 1 --no-cpu-baseline > $F/bench_cgan.json 2> $F/bench_cgan.err
+python bench.py --legs none --workload cgan --steps 4 --warmup 1 --no-cpu-baseline > $F/bench_cgan.json 2> $F/bench_cgan.err
 echo "cgan done"; cut -c1-160 $F/bench_cgan.json

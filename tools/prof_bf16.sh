@@ -6,6 +6,6 @@ OUT=$R/gpurun_out/prof_bf16
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 export BP_SIDE_WGRAD=0 BP_BRANCH_STREAMS=0
-timeout -k 10 500 rocprofv3 --kernel-trace --stats -d $OUT/stats -o r --output-format csv -- python3 $R/bench.py --dtype bf16 --steps 3 --warmup 1 --no-cpu-baseline --no-paint > $OUT/stats.log 2>&1
+timeout -k 10 500 rocprofv3 --kernel-trace --stats -d $OUT/stats -o r --output-format csv -- python3 $R/bench.py --legs none --dtype bf16 --steps 3 --warmup 1 --no-cpu-baseline --no-paint > $OUT/stats.log 2>&1
 python3 $R/tools/prof_summary.py $(ls $OUT/stats/*kernel_stats.csv | head -1) 6 60 > $OUT/summary.txt
 cat $OUT/summary.txt

@@ -8,7 +8,7 @@ R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/prof_round
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="$R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-paint $BENCH_EXTRA"
+ARGS="$R/bench.py --legs none --steps 2 --warmup 1 --no-cpu-baseline --no-paint $BENCH_EXTRA"
 timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $OUT/stats -o r --output-format csv -- python3 $ARGS > $OUT/stats.log 2>&1
 export BP_SIDE_WGRAD=0 BP_BRANCH_STREAMS=0
 timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $OUT/stats_serial -o r --output-format csv -- python3 $ARGS > $OUT/stats_serial.log 2>&1

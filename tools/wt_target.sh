@@ -1,5 +1,5 @@
 #!/bin/bash
-run() { env $1 python bench.py --steps 16 --warmup 3 --no-cpu-baseline --no-paint 2>/dev/null | python -c "
+run() { env $1 python bench.py --legs none --steps 16 --warmup 3 --no-cpu-baseline --no-paint 2>/dev/null | python -c "
 import sys, json
 d = json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$1', d['value'], d['ms_per_step'])"; }
 run BP_X=1
