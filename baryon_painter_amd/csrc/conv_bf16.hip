@@ -9,6 +9,13 @@ int bp_bf16_launch_cc8(const BConfig& c, const BArgs& a, bool in_bf16, bool out_
 int bp_bf16_launch_cc16(const BConfig& c, const BArgs& a, bool in_bf16, bool out_bf16, dim3 grid, hipStream_t st);
 int bp_bf16_launch_cc32(const BConfig& c, const BArgs& a, bool in_bf16, bool out_bf16, dim3 grid, hipStream_t st);
 
+// conv_bf16_flat.hip: flattened-K kernel for the unit-stride k7 head layers; its weight image follows the generic one
+int64_t bp_bf16_flat_packed_elems(const ConvGeom& g);
+int bp_bf16_flat_pack(const ConvGeom& g, const WeightMap& wm, const float* w_torch, u16* dst, hipStream_t st);
+bool bp_bf16_flat_ok(const ConvGeom& g, const bp_view* in, const bp_view* out, const float* bias, bool stats);
+int bp_bf16_flat_run(const ConvGeom& g, const bp_view* in, const PW& pw, const u16* packed_flat, const bp_view* out,
+                     hipStream_t st);
+
 namespace {
 
 struct BPackArgs {
@@ -73,10 +80,15 @@ bool bp_bf16_igemm_ok(const ConvGeom& g, const bp_view* in, const bp_view* out) 
   return true;
 }
 
+static int64_t generic_packed_elems(const ConvGeom& g, const BConfig& c) {
+  return (int64_t)g.nphase * g.nphase * g.taps * c.nrun * c.nchunk * c.cout_padP * 32;
+}
+
+// [generic image | flattened-K image (conv_bf16_flat.hip) where that kernel applies]
 int64_t bp_bf16_packed_elems(const ConvGeom& g) {
   const BConfig c = b_config(g);
   if (!c.ok) return -1;
-  return (int64_t)g.nphase * g.nphase * g.taps * c.nrun * c.nchunk * c.cout_padP * 32;
+  return generic_packed_elems(g, c) + bp_bf16_flat_packed_elems(g);
 }
 
 int bp_bf16_pack(const ConvGeom& g, const WeightMap& wm, const float* w_torch, void* packed, hipStream_t st) {
@@ -88,9 +100,10 @@ int bp_bf16_pack(const ConvGeom& g, const WeightMap& wm, const float* w_torch, v
   a.transposed = g.gather_transposed; a.IS = g.IS; a.cin_g = g.cin_g; a.cout_g = g.cout_g;
   a.CC = c.CC; a.nchunk = c.nchunk; a.cout_padP = c.cout_padP; a.COB = c.COB; a.NT = c.NT; a.nrun = c.nrun;
   for (int s = 0; s < c.nrun; ++s) { a.run_xm[s] = c.run_xm[s]; a.run_xq[s] = c.run_xq[s]; }
-  a.total = bp_bf16_packed_elems(g);
+  a.total = generic_packed_elems(g, c);
   hipLaunchKernelGGL(pack_bf16_kernel, dim3((unsigned)((a.total + 255) / 256)), dim3(256), 0, st, a);
   BP_CHECK_LAUNCH();
+  if (bp_bf16_flat_packed_elems(g) > 0) return bp_bf16_flat_pack(g, wm, w_torch, a.dst + a.total, st);
   return BP_OK;
 }
 
@@ -114,6 +127,8 @@ int bp_bf16_igemm_run(const ConvGeom& g, const bp_view* in, const PW& pw, const 
                       const bp_view* out, hipStream_t st, const IgemmStatsReq* sr) {
   const BConfig c = b_config(g);
   if (!c.ok || !bp_bf16_igemm_ok(g, in, out)) return BP_EUNSUPPORTED;
+  if (bp_bf16_flat_ok(g, in, out, bias, sr != nullptr))
+    return bp_bf16_flat_run(g, in, pw, reinterpret_cast<const u16*>(packed) + generic_packed_elems(g, c), out, st);
   BArgs a{};
   a.in = in->ptr; a.in_h = in->h; a.in_w = in->w; a.in_cs = in->cstride; a.in_co = in->coff; a.cin = g.cin_g;
   a.out = out->ptr; a.out_h = out->h; a.out_w = out->w; a.out_cs = out->cstride; a.out_co = out->coff;

@@ -750,6 +750,7 @@ class CVAE(torch.nn.Module):
             self._graphs[key] = g
         for u in g["units"]:
             u.maybe_pack()                       # eager, a no-op unless the weights changed
+            u.maybe_bn_eval()                    # ... or the running statistics
         g["y"].copy_(y)
         if aux is not None:
             g["aux"].copy_(aux)
@@ -784,6 +785,7 @@ class CVAE(torch.nn.Module):
             self._graphs[key] = g
         for u in g["units"]:
             u.maybe_pack()
+            u.maybe_bn_eval()
         return g
 
     def _capture_paint_graph(self, n, given_z=False, pipeline=False):

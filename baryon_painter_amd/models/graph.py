@@ -439,6 +439,9 @@ class ConvUnit:
         self.maybe_pack()
         hold = self.holder
         fused = training and self.fwd_stats
+        if training and self.bn is not None:
+            # (running statistics and this unit's pending scale / shift are about to change: eval-mode users recompute)
+            plan.model._bn_epoch = getattr(plan.model, "_bn_epoch", 0) + 1
         # single device: the batch-norm finalize rides on the launch that sums the epilogue's partial rows
         fused_bn = fused and self.bn is not None and FUSED_FINALIZE \
             and not (plan.sync is not None and plan.sync.sync_bn)
@@ -488,9 +491,29 @@ class ConvUnit:
                                        L.ptr(self.out_pw.scale), L.ptr(self.out_pw.shift),
                                        L.ptr(self.save_mean), L.ptr(self.save_invstd), st), f"{self.name} bn")
         else:
-            L.check(lib.bp_bn_eval_pointwise(c, L.ptr(bn.weight), L.ptr(bn.bias), L.ptr(bn.running_mean),
-                                             L.ptr(bn.running_var), float(bn.eps), L.ptr(self.out_pw.scale),
-                                             L.ptr(self.out_pw.shift), st), f"{self.name} bn eval")
+            self.maybe_bn_eval()
+
+    def maybe_bn_eval(self):
+        """Eval mode: the per-channel (scale, shift) of this layer's batch-norm from its running statistics.  They only
+        change when the parameters or the running statistics do, so the launch is skipped while neither has (one tiny
+        launch per batch-norm layer and batch otherwise: 168 per replay of the paint graph).  A captured graph does
+        not contain it: its owner calls this eagerly before a replay, next to ``maybe_pack``."""
+        bn = self.bn
+        if bn is None:
+            return
+        m = self.plan.model
+        ts = (bn.weight, bn.bias, bn.running_mean, bn.running_var)
+        ver = (getattr(m, "_param_epoch", 0), getattr(m, "_bn_epoch", 0)) + \
+            tuple((t._version, t.data_ptr()) if t is not None else None for t in ts)
+        if ver == getattr(self, "_bn_eval_version", None):
+            return
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError(f"{self.name}: batch-norm statistics changed inside a graph capture")
+        L.check(self.plan.lib.bp_bn_eval_pointwise(self.cv.cout, L.ptr(bn.weight), L.ptr(bn.bias),
+                                                   L.ptr(bn.running_mean), L.ptr(bn.running_var), float(bn.eps),
+                                                   L.ptr(self.out_pw.scale), L.ptr(self.out_pw.shift), _stream()),
+                f"{self.name} bn eval")
+        self._bn_eval_version = ver
 
     # ---- backward
     def prepare_backward(self):

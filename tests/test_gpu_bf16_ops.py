@@ -55,12 +55,14 @@ CASES = [
     (1, 64, 32, 4, 2, 1, (3, 5, 9), None),
     (1, 32, 16, 4, 2, 1, (2, 9, 21), None),
     (0, 16, 8, 7, 1, 3, (2, 19, 35), None),         # p_mu_out.0 (data gradient gathers 8 channels: CC = 8)
+    (0, 16, 8, 7, 1, 3, (3, 37, 150), None),        # ... several 64 x 16 tiles of the flattened-K kernel (conv_bf16_flat.hip:
+    #                                                 bf16 -> fp32 forward, fp32 -> bf16 data gradient), ragged both ways
 ]
 
 
 @pytest.mark.parametrize("io", [(True, True), (False, True), (True, False), (False, False)],
                          ids=["bf16-bf16", "f32-bf16", "bf16-f32", "f32-f32"])
-@pytest.mark.parametrize("case", CASES, ids=lambda c: "%s%d_%d_k%ds%d" % ("T" if c[0] else "C", *c[1:5]))
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "%s%d_%d_k%ds%d_%dx%d" % ("T" if c[0] else "C", *c[1:5], *c[6][1:]))
 def test_bf16_convolution_forward_dgrad_wgrad(case, io):
     lib = L.load()
     tr, ci, co, k, s, p, (n, h, w), in_cs = case
