@@ -348,8 +348,8 @@ class CVAEPainter(Painter):
             raise NotImplementedError("Painting with more than one output field is not supported yet.")
         k_in, st_in = find(self.transform, 0, self.input_field)
         k_out, st_out = find(self.inverse_transform, 1, self.label_fields[0])
-        s_in = np.array([np.sqrt(T.interpolate_z(st_in, float(z))["var"]) for z in zs])
-        s_out = np.array([np.sqrt(T.interpolate_z(st_out, float(z))["var"]) for z in zs])
+        s_in = np.sqrt(T.interpolate_z_many(st_in, zs, "var"))          # (vectorised: no Python call per tile)
+        s_out = np.sqrt(T.interpolate_z_many(st_out, zs, "var"))
         return s_in, k_in, k_out, s_out
 
     def paint_stream(self, inputs, z, batch_size=64, tile_ids=None, seed=0, rank=0, world_size=1, out=None):
@@ -391,17 +391,26 @@ class CVAEPainter(Painter):
         # Two slots = the graph's own two buffer sets (CVAE.paint_graph): uploads land where bp_paint_load reads,
         # downloads leave from where bp_paint_store writes.  Per slot one pinned parameter block (one copy per batch).
         layout = g["block_layout"]
+        # pinned host buffers are kept between calls (page-locking 4 x 64 MiB costs tens of milliseconds per call)
+        cache = self.__dict__.setdefault("_paint_host_buffers", {})
+        key = (B, H, W, g["block_bytes"], str(dev))
+        if key not in cache:
+            cache.clear()
+            cache[key] = [{"h_blk": torch.zeros(g["block_bytes"], dtype=torch.uint8).pin_memory(), "h_in": None,
+                           "h_out": None} for _ in range(2)]
         slots = []
-        for gs in g["slots"]:
-            h_blk = torch.zeros(g["block_bytes"], dtype=torch.uint8).pin_memory()
+        for gs, hb in zip(g["slots"], cache[key]):
+            h_blk = hb["h_blk"]
             hv = {}
             for name, (o, dt, shape) in layout.items():
                 nb = torch.tensor([], dtype=dt).element_size() * int(np.prod(shape))
                 hv[name] = h_blk[o:o + nb].view(dt).view(shape).numpy()
             hv["seed"][0] = np.array(int(seed) & 0xFFFFFFFFFFFFFFFF, dtype=np.uint64).astype(np.int64)
-            slots.append({"g": gs, "h_blk": h_blk, "hv": hv,
-                          "h_in": None if torch_in else torch.empty((B, 1, H, W), dtype=torch.float32).pin_memory(),
-                          "h_out": None if torch_out else torch.empty((B, 1, H, W), dtype=torch.float32).pin_memory(),
+            if not torch_in and hb["h_in"] is None:
+                hb["h_in"] = torch.empty((B, 1, H, W), dtype=torch.float32).pin_memory()
+            if not torch_out and hb["h_out"] is None:
+                hb["h_out"] = torch.empty((B, 1, H, W), dtype=torch.float32).pin_memory()
+            slots.append({"g": gs, "h_blk": h_blk, "hv": hv, "h_in": hb["h_in"], "h_out": hb["h_out"],
                           "ev_up": torch.cuda.Event(), "ev_done": torch.cuda.Event(), "ev_down": torch.cuda.Event(),
                           "pending": None})
 
@@ -414,31 +423,48 @@ class CVAEPainter(Painter):
                 result[a - lo:b - lo] = sl["h_out"][:b - a, 0].numpy()
             sl["pending"] = None
 
+        starts = list(range(lo, hi, B))
+
+        def upload(bi):
+            """Fill slot bi % 2's pinned buffers with batch bi and start its host-to-device copies."""
+            a = starts[bi]
+            b = min(a + B, hi)
+            m = b - a
+            sl = slots[bi % 2]
+            gs, hv = sl["g"], sl["hv"]
+            sl["ev_up"].synchronize()                     # the slot's previous upload has left its pinned buffers
+            hv["xf_in"][:m, 0], hv["xf_in"][:m, 1] = s_in[a - lo:b - lo], k_in
+            hv["xf_out"][:m, 0], hv["xf_out"][:m, 1] = k_out, s_out[a - lo:b - lo]
+            hv["aux"][:m, 0] = zs[a:b]
+            hv["tile_ids"][:m] = ids[a:b]
+            if m < B:                                     # a short last batch: pad with its last tile's parameters
+                for k in ("xf_in", "xf_out", "aux", "tile_ids"):
+                    hv[k][m:] = hv[k][m - 1]
+            if torch_in:
+                src = inputs[a:b].reshape(m, 1, H, W)
+            else:
+                sl["h_in"][:m, 0].numpy()[...] = np.asarray(inputs[a:b], dtype=np.float32)
+                src = sl["h_in"][:m]
+            up.wait_event(sl["ev_done"])                  # the slot's previous batch has been painted (inputs read)
+            with torch.cuda.stream(up):
+                gs["raw"][:m].copy_(src, non_blocking=True)
+                gs["block"].copy_(sl["h_blk"], non_blocking=True)
+                sl["ev_up"].record(up)
+
         with torch.no_grad():
-            for bi, a in enumerate(range(lo, hi, B)):
+            if starts:
+                upload(0)
+            for bi, a in enumerate(starts):
                 b = min(a + B, hi)
                 m = b - a
                 sl = slots[bi % 2]
-                gs, hv = sl["g"], sl["hv"]
+                gs = sl["g"]
+                # The NEXT batch's upload is enqueued BEFORE this batch's graph: copies enqueued behind a graph launch
+                # only start once that graph has drained (measured: tools/paint_probe.py -- the upload then sits on the
+                # critical path, 1.2 ms per 64 tiles); enqueued ahead of it they run beside it.
+                if bi + 1 < len(starts):
+                    upload(bi + 1)
                 harvest(sl)                                   # this slot's previous batch has left the device
-                sl["ev_up"].synchronize()                     # ... and its parameter block has been uploaded
-                hv["xf_in"][:m, 0], hv["xf_in"][:m, 1] = s_in[a - lo:b - lo], k_in
-                hv["xf_out"][:m, 0], hv["xf_out"][:m, 1] = k_out, s_out[a - lo:b - lo]
-                hv["aux"][:m, 0] = zs[a:b]
-                hv["tile_ids"][:m] = ids[a:b]
-                if m < B:                                     # a short last batch: pad with its last tile's parameters
-                    for k in ("xf_in", "xf_out", "aux", "tile_ids"):
-                        hv[k][m:] = hv[k][m - 1]
-                if torch_in:
-                    src = inputs[a:b].reshape(m, 1, H, W)
-                else:
-                    sl["h_in"][:m, 0].numpy()[...] = np.asarray(inputs[a:b], dtype=np.float32)
-                    src = sl["h_in"][:m]
-                up.wait_event(sl["ev_done"])                  # the slot's previous batch has been painted (inputs read)
-                with torch.cuda.stream(up):
-                    gs["raw"][:m].copy_(src, non_blocking=True)
-                    gs["block"].copy_(sl["h_blk"], non_blocking=True)
-                    sl["ev_up"].record(up)
                 main.wait_event(sl["ev_up"])
                 main.wait_event(sl["ev_down"])                # ... and its previous output has been downloaded
                 gs["graph"].replay()

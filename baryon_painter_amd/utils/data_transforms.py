@@ -38,6 +38,23 @@ def interpolate_z(stats_of_field, z):
     return {k: w * stats_of_field[hi][k] + (1 - w) * stats_of_field[lo][k] for k in stats_of_field[zs[0]]}
 
 
+def interpolate_z_many(stats_of_field, zs, key="var"):
+    """``interpolate_z(stats_of_field, z)[key]`` for an array of redshifts at once -- the same float64 arithmetic
+    element by element (w * hi + (1 - w) * lo, clamped at both ends), without a Python call per tile
+    (paint_stream: 100k tiles)."""
+    tab = np.array(list(stats_of_field.keys()), dtype=np.float64)
+    val = np.array([stats_of_field[z][key] for z in stats_of_field.keys()], dtype=np.float64)
+    zs = np.asarray(zs, dtype=np.float64)
+    idx = np.searchsorted(tab, zs, side="right")
+    i1 = np.clip(idx, 1, len(tab) - 1) if len(tab) > 1 else np.zeros_like(idx)
+    i0 = i1 - 1 if len(tab) > 1 else i1
+    with np.errstate(divide="ignore", invalid="ignore"):
+        w = (zs - tab[i0]) / (tab[i1] - tab[i0]) if len(tab) > 1 else np.zeros_like(zs)
+        out = w * val[i1] + (1 - w) * val[i0]
+    out = np.where(idx >= len(tab), val[-1], out)
+    return np.where(idx <= 0, val[0], out)
+
+
 # mode -> (forward, inverse); each takes (x, k, std, mean, eps).  Formulas: data_transforms.py:72-108.
 _MODES = {
     "log": (lambda x, k, std, mean, eps: np.where(x > 0, np.log(x / std + eps) / k, np.log(eps) / k),

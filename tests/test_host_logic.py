@@ -269,3 +269,17 @@ def test_cgan_field_and_redshift_transforms_known_answers():
     assert np.allclose(p.inverse_transform(p.transform(y, "pressure", 0.3), "pressure", 0.3), y, rtol=2e-5, atol=2e-6)
     assert CGAN.z_transform(0.0) == -1.0 and CGAN.z_transform(2.0) == 1.0
     assert torch.equal(CGAN.z_transform(torch.tensor([0.0, 0.5, 1.0])), torch.tensor([-1.0, -0.5, 0.0]))
+
+
+def test_vectorised_redshift_interpolation_equals_the_scalar_one():
+    """paint_stream's per-tile sigma table (data_transforms.interpolate_z_many) is bit for bit the reference's
+    per-call interpolation (data_transforms.py:52-64: searchsorted side="right", clamped at both ends)."""
+    from baryon_painter_amd.utils import data_transforms as T
+    rng = np.random.default_rng(0)
+    st = {0.0: {"mean": 1.0, "var": 1.47251}, 0.125: {"mean": 1.0, "var": 1.3}, 0.5: {"mean": 1.0, "var": 0.9},
+          2.0: {"mean": 1.0, "var": 0.1165}}
+    zs = np.concatenate([rng.uniform(-0.5, 2.5, 500), [0.0, 0.125, 0.5, 2.0, 1.9999999, 2.0000001, -1e-9]])
+    for key in ("var", "mean"):
+        assert np.array_equal(np.array([T.interpolate_z(st, float(z))[key] for z in zs]), T.interpolate_z_many(st, zs, key))
+    one = {0.3: {"mean": 1.0, "var": 2.0}}
+    assert np.array_equal(T.interpolate_z_many(one, zs), np.full(len(zs), 2.0))

@@ -1,6 +1,6 @@
 #!/bin/bash
 # after `gpurun -- bash tools/final_round.sh`: copy the merged evidence from gpurun_out/final/ into profiles/ (tracked)
-F=gpurun_out/final; R=${1:-r02}
+F=${2:-gpurun_out/r3_final}; R=${1:-r03}
 cp $F/pmc_traffic.json profiles/pmc_traffic.json
 for n in bench_f32.json bench_bf16.json bench_cgan.json f32_layers.txt bf16_layers.txt f32_pmc_hbm_traffic_per_kernel.txt \
          f32_default_kernel_stats_summary.txt f32_serial_kernel_stats_summary.txt f32_default_kernel_stats.csv \
