@@ -1,47 +1,59 @@
-// Flattened-K bf16 matrix-core kernel for the UNIT-STRIDE k = 7 layers of the generator heads in throughput mode
-// (BASELINE.json configs[3] / [4]): p_mu_out.0 / p_var_out.0 forward (16 -> 8 channels at full resolution) and their
-// data gradient (8 -> 16).  These two launches were the largest single-layer item of the bf16 step (2 x 0.87 ms,
-// 0.2-0.3 PFLOP/s in igemm_bf16_kernel<16,1,1,4,6,...>: a 16-pixel x 8-channel tile per tap-row slab, weights
-// re-streamed through LDS per tile, two barriers per tap row); at bf16 matrix speed the layer is 0.11 ms of MFMA and
-// 0.17 ms of HBM.
+// Flattened-K bf16 matrix-core kernel for the UNIT-STRIDE few-channel layers at full resolution in throughput mode
+// (BASELINE.json configs[3] / [4]):
+//     p_mu_out.0 / p_var_out.0   k7  16 -> 8    forward (bf16 trunk in, fp32 out) and data gradient (8 -> 16, fp32 in,
+//                                               bf16 out)
+//     p_y_z_in.0  (the stem)     k5  3(+1) -> 16  forward (fp32 in, bf16 out, batch-norm sums from the epilogue) and the
+//                                               data gradient restricted to the latent channel (16 -> 1, bf16 in, fp32 out)
+// These launches were the largest single-layer items of the bf16 step in igemm_bf16_kernel (a 16-pixel tile per
+// tap-row slab, weights re-streamed through LDS per tile, two barriers per tap row: 0.2-0.3 PFLOP/s, 1-2 TB/s); at bf16
+// matrix speed each of them is 0.03-0.11 ms of MFMA and 0.15-0.25 ms of HBM.
 //
 // Scheme (the bf16 counterpart of conv_flat.hip):
-//   * GEMM K = the FLATTENED (tap column, channel) index of one tap row -- 7 x CIN consecutive bf16 of an NHWC row --
-//     cut into blocks of 32 (v_mfma_f32_16x16x32_bf16); the packed weights carry zeros past 7 x CIN, so a lane's
-//     operand is always ONE 16-byte LDS read of 8 consecutive bf16 of the staged row, whatever the tap.
-//   * MFMA rows = produced channels.  With 8 produced channels the 16 rows hold TWO output rows: row block rs uses
-//     tap row ky - rs, so one input-row fragment feeds both (weight fragment "pair p" = [W[p] | W[p-1]]).
+//   * GEMM K = the FLATTENED (tap column, channel) index of one tap row -- KS x CIN consecutive bf16 of an NHWC row --
+//     cut into blocks of 32 (v_mfma_f32_16x16x32_bf16); the packed weights carry zeros past KS x CIN, so a lane's
+//     operand is always 8 consecutive bf16 of the staged row (one 16-byte LDS read; two 8-byte reads for CIN = 4).
+//   * MFMA rows = produced channels.  With COUTP < 16 produced channels the 16 rows hold RS = 16 / COUTP OUTPUT ROWS:
+//     row block rs uses tap row ky - rs, so one input-row fragment feeds all of them (weight fragment "p" =
+//     [W[p] | W[p-1] | ...]).
 //   * A wave owns 16 pixels x 4 output rows per pass: an input-row fragment is read once and multiplied with up to
-//     two (8 channels) / four (16 channels) weight fragments; ALL weight fragments (32 / 14) live in registers, loaded
-//     once per workgroup -- no weight traffic, no barrier inside a tile.
+//     4 / RS weight fragments; ALL weight fragments live in registers, loaded once per workgroup -- no weight traffic
+//     through LDS, no barrier inside a tile.
 //   * D = W x X: a lane ends up with 4 consecutive channels of one pixel -> 16-byte fp32 / 8-byte bf16 stores, 512
 //     contiguous bytes per output row and instruction.
 //   * Staging: every unit of the halo tile is loaded unconditionally from clamped coordinates, all loads of the tile
 //     in flight at once, kept as raw words; the producer's pending batch-norm + (leaky) ReLU is applied and the value
 //     rounded to bf16 on the way into LDS, zero padding after the activation (as torch pads the activated tensor).
+//   * STATS: training-mode batch-norm sums {sum y, sum y^2} of the tensor AS STORED (bf16-rounded) from the
+//     accumulators: a lane's 16 values in fp32, the 16 lanes of a channel quad by shuffles, the four waves through
+//     LDS; one fixed-order row of doubles per tile (conv_igemm.hip folds the rows).
 #include "conv_bf16.hpp"
 
 using namespace bpbf16;
 
+// conv_igemm.hip: partial rows of epilogue statistics -> sums (+ the fused batch-norm finalize)
+size_t bp_stats_rows_bytes(int64_t rows, int C);
+int bp_stats_rows_finish(double* ws, int64_t rows, int C, const IgemmStatsReq* sr, hipStream_t st);
+
 namespace {
 
 struct FbArgs {
-  const void* in; int h, w, in_cs, in_co;
-  void* out; int out_cs, out_co;
+  const void* in; int h, w, in_cs, in_co, cin;
+  void* out; int out_cs, out_co, cout;
   const u16* wp;
   PW pw;
   int tiles_x, tiles_y, n;
+  double* stat; int stat_c;
 };
 
-constexpr int FB_K = 7, FB_PAD = 3;
 constexpr int FB_TW = 64, FB_TH = 16, FB_R = 4;
-constexpr int FB_LW = FB_TW + FB_K - 1, FB_LH = FB_TH + FB_K - 1;
 
-template <int CIN> struct FbShape {
-  static constexpr int KB = (FB_K * CIN + 31) / 32;
-  static constexpr int ROWE = FB_LW * CIN;                    // bf16 per staged row
-  static constexpr int SLACK = 32;                            // the last K block reads up to one pixel past a row
-  static constexpr size_t LDS = ((size_t)FB_LH * ROWE + SLACK) * 2 + 3 * CIN * sizeof(float);
+template <int KS, int CIN> struct FbShape {
+  static constexpr int KB = (KS * CIN + 31) / 32;
+  static constexpr int LW = FB_TW + KS - 1, LH = FB_TH + KS - 1;
+  static constexpr int ROWE = LW * CIN;                       // bf16 per staged row
+  static_assert(ROWE % 8 == 0, "a staged row is a whole number of 8-element units");
+  static constexpr int SLACK = 32;                            // the last K block reads up to one unit past a row
+  static constexpr size_t LDS = ((size_t)LH * ROWE + SLACK) * 2 + 3 * 16 * sizeof(float) + 4 * 32 * sizeof(double);
 };
 
 // XCD-aware tile order: workgroups go to the 8 XCDs round-robin by linear id; give each XCD a contiguous run of
@@ -53,19 +65,23 @@ __device__ __forceinline__ int fb_tile_of_block(int n) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
-template <int CIN, int COUT, bool IN_BF16, bool OUT_BF16>
-__global__ __launch_bounds__(256, 3) void flatb_k7_kernel(FbArgs a) {
-  using S = FbShape<CIN>;
-  constexpr int KB = S::KB, ROWE = S::ROWE;
-  constexpr int RS = 16 / COUT;                 // output rows per MFMA
-  constexpr int NP = FB_K + RS - 1;             // weight fragments per K block ("pairs")
+template <int KS, int CIN, int COUTP, bool IN_BF16, bool OUT_BF16, bool STATS>
+__global__ __launch_bounds__(256, 3) void flatb_kernel(FbArgs a) {
+  using S = FbShape<KS, CIN>;
+  constexpr int KB = S::KB, ROWE = S::ROWE, LH = S::LH, PAD = KS / 2;
+  constexpr int RS = 16 / COUTP;                // output rows per MFMA
+  constexpr int NP = KS + RS - 1;               // weight fragments per K block
   constexpr int NS = FB_R / RS;                 // accumulator sets per pass
-  constexpr int UPP = CIN / 8;                  // 8-channel staging units per pixel
-  constexpr int NU = FB_LH * FB_LW * UPP;
+  constexpr int UPR = ROWE / 8;                 // 8-element staging units per row
+  constexpr int NPX = CIN >= 8 ? 1 : 8 / CIN;   // pixels per unit
+  constexpr int UPP = CIN >= 8 ? CIN / 8 : 1;   // units per pixel
+  constexpr int NU = LH * UPR;
   constexpr int SLOTS = (NU + 255) / 256;
+  static_assert(256 % UPP == 0 && (IN_BF16 || CIN <= 8), "staging layout");
   extern __shared__ __attribute__((aligned(16))) u16 smem_fb[];
   u16* lds = smem_fb;
-  float* lpw = reinterpret_cast<float*>(lds + FB_LH * ROWE + S::SLACK);
+  float* lpw = reinterpret_cast<float*>(lds + LH * ROWE + S::SLACK);
+  double* red = reinterpret_cast<double*>(lpw + 3 * 16);
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -78,48 +94,77 @@ __global__ __launch_bounds__(256, 3) void flatb_k7_kernel(FbArgs a) {
 
   // ---- stage the halo tile: all loads first (raw words), then activation + bf16 + LDS
   const int64_t img = (int64_t)n * a.h * a.w * a.in_cs + a.in_co;
-  RawUnit<8, IN_BF16> stage[SLOTS];
-  int inside[SLOTS];
+  uint4 stage[SLOTS][IN_BF16 ? 1 : 2];
+  int inside[SLOTS];                            // -1: no such unit; else bit p: pixel p of the unit lies in the image
 #pragma unroll
   for (int i = 0; i < SLOTS; ++i) {
     const int e = tid + i * 256;
-    const int pi = e / UPP, cu = e - pi * UPP;
-    const int row = pi / FB_LW, px = pi - row * FB_LW;
-    const int gy = ty0 - FB_PAD + row, gx = tx0 - FB_PAD + px;
-    const bool ok = e < NU && gy >= 0 && gy < a.h && gx >= 0 && gx < a.w;
-    inside[i] = e >= NU ? -1 : (ok ? 1 : 0);
-    const int cy = min(max(gy, 0), a.h - 1), cx = min(max(gx, 0), a.w - 1);
-    load_unit_raw<8, IN_BF16>(a.in, img + ((int64_t)cy * a.w + cx) * a.in_cs + cu * 8, stage[i]);
+    const int row = e / UPR, u = e - row * UPR;
+    const int gy = ty0 - PAD + row;
+    const int cy = min(max(gy, 0), a.h - 1);
+    int flags = 0;
+#pragma unroll
+    for (int p = 0; p < NPX; ++p) {
+      const int px = CIN >= 8 ? u / UPP : u * NPX + p;
+      const int cu = CIN >= 8 ? u % UPP : 0;
+      const int gx = tx0 - PAD + px;
+      if (gy >= 0 && gy < a.h && gx >= 0 && gx < a.w) flags |= 1 << p;
+      const int cx = min(max(gx, 0), a.w - 1);
+      const int64_t off = img + ((int64_t)cy * a.w + cx) * a.in_cs + cu * 8;
+      if constexpr (IN_BF16) {
+        stage[i][0] = *reinterpret_cast<const uint4*>(reinterpret_cast<const u16*>(a.in) + off);
+      } else if constexpr (CIN >= 8) {
+        stage[i][0] = *reinterpret_cast<const uint4*>(reinterpret_cast<const float*>(a.in) + off);
+        stage[i][1] = *reinterpret_cast<const uint4*>(reinterpret_cast<const float*>(a.in) + off + 4);
+      } else {
+        stage[i][p] = *reinterpret_cast<const uint4*>(reinterpret_cast<const float*>(a.in) + off);
+      }
+    }
+    inside[i] = e < NU ? flags : -1;
   }
   const bool on = a.pw.scale != nullptr;
-  if (on && tid < CIN) {
-    lpw[tid] = a.pw.scale[tid]; lpw[CIN + tid] = a.pw.shift[tid]; lpw[2 * CIN + tid] = a.pw.slope[tid];
+  if (tid < 16) {
+    const bool ok = on && tid < a.cin;
+    lpw[tid] = ok ? a.pw.scale[tid] : 1.f; lpw[16 + tid] = ok ? a.pw.shift[tid] : 0.f; lpw[32 + tid] = ok ? a.pw.slope[tid] : 1.f;
   }
-  if (tid < S::SLACK / 8) *reinterpret_cast<uint4*>(lds + FB_LH * ROWE + tid * 8) = make_uint4(0u, 0u, 0u, 0u);
+  if (tid < S::SLACK / 8) *reinterpret_cast<uint4*>(lds + LH * ROWE + tid * 8) = make_uint4(0u, 0u, 0u, 0u);
   __syncthreads();
   {
-    // (256 % UPP == 0: a thread always handles the same channel octet -- its activation parameters once, in registers)
-    const int cu = tid % UPP;
+    // (256 % UPP == 0: a thread always handles the same channels -- its activation parameters once, in registers)
+    const int c0 = CIN >= 8 ? (tid % UPP) * 8 : 0;
     float sc[8], sf[8], sl[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      sc[j] = on ? lpw[cu * 8 + j] : 1.f; sf[j] = on ? lpw[CIN + cu * 8 + j] : 0.f; sl[j] = on ? lpw[2 * CIN + cu * 8 + j] : 1.f;
+      const int ch = CIN >= 8 ? c0 + j : j % CIN;
+      sc[j] = lpw[ch]; sf[j] = lpw[16 + ch]; sl[j] = lpw[32 + ch];
     }
 #pragma unroll
     for (int i = 0; i < SLOTS; ++i) {
       if (inside[i] < 0) continue;
       float raw[8], v[8];
-      unpack_unit<8, IN_BF16>(stage[i], raw);
+      if constexpr (IN_BF16) {
+        const unsigned w[4] = {stage[i][0].x, stage[i][0].y, stage[i][0].z, stage[i][0].w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { raw[2 * j] = bf2f((u16)(w[j] & 0xffffu)); raw[2 * j + 1] = bf2f((u16)(w[j] >> 16)); }
+      } else {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          raw[4 * q] = __builtin_bit_cast(float, stage[i][q].x); raw[4 * q + 1] = __builtin_bit_cast(float, stage[i][q].y);
+          raw[4 * q + 2] = __builtin_bit_cast(float, stage[i][q].z); raw[4 * q + 3] = __builtin_bit_cast(float, stage[i][q].w);
+        }
+      }
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         float x = raw[j];
         if (on) { x = fmaf(x, sc[j], sf[j]); x = x > 0.f ? x : x * sl[j]; }
-        v[j] = inside[i] ? x : 0.f;
+        const int p = NPX == 1 ? 0 : j / CIN;
+        const int ch = CIN >= 8 ? c0 + j : j % CIN;
+        v[j] = (((inside[i] >> p) & 1) && ch < a.cin) ? x : 0.f;
       }
       lds_store_unit<8>(lds + (tid + i * 256) * 8, v);
     }
   }
-  // weights: registers, one 16-byte load per fragment and lane ([pair][K block][k octet][row][8] packed image).
+  // weights: registers, one 16-byte load per fragment and lane ([fragment p][K block][k octet][row][8] packed image).
   // Loaded AFTER the staging registers are dead: the kernel then fits three waves per SIMD (three workgroups per CU),
   // and the other workgroups' matrix work covers this L2 round trip.
   bf8 wf[NP][KB];
@@ -134,8 +179,9 @@ __global__ __launch_bounds__(256, 3) void flatb_k7_kernel(FbArgs a) {
   const int x0 = wave * 16;
   const int fbase = (x0 + lj) * CIN + kg * 8;
   const int ox = tx0 + x0 + lj;
-  const int rs_l = (kg * 4) / COUT;             // which output row of an MFMA this lane's 4 accumulator rows hold
-  const int co_l = (kg * 4) % COUT;
+  const int rs_l = (kg * 4) / COUTP;            // which output row of an MFMA this lane's 4 accumulator rows hold
+  const int co_l = (kg * 4) % COUTP;
+  float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};       // STATS: this lane's 4 channels
 #pragma unroll 1
   for (int pass = 0; pass < FB_TH / FB_R; ++pass) {
     v4f acc[NS];
@@ -143,10 +189,10 @@ __global__ __launch_bounds__(256, 3) void flatb_k7_kernel(FbArgs a) {
     for (int s = 0; s < NS; ++s) acc[s] = v4f{0.f, 0.f, 0.f, 0.f};
     const u16* base = lds + (pass * FB_R) * ROWE + fbase;
 #pragma unroll
-    for (int jr = 0; jr < FB_R + FB_K - 1; ++jr) {
+    for (int jr = 0; jr < FB_R + KS - 1; ++jr) {
 #pragma unroll
       for (int kb = 0; kb < KB; ++kb) {
-        const bf8 xf = lds_frag<32>(base + jr * ROWE + kb * 32);
+        const bf8 xf = lds_frag<(CIN < 8 ? 4 : 32)>(base + jr * ROWE + kb * 32);
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
           const int p = jr - s * RS;
@@ -160,12 +206,50 @@ __global__ __launch_bounds__(256, 3) void flatb_k7_kernel(FbArgs a) {
       const int oy = ty0 + pass * FB_R + s * RS + rs_l;
       if (oy >= a.h || ox >= a.w) continue;
       const int64_t o = ((int64_t)(n * a.h + oy) * a.w + ox) * a.out_cs + a.out_co + co_l;
-      if constexpr (OUT_BF16)
-        *reinterpret_cast<uint2*>(reinterpret_cast<u16*>(a.out) + o) =
-            make_uint2(pack2(acc[s][0], acc[s][1]), pack2(acc[s][2], acc[s][3]));
-      else
-        *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.out) + o) =
-            make_float4(acc[s][0], acc[s][1], acc[s][2], acc[s][3]);
+      if constexpr (OUT_BF16) {
+        u16* q = reinterpret_cast<u16*>(a.out) + o;
+        if (co_l + 3 < a.cout) *reinterpret_cast<uint2*>(q) = make_uint2(pack2(acc[s][0], acc[s][1]), pack2(acc[s][2], acc[s][3]));
+        else
+#pragma unroll
+          for (int r = 0; r < 4; ++r) if (co_l + r < a.cout) q[r] = f2bf(acc[s][r]);
+      } else {
+        float* q = reinterpret_cast<float*>(a.out) + o;
+        if (co_l + 3 < a.cout) *reinterpret_cast<float4*>(q) = make_float4(acc[s][0], acc[s][1], acc[s][2], acc[s][3]);
+        else
+#pragma unroll
+          for (int r = 0; r < 4; ++r) if (co_l + r < a.cout) q[r] = acc[s][r];
+      }
+      if constexpr (STATS) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v = acc[s][r];
+          if constexpr (OUT_BF16) v = bf2f(f2bf(v));
+          s1[r] += v; s2[r] = fmaf(v, v, s2[r]);
+        }
+      }
+    }
+  }
+  if constexpr (STATS) {
+    // (COUTP == 16 for every layer with a batch-norm here: lane kg holds channels 4 kg .. 4 kg + 3, the 16 lanes lj of
+    //  a quarter-wave share them.)  16 values per lane in fp32, then doubles: lanes by shuffles, waves through LDS.
+    static_assert(!STATS || COUTP == 16, "statistics: 16 produced channels");
+    double d1[4], d2[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { d1[r] = (double)s1[r]; d2[r] = (double)s2[r]; }
+#pragma unroll
+    for (int m = 8; m >= 1; m >>= 1)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { d1[r] += __shfl_xor(d1[r], m, 16); d2[r] += __shfl_xor(d2[r], m, 16); }
+    if (lj == 0) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { red[wave * 32 + kg * 4 + r] = d1[r]; red[wave * 32 + 16 + kg * 4 + r] = d2[r]; }
+    }
+    __syncthreads();
+    if (tid < 32) {
+      const double v = ((red[tid] + red[32 + tid]) + red[64 + tid]) + red[96 + tid];
+      const int64_t row = t;                   // one row per tile, whatever workgroup computed it
+      const int ch = tid & 15;
+      if (ch < a.stat_c) a.stat[(row * 2 + (tid >> 4)) * a.stat_c + ch] = v;
     }
   }
 }
@@ -173,13 +257,13 @@ __global__ __launch_bounds__(256, 3) void flatb_k7_kernel(FbArgs a) {
 struct FbPackArgs {
   const float* w; u16* dst;
   int64_t sa, sb;
-  int cin, cout, KB, RS, NP, flip;
+  int ks, cin, cinp, cout, coutp, KB, flip;
   int64_t total;
 };
 
-// [pair p][K block][k octet kg][row i][8]: row i = (output row select rs, produced channel co), tap row ky = p - rs,
-// K index k = 32 kb + 8 kg + e -> (tap column kx = k / cin, gathered channel c = k % cin); zero where no such tap.
-// flip: the gather is the data gradient of a convolution (transposed form): tap t reads weight element k - 1 - t.
+// [fragment p][K block][k octet kg][row i][8]: row i = (output row select rs, produced channel co), tap row ky = p - rs,
+// K index k = 32 kb + 8 kg + e -> (tap column kx = k / cinp, gathered channel c = k % cinp); zero where no such tap /
+// channel.  flip: the gather is the data gradient of a convolution (transposed form): tap t reads weight k - 1 - t.
 __global__ __launch_bounds__(256) void flatb_pack_kernel(FbPackArgs a) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= a.total) return;
@@ -189,43 +273,58 @@ __global__ __launch_bounds__(256) void flatb_pack_kernel(FbPackArgs a) {
   const int kg = r % 4; r /= 4;
   const int kb = r % a.KB; r /= a.KB;
   const int p = (int)r;
-  const int rs = row / a.cout, co = row % a.cout;
+  const int rs = row / a.coutp, co = row % a.coutp;
   const int ky = p - rs;
   const int k = kb * 32 + kg * 8 + e;
-  const int kx = k / a.cin, c = k % a.cin;
+  const int kx = k / a.cinp, c = k % a.cinp;
   float v = 0.f;
-  if (rs < a.RS && ky >= 0 && ky < FB_K && kx < FB_K) {
-    const int wy = a.flip ? FB_K - 1 - ky : ky, wx = a.flip ? FB_K - 1 - kx : kx;
-    v = a.w[c * a.sa + co * a.sb + wy * FB_K + wx];
+  if (ky >= 0 && ky < a.ks && kx < a.ks && c < a.cin && co < a.cout) {
+    const int wy = a.flip ? a.ks - 1 - ky : ky, wx = a.flip ? a.ks - 1 - kx : kx;
+    v = a.w[c * a.sa + co * a.sb + wy * a.ks + wx];
   }
   a.dst[i] = f2bf(v);
 }
 
-static bool fb_shape(const ConvGeom& g, int* KB, int* RS, int* NP) {
+// which instance serves this geometry: 0 none, 1 k7 16->8, 2 k7 8->16, 3 k5 3(4)->16 (stem forward), 4 k5 16->(1..4)
+struct FbKind { int kind, ks, cinp, coutp; };
+static FbKind fb_kind(const ConvGeom& g) {
   static const bool off = getenv("BP_BF16_NOFLAT") != nullptr;
-  if (off) return false;
-  if (g.k != FB_K || g.stride != 1 || g.pad != FB_PAD || g.nphase != 1 || g.taps != FB_K || g.IS != 1 || g.OS != 1)
-    return false;
-  if (!((g.cin_g == 16 && g.cout_g == 8) || (g.cin_g == 8 && g.cout_g == 16))) return false;
-  *KB = (FB_K * g.cin_g + 31) / 32;
-  *RS = 16 / g.cout_g;
-  *NP = FB_K + *RS - 1;
-  return true;
+  static const bool off5 = getenv("BP_BF16_NOFLAT5") != nullptr;
+  FbKind none{0, 0, 0, 0};
+  if (off || g.stride != 1 || g.nphase != 1 || g.IS != 1 || g.OS != 1 || g.taps != g.k || g.pad != g.k / 2) return none;
+  if (g.k == 7 && g.cin_g == 16 && g.cout_g == 8) return FbKind{1, 7, 16, 8};
+  if (g.k == 7 && g.cin_g == 8 && g.cout_g == 16) return FbKind{2, 7, 8, 16};
+  if (g.k == 5 && !off5 && g.cin_g <= 4 && g.cin_g >= 1 && g.cout_g == 16) return FbKind{3, 5, 4, 16};
+  if (g.k == 5 && !off5 && g.cin_g == 16 && g.cout_g >= 1 && g.cout_g <= 4) return FbKind{4, 5, 16, 4};
+  return none;
+}
+
+template <int KS, int CIN, int COUTP, bool IB, bool OB, bool ST>
+static void fb_launch(const FbArgs& a, dim3 grid, hipStream_t st) {
+  auto k = flatb_kernel<KS, CIN, COUTP, IB, OB, ST>;
+  constexpr size_t lds = FbShape<KS, CIN>::LDS;
+  static const int once = (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               (int)lds), 0);
+  (void)once;
+  hipLaunchKernelGGL(k, grid, dim3(256), lds, st, a);
 }
 
 }  // namespace
 
 // elements of the flattened-K weight image of this layer (0: the kernel does not apply)
 int64_t bp_bf16_flat_packed_elems(const ConvGeom& g) {
-  int KB, RS, NP;
-  if (!fb_shape(g, &KB, &RS, &NP)) return 0;
+  const FbKind f = fb_kind(g);
+  if (!f.kind) return 0;
+  const int KB = (f.ks * f.cinp + 31) / 32, NP = f.ks + 16 / f.coutp - 1;
   return (int64_t)NP * KB * 64 * 8;
 }
 
 int bp_bf16_flat_pack(const ConvGeom& g, const WeightMap& wm, const float* w_torch, u16* dst, hipStream_t st) {
+  const FbKind f = fb_kind(g);
+  if (!f.kind) return BP_EUNSUPPORTED;
   FbPackArgs a{};
-  if (!fb_shape(g, &a.KB, &a.RS, &a.NP)) return BP_EUNSUPPORTED;
-  a.w = w_torch; a.dst = dst; a.sa = wm.sa; a.sb = wm.sb; a.cin = g.cin_g; a.cout = g.cout_g;
+  a.w = w_torch; a.dst = dst; a.sa = wm.sa; a.sb = wm.sb; a.ks = f.ks; a.cin = g.cin_g; a.cinp = f.cinp;
+  a.cout = g.cout_g; a.coutp = f.coutp; a.KB = (f.ks * f.cinp + 31) / 32;
   a.flip = g.gather_transposed;
   a.total = bp_bf16_flat_packed_elems(g);
   hipLaunchKernelGGL(flatb_pack_kernel, dim3((unsigned)((a.total + 255) / 256)), dim3(256), 0, st, a);
@@ -233,41 +332,58 @@ int bp_bf16_flat_pack(const ConvGeom& g, const WeightMap& wm, const float* w_tor
   return BP_OK;
 }
 
+static int64_t fb_tiles(const bp_view* out) {
+  return (int64_t)bp_ceil_div(out->w, FB_TW) * bp_ceil_div(out->h, FB_TH) * out->n;
+}
+
 bool bp_bf16_flat_ok(const ConvGeom& g, const bp_view* in, const bp_view* out, const float* bias, bool stats) {
-  int KB, RS, NP;
-  if (!fb_shape(g, &KB, &RS, &NP) || bias || stats || !in || !out) return false;
+  const FbKind f = fb_kind(g);
+  if (!f.kind || bias || !in || !out) return false;
+  if (stats && f.kind != 3) return false;
   if (in->c != g.cin_g || out->c != g.cout_g || in->h != out->h || in->w != out->w || in->n != out->n) return false;
-  // the forward reads the bf16 trunk and writes the fp32 head; its data gradient reads fp32 and writes bf16
   const bool ib = in->dtype == BP_BF16, ob = out->dtype == BP_BF16;
-  if (!((g.cin_g == 16 && ib && !ob) || (g.cin_g == 8 && !ib && ob))) return false;
-  const int ie = ib ? 2 : 4, oe = ob ? 2 : 4;
-  if ((in->cstride * ie) % 16 || (in->coff * ie) % 16 || reinterpret_cast<uintptr_t>(in->ptr) % 16) return false;
-  if ((out->cstride * oe) % (4 * oe) || (out->coff * oe) % (4 * oe) || reinterpret_cast<uintptr_t>(out->ptr) % 16) return false;
-  const int64_t tiles = (int64_t)bp_ceil_div(out->w, FB_TW) * bp_ceil_div(out->h, FB_TH) * out->n;
-  return tiles < (1ll << 31);
+  // element types of the instances: the bf16 trunk on one side, the fp32 few-channel edge on the other
+  if ((f.kind == 1 || f.kind == 4) ? !(ib && !ob) : !(!ib && ob)) return false;
+  if (reinterpret_cast<uintptr_t>(in->ptr) % 16 || reinterpret_cast<uintptr_t>(out->ptr) % 16) return false;
+  // staged units: 8 channels (16 bytes of bf16 / two float4) or, for the 4-channel stem, one float4 per pixel
+  if (f.kind == 3) {
+    if (in->cstride % 4 || in->coff % 4 || in->coff + 4 > in->cstride) return false;      // (reads a whole channel quad)
+  } else if ((in->cstride * (ib ? 2 : 4)) % 16 || (in->coff * (ib ? 2 : 4)) % 16) return false;
+  if (out->cstride % 4 || out->coff % 4) return false;                                    // 4-channel vector stores
+  return fb_tiles(out) < (1ll << 31);
+}
+
+size_t bp_bf16_flat_stats_workspace(const ConvGeom& g, const bp_view* in, const bp_view* out) {
+  if (!bp_bf16_flat_ok(g, in, out, nullptr, true)) return 0;
+  return bp_stats_rows_bytes(fb_tiles(out), g.cout_g);
 }
 
 int bp_bf16_flat_run(const ConvGeom& g, const bp_view* in, const PW& pw, const u16* packed_flat, const bp_view* out,
-                     hipStream_t st) {
+                     hipStream_t st, const IgemmStatsReq* sr) {
+  const FbKind f = fb_kind(g);
   FbArgs a{};
-  a.in = in->ptr; a.h = in->h; a.w = in->w; a.in_cs = in->cstride; a.in_co = in->coff;
-  a.out = out->ptr; a.out_cs = out->cstride; a.out_co = out->coff;
+  a.in = in->ptr; a.h = in->h; a.w = in->w; a.in_cs = in->cstride; a.in_co = in->coff; a.cin = g.cin_g;
+  a.out = out->ptr; a.out_cs = out->cstride; a.out_co = out->coff; a.cout = g.cout_g;
   a.wp = packed_flat; a.pw = pw; a.n = in->n;
   a.tiles_x = bp_ceil_div(out->w, FB_TW); a.tiles_y = bp_ceil_div(out->h, FB_TH);
-  const dim3 grid((unsigned)(a.tiles_x * a.tiles_y * a.n)), block(256);
-  if (g.cin_g == 16) {
-    auto k = flatb_k7_kernel<16, 8, true, false>;
-    static const int once = (hipFuncSetAttribute(reinterpret_cast<const void*>(k),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)FbShape<16>::LDS), 0);
-    (void)once;
-    hipLaunchKernelGGL(k, grid, block, FbShape<16>::LDS, st, a);
-  } else {
-    auto k = flatb_k7_kernel<8, 16, false, true>;
-    static const int once = (hipFuncSetAttribute(reinterpret_cast<const void*>(k),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)FbShape<8>::LDS), 0);
-    (void)once;
-    hipLaunchKernelGGL(k, grid, block, FbShape<8>::LDS, st, a);
+  const int64_t rows = fb_tiles(out);
+  if (sr) {
+    const size_t need = bp_stats_rows_bytes(rows, g.cout_g);
+    if (sr->mode != 1 || !need) return BP_EUNSUPPORTED;
+    if (!sr->ws || sr->ws_bytes < need || !sr->sums) return BP_EWORKSPACE;
+    a.stat = reinterpret_cast<double*>(sr->ws); a.stat_c = g.cout_g;
+  }
+  const dim3 grid((unsigned)rows);
+  switch (f.kind) {
+    case 1: fb_launch<7, 16, 8, true, false, false>(a, grid, st); break;
+    case 2: fb_launch<7, 8, 16, false, true, false>(a, grid, st); break;
+    case 3: if (sr) fb_launch<5, 4, 16, false, true, true>(a, grid, st);
+            else fb_launch<5, 4, 16, false, true, false>(a, grid, st);
+            break;
+    case 4: fb_launch<5, 16, 4, true, false, false>(a, grid, st); break;
+    default: return BP_EUNSUPPORTED;
   }
   BP_CHECK_LAUNCH();
-  return BP_OK;
+  if (!sr) return BP_OK;
+  return bp_stats_rows_finish(a.stat, rows, g.cout_g, sr, st);
 }
