@@ -395,6 +395,15 @@ __global__ __launch_bounds__(64 * NW, 2) void igemm_bf16_kernel(BArgs a) {
 #pragma unroll
     for (int i = 0; i < SLOTS; ++i) {
       if (s_g[i] == -2) continue;
+      if constexpr (IN_BF16 && U == 8) {
+        if (!on && chunk * CC + cu * U + U <= a.cin) {
+          // bf16 in, no pending activation (every data gradient): the raw words ARE the LDS image
+          const int e = tid + i * NTH;
+          u16* dst = CC == 32 ? lds_in + ((e % UPP) * a.npixp + e / UPP) * 8 : lds_in + e * U;
+          *reinterpret_cast<uint4*>(dst) = s_g[i] >= 0 ? stage[i].q[0] : make_uint4(0u, 0u, 0u, 0u);
+          continue;
+        }
+      }
       float v[U], raw[U];
       unpack_unit<U, IN_BF16>(stage[i], raw);
 #pragma unroll
@@ -584,6 +593,14 @@ __global__ __launch_bounds__(256, 2) void igemm_bf16_p_kernel(BPArgs pa) {
 #pragma unroll
     for (int i = 0; i < SLOTS; ++i) {
       if (s_r[i] < 0) continue;
+      if constexpr (IN_BF16 && U == 8) {
+        if (!on && cu * U + U <= a.cin) {      // bf16 in, no pending activation: the raw words ARE the LDS image
+          const int e = tid + i * 256;
+          u16* dst = CC == 32 ? lds_in + ((e % UPP) * a.npixp + e / UPP) * 8 : lds_in + e * U;
+          *reinterpret_cast<uint4*>(dst) = ((inside >> i) & 1u) ? stage[i].q[0] : make_uint4(0u, 0u, 0u, 0u);
+          continue;
+        }
+      }
       float v[U], raw[U];
       unpack_unit<U, IN_BF16>(stage[i], raw);
 #pragma unroll

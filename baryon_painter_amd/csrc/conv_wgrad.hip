@@ -138,10 +138,15 @@ struct WreduceArgs {
   int cx_total, cx_off, cy_off;     // position of this (cx, cy) block inside the full weight tensor
 };
 
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(WreduceArgs a) {
-  // 64 consecutive outputs (workspace order [ky][kx][cy][cx], cx fastest: coalesced) x 4 groups of
-  // splits per block; the 4 partial sums are added in a fixed order -> bitwise reproducible.
-  __shared__ double sh[4][64];
+// WR_GRP: split groups per block (threads = 64 outputs x WR_GRP): 4 for the few-way splits of the fp32 kernels, 16 for
+// the 128 ... 512-way splits of the bf16 and thin-layer kernels
+template <int WR_GRP>
+__global__ __launch_bounds__(64 * WR_GRP) void wgrad_reduce_kernel(WreduceArgs a) {
+  // 64 consecutive outputs (workspace order [ky][kx][cy][cx], cx fastest: coalesced) x WR_GRP groups of splits per
+  // block: a thread adds every WR_GRP-th split (two chains, loads independent of each other), the groups are then
+  // added in a fixed order -> bitwise reproducible.  (With four groups a 512-way split is 128 trips per thread:
+  // latency-bound, 30 us for 25 MB; sixteen cut the chain to 32.)
+  __shared__ double sh[WR_GRP][64];
   const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
   const int64_t i = (int64_t)blockIdx.x * 64 + lane;
   const int64_t total = (int64_t)a.k * a.k * a.cy * a.cx;
@@ -155,17 +160,21 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(WreduceArgs a) {
     const float* p = a.ws + ((int64_t)t * a.CYP + cy) * a.CXP + cx;
     double s0 = 0.0, s1 = 0.0;
     int sp = grp;
-    for (; sp + 4 < a.nsplit; sp += 8) {
+    for (; sp + WR_GRP < a.nsplit; sp += 2 * WR_GRP) {
       s0 += (double)p[sp * stride];
-      s1 += (double)p[(sp + 4) * stride];
+      s1 += (double)p[(sp + WR_GRP) * stride];
     }
     if (sp < a.nsplit) s0 += (double)p[sp * stride];
     s = s0 + s1;
   }
   sh[grp][lane] = s;
   __syncthreads();
-  if (grp == 0 && i < total)
-    a.dst[((int64_t)(a.cy_off + cy) * a.cx_total + a.cx_off + cx) * a.k * a.k + t] = (float)(((sh[0][lane] + sh[1][lane]) + sh[2][lane]) + sh[3][lane]);
+  if (grp == 0 && i < total) {
+    double r = sh[0][lane];
+#pragma unroll
+    for (int g = 1; g < WR_GRP; ++g) r += sh[g][lane];
+    a.dst[((int64_t)(a.cy_off + cy) * a.cx_total + a.cx_off + cx) * a.k * a.k + t] = (float)r;
+  }
 }
 
 struct WgradPlan {
@@ -223,7 +232,8 @@ static int wgrad_reduce(const float* ws, float* dst, int k, int cx, int cy, int 
   r.ws = ws; r.dst = dst; r.k = k; r.cx = cx; r.cy = cy; r.CXP = CXP; r.CYP = CYP; r.nsplit = nsplit;
   r.cx_total = cx_total < 0 ? cx : cx_total; r.cx_off = cx_off; r.cy_off = cy_off;
   const int64_t total = (int64_t)cy * cx * k * k;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, st, r);
+  if (r.nsplit > 64) hipLaunchKernelGGL(wgrad_reduce_kernel<16>, dim3((unsigned)((total + 63) / 64)), dim3(1024), 0, st, r);
+  else hipLaunchKernelGGL(wgrad_reduce_kernel<4>, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, st, r);
   BP_CHECK_LAUNCH();
   return BP_OK;
 }
@@ -395,7 +405,8 @@ int bp_wgrad_mfma(const bp_conv* cv, const bp_view* X, const PW& pwx, const bp_v
   r.ws = a.ws; r.dst = dst; r.k = cv->k; r.cx = X->c; r.cy = Y->c; r.CXP = p.CXP; r.CYP = p.CYP;
   r.nsplit = p.nsplit;
   const int64_t total = (int64_t)Y->c * X->c * cv->k * cv->k;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, st, r);
+  if (r.nsplit > 64) hipLaunchKernelGGL(wgrad_reduce_kernel<16>, dim3((unsigned)((total + 63) / 64)), dim3(1024), 0, st, r);
+  else hipLaunchKernelGGL(wgrad_reduce_kernel<4>, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, st, r);
   BP_CHECK_LAUNCH();
   return BP_OK;
 }

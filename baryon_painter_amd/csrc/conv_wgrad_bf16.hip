@@ -216,6 +216,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(WbArgs a) {
       for (int i = 0; i < NXS; ++i) {
         const int e = tid + i * 256;
         if (e >= XR * S * IWq * XU) continue;
+        u16* dst = xs + (xcu >> 1) * XT + (e / XU) * 16 + (xcu & 1) * 8;
+        if constexpr (XB) {
+          if (!xon) {        // bf16 in, no pending activation: the raw words ARE the LDS image (no unpack / round trip)
+            *reinterpret_cast<uint4*>(dst) = ((xin >> i) & 1u) ? xr[i].q[0] : make_uint4(0u, 0u, 0u, 0u);
+            continue;
+          }
+        }
         float v[8], raw[8];
         unpack_unit<8, XB>(xr[i], raw);
 #pragma unroll
@@ -224,12 +231,19 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(WbArgs a) {
           if (xon) { u = fmaf(u, lpw[xcu * 8 + j], lpw[CXC + xcu * 8 + j]); u = u > 0.f ? u : u * lpw[2 * CXC + xcu * 8 + j]; }
           v[j] = ((xin >> i) & 1u) ? u : 0.f;
         }
-        lds_store_unit<8>(xs + (xcu >> 1) * XT + (e / XU) * 16 + (xcu & 1) * 8, v);
+        lds_store_unit<8>(dst, v);
       }
 #pragma unroll
       for (int i = 0; i < NYS; ++i) {
         const int e = tid + i * 256;
         if (e >= BH * 32 * YU) continue;
+        u16* dst = ys + (ycu >> 1) * YT + (e / YU) * 16 + (ycu & 1) * 8;
+        if constexpr (YB) {
+          if (!yon) {        // (a layer's d_raw: always this case)
+            *reinterpret_cast<uint4*>(dst) = ((yin >> i) & 1u) ? yr[i].q[0] : make_uint4(0u, 0u, 0u, 0u);
+            continue;
+          }
+        }
         float v[8], raw[8];
         unpack_unit<8, YB>(yr[i], raw);
 #pragma unroll
@@ -241,7 +255,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(WbArgs a) {
           }
           v[j] = ((yin >> i) & 1u) ? u : 0.f;
         }
-        lds_store_unit<8>(ys + (ycu >> 1) * YT + (e / YU) * 16 + (ycu & 1) * 8, v);
+        lds_store_unit<8>(dst, v);
       }
     };
     int tile = split;
@@ -386,8 +400,8 @@ int wb_launch(const bp_conv* cv, const bp_view* X, const PW& pwx, const bp_view*
   const int kyg = bp_ceil_div(cv->k, KHB);
   const int64_t ntiles = (int64_t)Y->n * a.tiles_x * a.tiles_y;
   const int64_t base = (int64_t)a.ncxb * ncyb * kyg;
-  static const int wb_target = getenv("BP_WB_TARGET") ? atoi(getenv("BP_WB_TARGET")) : 1024;
-  int64_t ns = (wb_target + base - 1) / base;     // ~4 workgroups per CU
+  static const int wb_target = getenv("BP_WB_TARGET") ? atoi(getenv("BP_WB_TARGET")) : 512;
+  int64_t ns = (wb_target + base - 1) / base;     // ~2 workgroups per CU (1024: 20.75 ms per bf16 step, 512: 20.59, 256: 21.1 -- partial sums are 590 KB per split of a trunk layer)
   if (ns > ntiles) ns = ntiles;
   if (ns < 1) ns = 1;
   if (ns > 65535) ns = 65535;
@@ -415,6 +429,190 @@ int wb_launch(const bp_conv* cv, const bp_view* X, const PW& pwx, const bp_view*
   return BP_OK;
 }
 
+// ---------------------------------------------------------------------------------------------- k7 head, flattened
+// Weight gradient of the heads' first layer (unit-stride k7, 16 bf16 channels in, 8 fp32 gradient channels out) -- after
+// conv_bf16_flat.hip took its forward and data gradient, the largest single launch of the bf16 step (1.2 ms in
+// wgrad_bf16_kernel<4,7,...>: one 16 x 16 channel tile per MFMA, half of it padding, 28 of 49 taps per workgroup, the
+// pixel tile staged twice).  Here:
+//   * MFMA columns = (output row select rs, gradient channel co): the dY image interleaves row PAIRS as 16 "channels",
+//     so ONE X fragment (input row i, tap column kx) feeds tap row ky = i - y + 3 of output row y AND ky - 1 of row
+//     y + 1: accumulator "pair p" = [dW[p] | dW[p-1]], 8 x 7 accumulators instead of 7 x 7 half-empty ones, and 56
+//     MFMAs per 64 pixel-rows instead of 98;
+//   * the four waves own two pairs each (14 accumulators), every wave walks the whole 64 x 16 pixel tile: one dY
+//     fragment per 14 MFMAs, the X fragments (ds_read_b64_tr_b16 of the [row][pixel][16] image the forward kernel
+//     stages) are the only per-MFMA LDS traffic;
+//   * persistent workgroups (two per CU) accumulate over their tiles and leave ONE partial each: the two halves of a
+//     tap meet through LDS, partials go to the workspace layout of conv_wgrad.hip (fixed-order reduce).
+struct WfArgs {
+  const u16* X; int h, w, xcs, xco;
+  const float* Y; int ycs, yco;
+  int n;
+  PW pwx;
+  float* ws;
+  int tiles_x, tiles_y;
+};
+
+constexpr int WF_K = 7, WF_TW = 64, WF_TH = 16, WF_LW = WF_TW + WF_K - 1, WF_LH = WF_TH + WF_K - 1;
+constexpr int WF_XE = WF_LH * WF_LW * 16, WF_YE = (WF_TH / 2) * WF_TW * 16;          // bf16 elements
+constexpr size_t WF_RED = (size_t)(WF_K + 1) * WF_K * 256 * sizeof(float);
+constexpr size_t WF_TILES = (size_t)(WF_XE + WF_YE) * 2 > WF_RED ? (size_t)(WF_XE + WF_YE) * 2 : WF_RED;
+constexpr size_t WF_LDS = WF_TILES + 3 * 16 * sizeof(float);
+
+__global__ __launch_bounds__(256, 2) void wgrad_flatb_k7_kernel(WfArgs a) {
+  extern __shared__ __attribute__((aligned(16))) u16 smem[];
+  u16* xs = smem;
+  u16* ys = smem + WF_XE;
+  float* lpw = reinterpret_cast<float*>(reinterpret_cast<char*>(smem) + WF_TILES);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, kq = lane >> 4;
+  const int trl = (4 * kq + (li >> 2)) * 16 + 4 * (li & 3);
+
+  const bool on = a.pwx.scale != nullptr;
+  if (tid < 16) {
+    lpw[tid] = on ? a.pwx.scale[tid] : 1.f; lpw[16 + tid] = on ? a.pwx.shift[tid] : 0.f; lpw[32 + tid] = on ? a.pwx.slope[tid] : 1.f;
+  }
+  __syncthreads();
+  const int cu = tid & 1;                       // X staging: this thread's channel octet
+  float sc[8], sf[8], sl[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { sc[j] = lpw[cu * 8 + j]; sf[j] = lpw[16 + cu * 8 + j]; sl[j] = lpw[32 + cu * 8 + j]; }
+
+  v4f acc[2][WF_K];
+#pragma unroll
+  for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+    for (int kx = 0; kx < WF_K; ++kx) acc[pp][kx] = v4f{0.f, 0.f, 0.f, 0.f};
+
+  constexpr int NUX = WF_LH * WF_LW * 2, XS = (NUX + 255) / 256;      // 8-channel units of the X halo tile
+  constexpr int NUY = WF_TH * WF_TW, YS = NUY / 256;                  // pixels of the dY tile (8 fp32 channels each)
+  const int per_img = a.tiles_x * a.tiles_y;
+  const int ntiles = per_img * a.n;
+  for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    const int n = t / per_img, tr = t - n * per_img;
+    const int ty0 = (tr / a.tiles_x) * WF_TH, tx0 = (tr % a.tiles_x) * WF_TW;
+    // ---- loads first (all in flight, raw words, clamped coordinates), then convert into LDS
+    uint4 xr[XS];
+    float4 yr[YS][2];
+    unsigned xin = 0, yin = 0;
+    const int64_t ximg = (int64_t)n * a.h * a.w * a.xcs + a.xco + cu * 8;
+#pragma unroll
+    for (int i = 0; i < XS; ++i) {
+      const int e = tid + i * 256, pi = e >> 1;
+      const int row = pi / WF_LW, px = pi - row * WF_LW;
+      const int gy = ty0 - 3 + row, gx = tx0 - 3 + px;
+      if (e < NUX && gy >= 0 && gy < a.h && gx >= 0 && gx < a.w) xin |= 1u << i;
+      const int cy = min(max(gy, 0), a.h - 1), cx = min(max(gx, 0), a.w - 1);
+      xr[i] = *reinterpret_cast<const uint4*>(a.X + ximg + ((int64_t)cy * a.w + cx) * a.xcs);
+    }
+    const int64_t yimg = (int64_t)n * a.h * a.w * a.ycs + a.yco;
+#pragma unroll
+    for (int i = 0; i < YS; ++i) {
+      const int e = tid + i * 256;
+      const int row = e / WF_TW, px = e - row * WF_TW;
+      const int gy = ty0 + row, gx = tx0 + px;
+      if (gy < a.h && gx < a.w) yin |= 1u << i;
+      const int cy = min(gy, a.h - 1), cx = min(gx, a.w - 1);
+      const float* q = a.Y + yimg + ((int64_t)cy * a.w + cx) * a.ycs;
+      yr[i][0] = *reinterpret_cast<const float4*>(q);
+      yr[i][1] = *reinterpret_cast<const float4*>(q + 4);
+    }
+    __syncthreads();                            // the previous tile's readers are done with the images
+#pragma unroll
+    for (int i = 0; i < XS; ++i) {
+      const int e = tid + i * 256;
+      if (e >= NUX) continue;
+      const unsigned w[4] = {xr[i].x, xr[i].y, xr[i].z, xr[i].w};
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { v[2 * j] = bf2f((u16)(w[j] & 0xffffu)); v[2 * j + 1] = bf2f((u16)(w[j] >> 16)); }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float x = v[j];
+        if (on) { x = fmaf(x, sc[j], sf[j]); x = x > 0.f ? x : x * sl[j]; }
+        v[j] = ((xin >> i) & 1u) ? x : 0.f;
+      }
+      lds_store_unit<8>(xs + e * 8, v);
+    }
+#pragma unroll
+    for (int i = 0; i < YS; ++i) {
+      const int e = tid + i * 256;
+      const int row = e / WF_TW, px = e - row * WF_TW;
+      const bool ok = (yin >> i) & 1u;
+      const float v[8] = {ok ? yr[i][0].x : 0.f, ok ? yr[i][0].y : 0.f, ok ? yr[i][0].z : 0.f, ok ? yr[i][0].w : 0.f,
+                          ok ? yr[i][1].x : 0.f, ok ? yr[i][1].y : 0.f, ok ? yr[i][1].z : 0.f, ok ? yr[i][1].w : 0.f};
+      lds_store_unit<8>(ys + (((row >> 1) * WF_TW + px) * 16) + (row & 1) * 8, v);       // row pairs interleaved
+    }
+    __syncthreads();
+    // ---- multiply: this wave's two pairs over the whole tile
+#pragma unroll 1
+    for (int rp = 0; rp < WF_TH / 2; ++rp) {
+#pragma unroll
+      for (int seg = 0; seg < WF_TW / 32; ++seg) {
+        const u16* py = ys + (rp * WF_TW + seg * 32) * 16 + trl;
+        const bf8 yf = frag_of(lds_tr(py), lds_tr(py + 16 * 16));
+#pragma unroll
+        for (int pp = 0; pp < 2; ++pp) {
+          const u16* px_ = xs + ((2 * rp + 2 * wave + pp) * WF_LW + seg * 32) * 16 + trl;
+#pragma unroll
+          for (int kx = 0; kx < WF_K; ++kx) {
+            const bf8 xf = frag_of(lds_tr(px_ + kx * 16), lds_tr(px_ + (kx + 16) * 16));
+            acc[pp][kx] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf, yf, acc[pp][kx], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+  // ---- the two halves of every tap meet through LDS: red[pair][kx][ci][(rs, co)]
+  __syncthreads();
+  float* red = reinterpret_cast<float*>(smem);
+#pragma unroll
+  for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+    for (int kx = 0; kx < WF_K; ++kx)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        red[(((2 * wave + pp) * WF_K + kx) * 16 + 4 * kq + r) * 16 + li] = acc[pp][kx][r];
+  __syncthreads();
+  float* out = a.ws + (int64_t)blockIdx.x * WF_K * WF_K * 8 * 16;
+  for (int e = tid; e < WF_K * WF_K * 8 * 16; e += 256) {
+    const int ci = e & 15, co = (e >> 4) & 7, tap = e >> 7;
+    const int ky = tap / WF_K, kx = tap - ky * WF_K;
+    out[e] = red[((ky * WF_K + kx) * 16 + ci) * 16 + co] + red[(((ky + 1) * WF_K + kx) * 16 + ci) * 16 + 8 + co];
+  }
+}
+
+static bool wf_ok(const bp_conv* cv, const bp_view* X, const bp_view* Y, const PW& pwy) {
+  static const bool off = getenv("BP_BF16_NOFLATW") != nullptr;
+  if (off || cv->transposed || cv->k != WF_K || cv->stride != 1 || cv->pad != 3 || X->c != 16 || Y->c != 8) return false;
+  if (X->dtype != BP_BF16 || Y->dtype != BP_F32 || pwy.scale) return false;
+  if (X->h != Y->h || X->w != Y->w || X->n != Y->n) return false;
+  if ((X->cstride * 2) % 16 || (X->coff * 2) % 16 || reinterpret_cast<uintptr_t>(X->ptr) % 16) return false;
+  if (Y->cstride % 4 || Y->coff % 4 || reinterpret_cast<uintptr_t>(Y->ptr) % 16) return false;
+  return true;
+}
+
+static int wf_launch(const bp_view* X, const PW& pwx, const bp_view* Y, float* ws, size_t ws_bytes, size_t* need,
+                     int* nsplit_out, int* cxp, int* cyp, hipStream_t st, bool dry) {
+  WfArgs a{};
+  a.X = reinterpret_cast<const u16*>(X->ptr); a.h = X->h; a.w = X->w; a.xcs = X->cstride; a.xco = X->coff;
+  a.Y = reinterpret_cast<const float*>(Y->ptr); a.ycs = Y->cstride; a.yco = Y->coff;
+  a.n = X->n; a.pwx = pwx; a.ws = ws;
+  a.tiles_x = bp_ceil_div(X->w, WF_TW); a.tiles_y = bp_ceil_div(X->h, WF_TH);
+  const int64_t ntiles = (int64_t)a.tiles_x * a.tiles_y * a.n;
+  const int ns = (int)(ntiles < 512 ? ntiles : 512);                 // two persistent workgroups per CU
+  *need = (size_t)ns * WF_K * WF_K * 8 * 16 * sizeof(float);
+  *nsplit_out = ns; *cxp = 16; *cyp = 8;
+  if (dry) return BP_OK;
+  if (!ws || ws_bytes < *need) return BP_EWORKSPACE;
+  static const hipError_t optin = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_flatb_k7_kernel),
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)WF_LDS);
+  if (optin != hipSuccess) return BP_ELAUNCH;
+  hipLaunchKernelGGL(wgrad_flatb_k7_kernel, dim3((unsigned)ns), dim3(256), WF_LDS, st, a);
+  BP_CHECK_LAUNCH();
+  return BP_OK;
+}
+
 // 16-byte loads of 8 channels need 16-byte aligned pixel rows; ragged channel counts take the scalar path
 bool wb_view_ok(const bp_view* v) {
   const int esz = v->dtype == BP_BF16 ? 2 : 4;
@@ -429,6 +627,7 @@ bool wb_view_ok(const bp_view* v) {
 int bp_wgrad_bf16(const bp_conv* cv, const bp_view* X, const PW& pwx, const bp_view* Y, const PW& pwy, float* ws,
                   size_t ws_bytes, size_t* need, int* nsplit, int* cxp, int* cyp, hipStream_t st, bool dry) {
   if (!wb_view_ok(X) || !wb_view_ok(Y)) return BP_EUNSUPPORTED;
+  if (wf_ok(cv, X, Y, pwy)) return wf_launch(X, pwx, Y, ws, ws_bytes, need, nsplit, cxp, cyp, st, dry);
   const int k = cv->k, s = cv->stride, cx = X->c, cy = Y->c;
 #define BP_WB_(...) return wb_launch<__VA_ARGS__>(cv, X, pwx, Y, pwy, ws, ws_bytes, need, nsplit, cxp, cyp, st, dry)
   if (k == 3 && s == 1) {
