@@ -613,6 +613,175 @@ static int wf_launch(const bp_view* X, const PW& pwx, const bp_view* Y, float* w
   return BP_OK;
 }
 
+// ---------------------------------------------------------------------------------------------- k5 stem, flattened
+// Weight gradient of the generator's stem (unit-stride k5, 3(+1) fp32 channels in, 16 bf16 gradient channels): MFMA rows
+// = the 16 gradient channels (dY image [row][pixel][16], transposing read), MFMA columns = (tap column kxs of a group of
+// four, input channel ci): the X image is [row][pixel][4] bf16, so 16 consecutive elements ARE four neighbouring
+// pixels x four channels and the transposing read takes its four 8-byte chunks from pixels P .. P + 3.  Ten
+// accumulators (5 tap rows x 2 column groups) per wave; the waves split the tile's rows and meet through LDS.  The
+// launch is HBM-bound (0.8 GB): 0.69 ms in wgrad_bf16_kernel<5,5,...> (one MFMA per tap, 12 of 16 rows padding).
+struct WsfArgs {
+  const float* X; int h, w, xcs, xco, cx;
+  const u16* Y; int ycs, yco;
+  int n;
+  PW pwx;
+  float* ws;
+  int tiles_x, tiles_y;
+};
+
+constexpr int SF_K = 5, SF_TW = 64, SF_TH = 16, SF_LW = SF_TW + 8, SF_LH = SF_TH + SF_K - 1;   // (+8: the second column group reads on)
+constexpr int SF_XE = SF_LH * SF_LW * 4 + 64, SF_YE = SF_TH * SF_TW * 16;
+constexpr size_t SF_RED = (size_t)4 * SF_K * 2 * 256 * sizeof(float);
+constexpr size_t SF_TILES = (size_t)(SF_XE + SF_YE) * 2 > SF_RED ? (size_t)(SF_XE + SF_YE) * 2 : SF_RED;
+constexpr size_t SF_LDS = SF_TILES + 3 * 4 * sizeof(float);
+
+__global__ __launch_bounds__(256, 2) void wgrad_flatb_stem_kernel(WsfArgs a) {
+  extern __shared__ __attribute__((aligned(16))) u16 smem[];
+  u16* xs = smem;
+  u16* ys = smem + SF_XE;
+  float* lpw = reinterpret_cast<float*>(reinterpret_cast<char*>(smem) + SF_TILES);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, kq = lane >> 4;
+  const int trl = (4 * kq + (li >> 2)) * 16 + 4 * (li & 3);        // [pixel][16] image
+  const int trx = ((4 * kq + (li >> 2)) + (li & 3)) * 4;           // [pixel][4] image: chunk c = pixel + c
+
+  const bool on = a.pwx.scale != nullptr;
+  if (tid < 4) {
+    const bool ok = on && tid < a.cx;
+    lpw[tid] = ok ? a.pwx.scale[tid] : 1.f; lpw[4 + tid] = ok ? a.pwx.shift[tid] : 0.f; lpw[8 + tid] = ok ? a.pwx.slope[tid] : 1.f;
+  }
+  for (int e = tid; e < SF_XE / 4; e += 256) *reinterpret_cast<uint2*>(xs + e * 4) = make_uint2(0u, 0u);   // (slack stays 0)
+  __syncthreads();
+  float sc[4], sf[4], sl[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { sc[j] = lpw[j]; sf[j] = lpw[4 + j]; sl[j] = lpw[8 + j]; }
+
+  v4f acc[SF_K][2];
+#pragma unroll
+  for (int ky = 0; ky < SF_K; ++ky) { acc[ky][0] = v4f{0.f, 0.f, 0.f, 0.f}; acc[ky][1] = v4f{0.f, 0.f, 0.f, 0.f}; }
+
+  constexpr int XW = SF_TW + SF_K - 1;                                 // staged pixels per X row
+  constexpr int NUX = SF_LH * XW, XS = (NUX + 255) / 256;              // pixels of the X halo tile (one float4 each)
+  constexpr int NUY = SF_TH * SF_TW * 2, YS = NUY / 256;               // 8-channel units of the dY tile
+  const int per_img = a.tiles_x * a.tiles_y;
+  const int ntiles = per_img * a.n;
+  for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    const int n = t / per_img, tr = t - n * per_img;
+    const int ty0 = (tr / a.tiles_x) * SF_TH, tx0 = (tr % a.tiles_x) * SF_TW;
+    float4 xr[XS];
+    uint4 yr[YS];
+    unsigned xin = 0, yin = 0;
+    const int64_t ximg = (int64_t)n * a.h * a.w * a.xcs + a.xco;
+#pragma unroll
+    for (int i = 0; i < XS; ++i) {
+      const int e = tid + i * 256;
+      const int row = e / XW, px = e - row * XW;
+      const int gy = ty0 - 2 + row, gx = tx0 - 2 + px;
+      if (e < NUX && gy >= 0 && gy < a.h && gx >= 0 && gx < a.w) xin |= 1u << i;
+      const int cy = min(max(gy, 0), a.h - 1), cx = min(max(gx, 0), a.w - 1);
+      xr[i] = *reinterpret_cast<const float4*>(a.X + ximg + ((int64_t)cy * a.w + cx) * a.xcs);
+    }
+    const int64_t yimg = (int64_t)n * a.h * a.w * a.ycs + a.yco + (tid & 1) * 8;
+#pragma unroll
+    for (int i = 0; i < YS; ++i) {
+      const int e = tid + i * 256, pi = e >> 1;
+      const int row = pi / SF_TW, px = pi - row * SF_TW;
+      const int gy = ty0 + row, gx = tx0 + px;
+      if (gy < a.h && gx < a.w) yin |= 1u << i;
+      const int cy = min(gy, a.h - 1), cx = min(gx, a.w - 1);
+      yr[i] = *reinterpret_cast<const uint4*>(a.Y + yimg + ((int64_t)cy * a.w + cx) * a.ycs);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < XS; ++i) {
+      const int e = tid + i * 256;
+      if (e >= NUX) continue;
+      const int row = e / XW, px = e - row * XW;
+      const float r[4] = {xr[i].x, xr[i].y, xr[i].z, xr[i].w};
+      float v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float x = r[j];
+        if (on) { x = fmaf(x, sc[j], sf[j]); x = x > 0.f ? x : x * sl[j]; }
+        v[j] = (((xin >> i) & 1u) && j < a.cx) ? x : 0.f;
+      }
+      lds_store_unit<4>(xs + (row * SF_LW + px) * 4, v);
+    }
+#pragma unroll
+    for (int i = 0; i < YS; ++i)      // d_raw: no activation -- the raw words are the LDS image
+      *reinterpret_cast<uint4*>(ys + (tid + i * 256) * 8) = ((yin >> i) & 1u) ? yr[i] : make_uint4(0u, 0u, 0u, 0u);
+    __syncthreads();
+#pragma unroll 1
+    for (int r = wave; r < SF_TH; r += 4) {
+#pragma unroll
+      for (int seg = 0; seg < SF_TW / 32; ++seg) {
+        const u16* py = ys + (r * SF_TW + seg * 32) * 16 + trl;
+        const bf8 yf = frag_of(lds_tr(py), lds_tr(py + 16 * 16));
+#pragma unroll
+        for (int ky = 0; ky < SF_K; ++ky)
+#pragma unroll
+          for (int g = 0; g < 2; ++g) {
+            const u16* px_ = xs + ((r + ky) * SF_LW + seg * 32 + 4 * g) * 4 + trx;
+            const bf8 xf = frag_of(lds_tr(px_), lds_tr(px_ + 16 * 4));
+            acc[ky][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf, xf, acc[ky][g], 0, 0, 0);
+          }
+      }
+    }
+  }
+  // ---- waves meet through LDS: red[wave][ky][g][co = 4 kq + r][n = li = (kxs, ci)]
+  __syncthreads();
+  float* red = reinterpret_cast<float*>(smem);
+#pragma unroll
+  for (int ky = 0; ky < SF_K; ++ky)
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[(((wave * SF_K + ky) * 2 + g) * 16 + 4 * kq + r) * 16 + li] = acc[ky][g][r];
+  __syncthreads();
+  float* out = a.ws + (int64_t)blockIdx.x * SF_K * SF_K * 16 * 4;             // [ky][kx][co][ci(4)]
+  for (int e = tid; e < SF_K * SF_K * 16 * 4; e += 256) {
+    const int ci = e & 3, co = (e >> 2) & 15, tap = e >> 6;
+    const int ky = tap / SF_K, kx = tap - ky * SF_K;
+    const int g = kx >> 2, kxs = kx & 3;
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) v += red[(((w * SF_K + ky) * 2 + g) * 16 + co) * 16 + kxs * 4 + ci];
+    out[e] = v;
+  }
+}
+
+static bool sf_ok(const bp_conv* cv, const bp_view* X, const bp_view* Y, const PW& pwy) {
+  static const bool off = getenv("BP_BF16_NOFLATW") != nullptr;
+  if (off || cv->transposed || cv->k != SF_K || cv->stride != 1 || cv->pad != 2 || X->c > 4 || Y->c != 16) return false;
+  if (X->dtype != BP_F32 || Y->dtype != BP_BF16 || pwy.scale) return false;
+  if (X->h != Y->h || X->w != Y->w || X->n != Y->n) return false;
+  if (X->cstride % 4 || X->coff % 4 || X->coff + 4 > X->cstride || reinterpret_cast<uintptr_t>(X->ptr) % 16) return false;
+  if ((Y->cstride * 2) % 16 || (Y->coff * 2) % 16 || reinterpret_cast<uintptr_t>(Y->ptr) % 16) return false;
+  return true;
+}
+
+static int sf_launch(const bp_view* X, const PW& pwx, const bp_view* Y, float* ws, size_t ws_bytes, size_t* need,
+                     int* nsplit_out, int* cxp, int* cyp, hipStream_t st, bool dry) {
+  WsfArgs a{};
+  a.X = reinterpret_cast<const float*>(X->ptr); a.h = X->h; a.w = X->w; a.xcs = X->cstride; a.xco = X->coff; a.cx = X->c;
+  a.Y = reinterpret_cast<const u16*>(Y->ptr); a.ycs = Y->cstride; a.yco = Y->coff;
+  a.n = X->n; a.pwx = pwx; a.ws = ws;
+  a.tiles_x = bp_ceil_div(X->w, SF_TW); a.tiles_y = bp_ceil_div(X->h, SF_TH);
+  const int64_t ntiles = (int64_t)a.tiles_x * a.tiles_y * a.n;
+  const int ns = (int)(ntiles < 512 ? ntiles : 512);                 // two persistent workgroups per CU
+  *need = (size_t)ns * SF_K * SF_K * 16 * 4 * sizeof(float);
+  *nsplit_out = ns; *cxp = 4; *cyp = 16;
+  if (dry) return BP_OK;
+  if (!ws || ws_bytes < *need) return BP_EWORKSPACE;
+  static const hipError_t optin = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_flatb_stem_kernel),
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)SF_LDS);
+  if (optin != hipSuccess) return BP_ELAUNCH;
+  hipLaunchKernelGGL(wgrad_flatb_stem_kernel, dim3((unsigned)ns), dim3(256), SF_LDS, st, a);
+  BP_CHECK_LAUNCH();
+  return BP_OK;
+}
+
 // 16-byte loads of 8 channels need 16-byte aligned pixel rows; ragged channel counts take the scalar path
 bool wb_view_ok(const bp_view* v) {
   const int esz = v->dtype == BP_BF16 ? 2 : 4;
@@ -628,6 +797,7 @@ int bp_wgrad_bf16(const bp_conv* cv, const bp_view* X, const PW& pwx, const bp_v
                   size_t ws_bytes, size_t* need, int* nsplit, int* cxp, int* cyp, hipStream_t st, bool dry) {
   if (!wb_view_ok(X) || !wb_view_ok(Y)) return BP_EUNSUPPORTED;
   if (wf_ok(cv, X, Y, pwy)) return wf_launch(X, pwx, Y, ws, ws_bytes, need, nsplit, cxp, cyp, st, dry);
+  if (sf_ok(cv, X, Y, pwy)) return sf_launch(X, pwx, Y, ws, ws_bytes, need, nsplit, cxp, cyp, st, dry);
   const int k = cv->k, s = cv->stride, cx = X->c, cy = Y->c;
 #define BP_WB_(...) return wb_launch<__VA_ARGS__>(cv, X, pwx, Y, pwy, ws, ws_bytes, need, nsplit, cxp, cyp, st, dry)
   if (k == 3 && s == 1) {
