@@ -185,9 +185,19 @@ class CGAN(torch.nn.Module):
             self._flat[name] = flat
         for h in self.sn_layers:
             self._grads[id(h.weight)] = h.weight_grad
-        for p in self.parameters():
-            self._grads[id(p)] = p.grad
+            h._grad_view = h.weight_orig.grad
+        self._grad_pairs = [(p, p.grad) for p in self.parameters()]
+        for p, gv in self._grad_pairs:
+            self._grads[id(p)] = gv
         self.last = {}
+
+    def _attach_grads(self):
+        """``p.grad`` = the views of the flat gradient buffers the kernels write (and data parallelism averages) --
+        re-attached at the start of every step: ``optimizer.zero_grad()`` / ``model.zero_grad()`` set them to None by
+        default, and a gradient that lived outside the flat buffer would silently not be averaged across ranks."""
+        for p, gv in self._grad_pairs:
+            if p.grad is None or p.grad.data_ptr() != gv.data_ptr():
+                p.grad = gv
 
     def _init_weights(self):
         """Kaiming-normal except the generator's last layer: Xavier with gain 0.25 (README.md:102)."""
@@ -247,6 +257,7 @@ class CGAN(torch.nn.Module):
             y, zc = self._inputs(y, z)
             n = y.shape[0]
             plan = self._plan(n)
+            self._attach_grads()
             plan.generate(y, zc, self.training)
             plan.load_real(x)
             # ---- discriminator step

@@ -98,7 +98,12 @@ class SNConv2d(_NoForward, torch.nn.Conv2d):
         inner = (g * self.weight).sum()
         uv = torch.outer(self.weight_u, self.weight_v).view_as(g)
         r = (g - inner * uv) / self.sigma
-        if self.weight_orig.grad is None:
+        gv = getattr(self, "_grad_view", None)       # the owner's persistent view of a flat gradient buffer (CGAN)
+        if gv is not None:
+            gv.copy_(r)                              # ALWAYS into the flat buffer: data-parallel averaging reduces that
+            if self.weight_orig.grad is None or self.weight_orig.grad.data_ptr() != gv.data_ptr():
+                self.weight_orig.grad = gv           # (zero_grad(set_to_none=True) detached it)
+        elif self.weight_orig.grad is None:
             self.weight_orig.grad = r
         else:
             self.weight_orig.grad.copy_(r)          # in place: the gradient may be a view of a flat buffer

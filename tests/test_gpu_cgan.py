@@ -168,3 +168,32 @@ def test_cgan_painter_api(tmp_path):
     with pytest.raises(ValueError):
         p.paint(dm[:10], z=z)
 
+
+
+def test_cgan_gradients_stay_in_the_flat_buffers_after_zero_grad():
+    """Data parallelism averages the two flat gradient buffers: every parameter's gradient -- the spectrally normalised
+    weights' too, which are finished by torch glue -- must be a view of them after ``zero_grad()`` (set_to_none is
+    torch's default) as well."""
+    from baryon_painter_amd.models.cgan import CGAN
+    torch.manual_seed(0)
+    m = CGAN(tile_size=64, device="cuda:0", n_res=1)
+    m.train(True)
+    x, y, z = syn.synthetic_batch(2, 64, 64, seed=5)
+    x = np.tanh(3 * x - 0.5).astype(np.float32)
+    opt_g = torch.optim.Adam(m.g_parameters(), lr=5e-5, betas=(0.5, 0.999))
+    opt_d = torch.optim.Adam(m.d_parameters(), lr=5e-5, betas=(0.5, 0.999))
+    args = (torch.from_numpy(x), torch.from_numpy(y), torch.from_numpy(z), opt_g, opt_d)
+    m.train_step(*args)
+    m.zero_grad()
+    opt_g.zero_grad()
+    opt_d.zero_grad()
+    assert all(p.grad is None for p in m.parameters())
+    m.train_step(*args)
+    for name, net in (("d", m.discriminator), ("g", m.generator)):
+        flat = m._flat[name]
+        lo, hi = flat.data_ptr(), flat.data_ptr() + flat.numel() * 4
+        for k, p in net.named_parameters():
+            assert p.grad is not None and lo <= p.grad.data_ptr() < hi, (name, k)
+        assert torch.isfinite(flat).all() and float(flat.abs().sum()) > 0
+    sn = m.sn_layers[0]
+    assert float(sn.weight_orig.grad.abs().sum()) > 0
