@@ -254,6 +254,337 @@ __global__ __launch_bounds__(256, 3) void flatb_kernel(FbArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------- stride 2, k4, p1
+// The two thin stride-2 layers at the full / half resolution boundary (p_y_z_in.3: Conv 16 -> 32, p_y_z_in.22:
+// ConvTranspose 32 -> 16) and each other's data gradients, in the same scheme.
+//
+// T form (ConvTranspose2d forward / data gradient of the strided Conv2d): 32 gathered channels on the COARSE grid, 16
+// produced on the fine one.  Output phase (py, px) of coarse pixel (y, x) reads coarse rows y + iy0(py) + {0, 1} and
+// pixels x + ix0(px) + {0, 1}: flattened K of a tap row = 2 pixels x 32 channels = two K blocks = two whole pixels, and
+// the three pixels x-1, x, x+1 serve both px phases -- 3 fragment reads per input row feed 8-16 MFMAs.  All 16 weight
+// fragments (4 phases x 2 tap rows x 2 K blocks) in registers; a wave = 16 coarse pixels x 4 coarse rows x 4 phases.
+struct FtArgs {
+  const u16* in; int h, w, in_cs, in_co;          // coarse grid
+  void* out; int oh, ow, out_cs, out_co;          // fine grid (2h x 2w)
+  const u16* wp;
+  PW pw;
+  int tiles_x, tiles_y, n;
+  double* stat; int stat_c;
+};
+
+constexpr int FT_TW = 32, FT_TH = 16, FT_LW = FT_TW + 2, FT_LH = FT_TH + 2, FT_C = 32;
+constexpr int FT_ROWE = FT_LW * FT_C;
+constexpr size_t FT_LDS = ((size_t)FT_LH * FT_ROWE) * 2 + 3 * FT_C * sizeof(float) + 4 * 32 * sizeof(double);
+
+template <bool STATS>
+__global__ __launch_bounds__(256, 3) void flatb_t2_kernel(FtArgs a) {
+  constexpr int NU = FT_LH * FT_LW * 4, SLOTS = (NU + 255) / 256;       // 8-channel units
+  extern __shared__ __attribute__((aligned(16))) u16 smem_fb[];
+  u16* lds = smem_fb;
+  float* lpw = reinterpret_cast<float*>(lds + FT_LH * FT_ROWE);
+  double* red = reinterpret_cast<double*>(lpw + 3 * FT_C);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lj = lane & 15, kg = lane >> 4;
+  const int per_img = a.tiles_x * a.tiles_y;
+  const int t = fb_tile_of_block(per_img * a.n);
+  const int n = t / per_img, tr = t - n * per_img;
+  const int ty0 = (tr / a.tiles_x) * FT_TH, tx0 = (tr % a.tiles_x) * FT_TW;
+
+  const int64_t img = (int64_t)n * a.h * a.w * a.in_cs + a.in_co + (tid & 3) * 8;
+  uint4 stage[SLOTS];
+  unsigned inside = 0;
+#pragma unroll
+  for (int i = 0; i < SLOTS; ++i) {
+    const int e = tid + i * 256, pi = e >> 2;
+    const int row = pi / FT_LW, px = pi - row * FT_LW;
+    const int gy = ty0 - 1 + row, gx = tx0 - 1 + px;
+    if (e < NU && gy >= 0 && gy < a.h && gx >= 0 && gx < a.w) inside |= 1u << i;
+    const int cy = min(max(gy, 0), a.h - 1), cx = min(max(gx, 0), a.w - 1);
+    stage[i] = *reinterpret_cast<const uint4*>(a.in + img + ((int64_t)cy * a.w + cx) * a.in_cs);
+  }
+  const bool on = a.pw.scale != nullptr;
+  if (on && tid < FT_C) { lpw[tid] = a.pw.scale[tid]; lpw[FT_C + tid] = a.pw.shift[tid]; lpw[2 * FT_C + tid] = a.pw.slope[tid]; }
+  __syncthreads();
+  {
+    const int c0 = (tid & 3) * 8;
+    float sc[8], sf[8], sl[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      sc[j] = on ? lpw[c0 + j] : 1.f; sf[j] = on ? lpw[FT_C + c0 + j] : 0.f; sl[j] = on ? lpw[2 * FT_C + c0 + j] : 1.f;
+    }
+#pragma unroll
+    for (int i = 0; i < SLOTS; ++i) {
+      const int e = tid + i * 256;
+      if (e >= NU) continue;
+      if (!on) {                         // (a data gradient: no pending activation, the raw words are the image)
+        *reinterpret_cast<uint4*>(lds + e * 8) = ((inside >> i) & 1u) ? stage[i] : make_uint4(0u, 0u, 0u, 0u);
+        continue;
+      }
+      const unsigned w[4] = {stage[i].x, stage[i].y, stage[i].z, stage[i].w};
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { v[2 * j] = bf2f((u16)(w[j] & 0xffffu)); v[2 * j + 1] = bf2f((u16)(w[j] >> 16)); }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float x = fmaf(v[j], sc[j], sf[j]);
+        x = x > 0.f ? x : x * sl[j];
+        v[j] = ((inside >> i) & 1u) ? x : 0.f;
+      }
+      lds_store_unit<8>(lds + e * 8, v);
+    }
+  }
+  // weights [phase (py, px)][tap row ty][K block = tap column tx]: 16 fragments
+  bf8 wf[4][2][2];
+#pragma unroll
+  for (int ph = 0; ph < 4; ++ph)
+#pragma unroll
+    for (int ty = 0; ty < 2; ++ty)
+#pragma unroll
+      for (int tx = 0; tx < 2; ++tx)
+        wf[ph][ty][tx] = __builtin_bit_cast(bf8, *reinterpret_cast<const uint4*>(a.wp + (((ph * 2 + ty) * 2 + tx) * 64 + lane) * 8));
+  __syncthreads();
+
+  const int x0 = (wave & 1) * 16;
+  float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+  const int oxb = 2 * (tx0 + x0 + lj);
+#pragma unroll 1
+  for (int pass = 0; pass < 2; ++pass) {
+    const int r0 = (wave >> 1) * 8 + pass * 4;              // first coarse row (tile-relative) of this pass
+    v4f acc[4][4];                                          // [coarse row][phase]
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int ph = 0; ph < 4; ++ph) acc[r][ph] = v4f{0.f, 0.f, 0.f, 0.f};
+    const u16* base = lds + (r0 * FT_LW + x0 + lj) * FT_C + kg * 8;
+#pragma unroll
+    for (int jr = 0; jr < 6; ++jr) {                        // LDS rows r0 + jr = coarse rows r0 - 1 + jr
+      bf8 xf[3];
+#pragma unroll
+      for (int o = 0; o < 3; ++o) xf[o] = lds_frag<32>(base + (jr * FT_LW + o) * FT_C);
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int py = 0; py < 2; ++py) {
+          const int ty = jr - r - py;                       // coarse row r reads LDS rows r + py + ty
+          if (ty < 0 || ty > 1) continue;
+#pragma unroll
+          for (int px = 0; px < 2; ++px)
+#pragma unroll
+            for (int tx = 0; tx < 2; ++tx)
+              acc[r][py * 2 + px] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[py * 2 + px][ty][tx], xf[px + tx], acc[r][py * 2 + px], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int ph = 0; ph < 4; ++ph) {
+        const int oy = 2 * (ty0 + r0 + r) + (ph >> 1), ox = oxb + (ph & 1);
+        if (oy >= a.oh || ox >= a.ow) continue;
+        const int64_t o = ((int64_t)(n * a.oh + oy) * a.ow + ox) * a.out_cs + a.out_co + kg * 4;
+        *reinterpret_cast<uint2*>(reinterpret_cast<u16*>(a.out) + o) =
+            make_uint2(pack2(acc[r][ph][0], acc[r][ph][1]), pack2(acc[r][ph][2], acc[r][ph][3]));
+        if constexpr (STATS) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) { const float v = bf2f(f2bf(acc[r][ph][q])); s1[q] += v; s2[q] = fmaf(v, v, s2[q]); }
+        }
+      }
+  }
+  if constexpr (STATS) {
+    double d1[4], d2[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { d1[r] = (double)s1[r]; d2[r] = (double)s2[r]; }
+#pragma unroll
+    for (int m = 8; m >= 1; m >>= 1)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { d1[r] += __shfl_xor(d1[r], m, 16); d2[r] += __shfl_xor(d2[r], m, 16); }
+    if (lj == 0) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { red[wave * 32 + kg * 4 + r] = d1[r]; red[wave * 32 + 16 + kg * 4 + r] = d2[r]; }
+    }
+    __syncthreads();
+    if (tid < 32) {
+      const double v = ((red[tid] + red[32 + tid]) + red[64 + tid]) + red[96 + tid];
+      a.stat[((int64_t)t * 2 + (tid >> 4)) * a.stat_c + (tid & 15)] = v;
+    }
+  }
+}
+
+struct FtPackArgs { const float* w; u16* dst; int64_t sa, sb; };
+// [phase][ty][tx][k octet][row = produced channel][8]; tap (t) of phase p reads weight element bp_t_ky(p, 1, 2, 2, t)
+__global__ __launch_bounds__(256) void flatb_t2_pack_kernel(FtPackArgs a) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= 16 * 512) return;
+  int r = i;
+  const int e = r % 8; r /= 8;
+  const int row = r % 16; r /= 16;
+  const int kg = r % 4; r /= 4;
+  const int tx = r % 2; r /= 2;
+  const int ty = r % 2; r /= 2;
+  const int px = r % 2, py = r / 2;
+  const int c = kg * 8 + e;
+  const int ky = bp_t_ky(py, 1, 2, 2, ty), kx = bp_t_ky(px, 1, 2, 2, tx);
+  a.dst[i] = f2bf(a.w[c * a.sa + row * a.sb + ky * 4 + kx]);
+}
+
+// S form (strided Conv2d forward / data gradient of the ConvTranspose2d): 16 gathered channels on the FINE grid, 32
+// produced on the coarse one.  Flattened K of a tap row = 4 pixels x 16 channels = two K blocks, starting at fine pixel
+// 2x - 1: consecutive in the staged row.  32 produced channels = two MFMA row tiles whose rows interleave channel quads
+// (tile 0: channels 8q .. 8q+3, tile 1: 8q+4 .. 8q+7), so a lane's 8 values are 8 consecutive channels = one 16-byte
+// store.  An input-row fragment feeds up to 2 output rows x 2 row tiles; 16 weight fragments in registers.
+struct FsArgs {
+  const u16* in; int h, w, in_cs, in_co;          // fine grid
+  void* out; int oh, ow, out_cs, out_co;          // coarse grid
+  const u16* wp;
+  PW pw;
+  int tiles_x, tiles_y, n;
+  double* stat; int stat_c;
+};
+
+constexpr int FS_TW = 32, FS_TH = 8, FS_LW = 2 * (FS_TW - 1) + 4, FS_LH = 2 * (FS_TH - 1) + 4, FS_C = 16;
+constexpr int FS_ROWE = FS_LW * FS_C;
+constexpr size_t FS_LDS = ((size_t)FS_LH * FS_ROWE + 32) * 2 + 3 * FS_C * sizeof(float) + 4 * 64 * sizeof(double);
+
+template <bool STATS>
+__global__ __launch_bounds__(256, 3) void flatb_s2_kernel(FsArgs a) {
+  constexpr int NU = FS_LH * FS_LW * 2, SLOTS = (NU + 255) / 256;       // 8-channel units
+  extern __shared__ __attribute__((aligned(16))) u16 smem_fb[];
+  u16* lds = smem_fb;
+  float* lpw = reinterpret_cast<float*>(lds + FS_LH * FS_ROWE + 32);
+  double* red = reinterpret_cast<double*>(lpw + 3 * FS_C);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lj = lane & 15, kg = lane >> 4;
+  const int per_img = a.tiles_x * a.tiles_y;
+  const int t = fb_tile_of_block(per_img * a.n);
+  const int n = t / per_img, tr = t - n * per_img;
+  const int ty0 = (tr / a.tiles_x) * FS_TH, tx0 = (tr % a.tiles_x) * FS_TW;      // coarse (output) tile origin
+
+  const int64_t img = (int64_t)n * a.h * a.w * a.in_cs + a.in_co + (tid & 1) * 8;
+  uint4 stage[SLOTS];
+  unsigned inside = 0;
+#pragma unroll
+  for (int i = 0; i < SLOTS; ++i) {
+    const int e = tid + i * 256, pi = e >> 1;
+    const int row = pi / FS_LW, px = pi - row * FS_LW;
+    const int gy = 2 * ty0 - 1 + row, gx = 2 * tx0 - 1 + px;
+    if (e < NU && gy >= 0 && gy < a.h && gx >= 0 && gx < a.w) inside |= 1u << i;
+    const int cy = min(max(gy, 0), a.h - 1), cx = min(max(gx, 0), a.w - 1);
+    stage[i] = *reinterpret_cast<const uint4*>(a.in + img + ((int64_t)cy * a.w + cx) * a.in_cs);
+  }
+  const bool on = a.pw.scale != nullptr;
+  if (on && tid < FS_C) { lpw[tid] = a.pw.scale[tid]; lpw[FS_C + tid] = a.pw.shift[tid]; lpw[2 * FS_C + tid] = a.pw.slope[tid]; }
+  if (tid < 4) *reinterpret_cast<uint4*>(lds + FS_LH * FS_ROWE + tid * 8) = make_uint4(0u, 0u, 0u, 0u);
+  __syncthreads();
+  {
+    const int c0 = (tid & 1) * 8;
+    float sc[8], sf[8], sl[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      sc[j] = on ? lpw[c0 + j] : 1.f; sf[j] = on ? lpw[FS_C + c0 + j] : 0.f; sl[j] = on ? lpw[2 * FS_C + c0 + j] : 1.f;
+    }
+#pragma unroll
+    for (int i = 0; i < SLOTS; ++i) {
+      const int e = tid + i * 256;
+      if (e >= NU) continue;
+      if (!on) {
+        *reinterpret_cast<uint4*>(lds + e * 8) = ((inside >> i) & 1u) ? stage[i] : make_uint4(0u, 0u, 0u, 0u);
+        continue;
+      }
+      const unsigned w[4] = {stage[i].x, stage[i].y, stage[i].z, stage[i].w};
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { v[2 * j] = bf2f((u16)(w[j] & 0xffffu)); v[2 * j + 1] = bf2f((u16)(w[j] >> 16)); }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float x = fmaf(v[j], sc[j], sf[j]);
+        x = x > 0.f ? x : x * sl[j];
+        v[j] = ((inside >> i) & 1u) ? x : 0.f;
+      }
+      lds_store_unit<8>(lds + e * 8, v);
+    }
+  }
+  bf8 wf[4][2][2];                       // [tap row][K block][row tile]
+#pragma unroll
+  for (int ky = 0; ky < 4; ++ky)
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+        wf[ky][kb][mt] = __builtin_bit_cast(bf8, *reinterpret_cast<const uint4*>(a.wp + (((ky * 2 + kb) * 2 + mt) * 64 + lane) * 8));
+  __syncthreads();
+
+  const int x0 = (wave & 1) * 16, r0 = (wave >> 1) * 4;
+  v4f acc[4][2];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) { acc[r][0] = v4f{0.f, 0.f, 0.f, 0.f}; acc[r][1] = v4f{0.f, 0.f, 0.f, 0.f}; }
+  const u16* base = lds + (2 * r0 * FS_LW + 2 * (x0 + lj)) * FS_C + kg * 8;
+#pragma unroll
+  for (int jr = 0; jr < 10; ++jr)
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      const bf8 xf = lds_frag<32>(base + jr * FS_ROWE + kb * 32);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ky = jr - 2 * r;
+        if (ky < 0 || ky > 3) continue;
+        acc[r][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ky][kb][0], xf, acc[r][0], 0, 0, 0);
+        acc[r][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ky][kb][1], xf, acc[r][1], 0, 0, 0);
+      }
+    }
+  float s1[8], s2[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) { s1[q] = 0.f; s2[q] = 0.f; }
+  const int ox = tx0 + x0 + lj;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int oy = ty0 + r0 + r;
+    if (oy >= a.oh || ox >= a.ow) continue;
+    const int64_t o = ((int64_t)(n * a.oh + oy) * a.ow + ox) * a.out_cs + a.out_co + kg * 8;
+    *reinterpret_cast<uint4*>(reinterpret_cast<u16*>(a.out) + o) =
+        make_uint4(pack2(acc[r][0][0], acc[r][0][1]), pack2(acc[r][0][2], acc[r][0][3]),
+                   pack2(acc[r][1][0], acc[r][1][1]), pack2(acc[r][1][2], acc[r][1][3]));
+    if constexpr (STATS) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) { const float v = bf2f(f2bf(acc[r][q >> 2][q & 3])); s1[q] += v; s2[q] = fmaf(v, v, s2[q]); }
+    }
+  }
+  if constexpr (STATS) {
+    double d1[8], d2[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { d1[q] = (double)s1[q]; d2[q] = (double)s2[q]; }
+#pragma unroll
+    for (int m = 8; m >= 1; m >>= 1)
+#pragma unroll
+      for (int q = 0; q < 8; ++q) { d1[q] += __shfl_xor(d1[q], m, 16); d2[q] += __shfl_xor(d2[q], m, 16); }
+    if (lj == 0) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) { red[wave * 64 + kg * 8 + q] = d1[q]; red[wave * 64 + 32 + kg * 8 + q] = d2[q]; }
+    }
+    __syncthreads();
+    if (tid < 64) {
+      const double v = ((red[tid] + red[64 + tid]) + red[128 + tid]) + red[192 + tid];
+      a.stat[((int64_t)t * 2 + (tid >> 5)) * a.stat_c + (tid & 31)] = v;
+    }
+  }
+}
+
+// [tap row ky][K block][row tile mt][k octet][row][8]: produced channel = 8 (row >> 2) + 4 mt + (row & 3),
+// K index k = 32 kb + 8 kg + e -> (tap column kx = k / 16, gathered channel c = k % 16)
+__global__ __launch_bounds__(256) void flatb_s2_pack_kernel(FtPackArgs a) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= 16 * 512) return;
+  int r = i;
+  const int e = r % 8; r /= 8;
+  const int row = r % 16; r /= 16;
+  const int kg = r % 4; r /= 4;
+  const int mt = r % 2; r /= 2;
+  const int kb = r % 2, ky = r / 2;
+  const int co = 8 * (row >> 2) + 4 * mt + (row & 3);
+  const int k = kb * 32 + kg * 8 + e, kx = k / 16, c = k % 16;
+  a.dst[i] = f2bf(a.w[c * a.sa + co * a.sb + ky * 4 + kx]);
+}
+
 struct FbPackArgs {
   const float* w; u16* dst;
   int64_t sa, sb;
@@ -285,12 +616,20 @@ __global__ __launch_bounds__(256) void flatb_pack_kernel(FbPackArgs a) {
   a.dst[i] = f2bf(v);
 }
 
-// which instance serves this geometry: 0 none, 1 k7 16->8, 2 k7 8->16, 3 k5 3(4)->16 (stem forward), 4 k5 16->(1..4)
+// which instance serves this geometry: 0 none, 1 k7 16->8, 2 k7 8->16, 3 k5 3(4)->16 (stem forward), 4 k5 16->(1..4),
+// 5 stride-2 k4 transposed form 32->16, 6 stride-2 k4 conv form 16->32
 struct FbKind { int kind, ks, cinp, coutp; };
 static FbKind fb_kind(const ConvGeom& g) {
   static const bool off = getenv("BP_BF16_NOFLAT") != nullptr;
   static const bool off5 = getenv("BP_BF16_NOFLAT5") != nullptr;
+  static const bool off2 = getenv("BP_BF16_NOFLAT2") != nullptr;
   FbKind none{0, 0, 0, 0};
+  if (!off && !off2 && g.k == 4 && g.stride == 2 && g.pad == 1) {
+    if (g.gather_transposed && g.nphase == 2 && g.taps == 2 && g.IS == 1 && g.OS == 2 && g.cin_g == 32 && g.cout_g == 16)
+      return FbKind{5, 4, 32, 16};
+    if (!g.gather_transposed && g.nphase == 1 && g.taps == 4 && g.IS == 2 && g.OS == 1 && g.cin_g == 16 && g.cout_g == 32)
+      return FbKind{6, 4, 16, 32};
+  }
   if (off || g.stride != 1 || g.nphase != 1 || g.IS != 1 || g.OS != 1 || g.taps != g.k || g.pad != g.k / 2) return none;
   if (g.k == 7 && g.cin_g == 16 && g.cout_g == 8) return FbKind{1, 7, 16, 8};
   if (g.k == 7 && g.cin_g == 8 && g.cout_g == 16) return FbKind{2, 7, 8, 16};
@@ -303,7 +642,7 @@ template <int KS, int CIN, int COUTP, bool IB, bool OB, bool ST>
 static void fb_launch(const FbArgs& a, dim3 grid, hipStream_t st) {
   auto k = flatb_kernel<KS, CIN, COUTP, IB, OB, ST>;
   constexpr size_t lds = FbShape<KS, CIN>::LDS;
-  static const int once = (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
+  static const int once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
                                                (int)lds), 0);
   (void)once;
   hipLaunchKernelGGL(k, grid, dim3(256), lds, st, a);
@@ -315,6 +654,7 @@ static void fb_launch(const FbArgs& a, dim3 grid, hipStream_t st) {
 int64_t bp_bf16_flat_packed_elems(const ConvGeom& g) {
   const FbKind f = fb_kind(g);
   if (!f.kind) return 0;
+  if (f.kind >= 5) return 16 * 512;
   const int KB = (f.ks * f.cinp + 31) / 32, NP = f.ks + 16 / f.coutp - 1;
   return (int64_t)NP * KB * 64 * 8;
 }
@@ -322,6 +662,13 @@ int64_t bp_bf16_flat_packed_elems(const ConvGeom& g) {
 int bp_bf16_flat_pack(const ConvGeom& g, const WeightMap& wm, const float* w_torch, u16* dst, hipStream_t st) {
   const FbKind f = fb_kind(g);
   if (!f.kind) return BP_EUNSUPPORTED;
+  if (f.kind >= 5) {
+    FtPackArgs t{w_torch, dst, wm.sa, wm.sb};
+    if (f.kind == 5) hipLaunchKernelGGL(flatb_t2_pack_kernel, dim3(32), dim3(256), 0, st, t);
+    else hipLaunchKernelGGL(flatb_s2_pack_kernel, dim3(32), dim3(256), 0, st, t);
+    BP_CHECK_LAUNCH();
+    return BP_OK;
+  }
   FbPackArgs a{};
   a.w = w_torch; a.dst = dst; a.sa = wm.sa; a.sb = wm.sb; a.ks = f.ks; a.cin = g.cin_g; a.cinp = f.cinp;
   a.cout = g.cout_g; a.coutp = f.coutp; a.KB = (f.ks * f.cinp + 31) / 32;
@@ -335,10 +682,27 @@ int bp_bf16_flat_pack(const ConvGeom& g, const WeightMap& wm, const float* w_tor
 static int64_t fb_tiles(const bp_view* out) {
   return (int64_t)bp_ceil_div(out->w, FB_TW) * bp_ceil_div(out->h, FB_TH) * out->n;
 }
+// tiles of the stride-2 instances: coarse-grid tiles of the gathered (T form) / produced (S form) tensor
+static int64_t f2_tiles(int kind, const bp_view* in, const bp_view* out, int* tx, int* ty) {
+  if (kind == 5) { *tx = bp_ceil_div(in->w, FT_TW); *ty = bp_ceil_div(in->h, FT_TH); }
+  else { *tx = bp_ceil_div(out->w, FS_TW); *ty = bp_ceil_div(out->h, FS_TH); }
+  return (int64_t)*tx * *ty * out->n;
+}
+static bool f2_ok(const FbKind& f, const bp_view* in, const bp_view* out) {
+  if (in->dtype != BP_BF16 || out->dtype != BP_BF16 || in->n != out->n || in->c != f.cinp || out->c != f.coutp) return false;
+  if (f.kind == 5 ? (out->h != 2 * in->h || out->w != 2 * in->w) : (in->h != 2 * out->h || in->w != 2 * out->w)) return false;
+  if (reinterpret_cast<uintptr_t>(in->ptr) % 16 || reinterpret_cast<uintptr_t>(out->ptr) % 16) return false;
+  if (in->cstride % 8 || in->coff % 8) return false;
+  const int ov = f.kind == 5 ? 4 : 8;                      // channels per vector store
+  if (out->cstride % ov || out->coff % ov) return false;
+  int tx, ty;
+  return f2_tiles(f.kind, in, out, &tx, &ty) < (1ll << 31);
+}
 
 bool bp_bf16_flat_ok(const ConvGeom& g, const bp_view* in, const bp_view* out, const float* bias, bool stats) {
   const FbKind f = fb_kind(g);
   if (!f.kind || bias || !in || !out) return false;
+  if (f.kind >= 5) return f2_ok(f, in, out);
   if (stats && f.kind != 3) return false;
   if (in->c != g.cin_g || out->c != g.cout_g || in->h != out->h || in->w != out->w || in->n != out->n) return false;
   const bool ib = in->dtype == BP_BF16, ob = out->dtype == BP_BF16;
@@ -355,12 +719,52 @@ bool bp_bf16_flat_ok(const ConvGeom& g, const bp_view* in, const bp_view* out, c
 
 size_t bp_bf16_flat_stats_workspace(const ConvGeom& g, const bp_view* in, const bp_view* out) {
   if (!bp_bf16_flat_ok(g, in, out, nullptr, true)) return 0;
+  const FbKind f = fb_kind(g);
+  if (f.kind >= 5) {
+    int tx, ty;
+    return bp_stats_rows_bytes(f2_tiles(f.kind, in, out, &tx, &ty), g.cout_g);
+  }
   return bp_stats_rows_bytes(fb_tiles(out), g.cout_g);
 }
 
 int bp_bf16_flat_run(const ConvGeom& g, const bp_view* in, const PW& pw, const u16* packed_flat, const bp_view* out,
                      hipStream_t st, const IgemmStatsReq* sr) {
   const FbKind f = fb_kind(g);
+  if (f.kind >= 5) {
+    int tx, ty;
+    const int64_t rows = f2_tiles(f.kind, in, out, &tx, &ty);
+    double* stat = nullptr;
+    if (sr) {
+      const size_t need = bp_stats_rows_bytes(rows, g.cout_g);
+      if (sr->mode != 1 || !need) return BP_EUNSUPPORTED;
+      if (!sr->ws || sr->ws_bytes < need || !sr->sums) return BP_EWORKSPACE;
+      stat = reinterpret_cast<double*>(sr->ws);
+    }
+    if (f.kind == 5) {
+      FtArgs t{reinterpret_cast<const u16*>(in->ptr), in->h, in->w, in->cstride, in->coff, out->ptr, out->h, out->w,
+               out->cstride, out->coff, packed_flat, pw, tx, ty, in->n, stat, g.cout_g};
+      static const int once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(flatb_t2_kernel<true>),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)FT_LDS),
+                               (void)hipFuncSetAttribute(reinterpret_cast<const void*>(flatb_t2_kernel<false>),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)FT_LDS), 0);
+      (void)once;
+      if (sr) hipLaunchKernelGGL(flatb_t2_kernel<true>, dim3((unsigned)rows), dim3(256), FT_LDS, st, t);
+      else hipLaunchKernelGGL(flatb_t2_kernel<false>, dim3((unsigned)rows), dim3(256), FT_LDS, st, t);
+    } else {
+      FsArgs t{reinterpret_cast<const u16*>(in->ptr), in->h, in->w, in->cstride, in->coff, out->ptr, out->h, out->w,
+               out->cstride, out->coff, packed_flat, pw, tx, ty, in->n, stat, g.cout_g};
+      static const int once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(flatb_s2_kernel<true>),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)FS_LDS),
+                               (void)hipFuncSetAttribute(reinterpret_cast<const void*>(flatb_s2_kernel<false>),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)FS_LDS), 0);
+      (void)once;
+      if (sr) hipLaunchKernelGGL(flatb_s2_kernel<true>, dim3((unsigned)rows), dim3(256), FS_LDS, st, t);
+      else hipLaunchKernelGGL(flatb_s2_kernel<false>, dim3((unsigned)rows), dim3(256), FS_LDS, st, t);
+    }
+    BP_CHECK_LAUNCH();
+    if (!sr) return BP_OK;
+    return bp_stats_rows_finish(stat, rows, g.cout_g, sr, st);
+  }
   FbArgs a{};
   a.in = in->ptr; a.h = in->h; a.w = in->w; a.in_cs = in->cstride; a.in_co = in->coff; a.cin = g.cin_g;
   a.out = out->ptr; a.out_cs = out->cstride; a.out_co = out->coff; a.cout = g.cout_g;
