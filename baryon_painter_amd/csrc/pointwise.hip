@@ -607,30 +607,39 @@ __global__ __launch_bounds__(RB) void loglik_forward_kernel(LoglikArgs a) {
   }
 }
 
-__global__ void loglik_finalize_kernel(bp_loglik ll, const double* partial, int nblk, const double* kl_sum,
-                                       float* stats) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+// One wave: the partial rows are summed by 64 lanes (lane l takes rows l, l + 64, ...) and a fixed-order shuffle
+// tree -- one thread walking 2 x 1024 rows was 87 us of dependent loads between the forward and the backward pass.
+__global__ __launch_bounds__(64) void loglik_finalize_kernel(bp_loglik ll, const double* partial, int nblk,
+                                                             const double* kl_sum, float* stats) {
+  if (blockIdx.x != 0) return;
+  const int lane = threadIdx.x;
   const int c = ll.c;
   const double norm = (double)ll.n * ll.L;
   const double c0 = -0.5 * log(2.0 * M_PI);
   double total = 0.0;
   for (int ch = 0; ch < c; ++ch) {
     double sf = 0.0, sv = 0.0;
-    for (int b = 0; b < nblk; ++b) {
+    for (int b = lane; b < nblk; b += 64) {
       sf += partial[((int64_t)b * 2 + 0) * c + ch];
       sv += partial[((int64_t)b * 2 + 1) * c + ch];
     }
-    const double fixed = c0 + sf / norm;
-    const double freev = c0 + sv / norm;
-    const double llk = ll.predict_var ? (1.0 - ll.alpha_var) * fixed + ll.alpha_var * freev : fixed;
-    stats[2 + ch] = (float)llk;
-    stats[2 + c + ch] = (float)fixed;
-    stats[2 + 2 * c + ch] = (float)(ll.predict_var ? freev : 0.0);
-    total += llk;
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) { sf += __shfl_down(sf, s, 64); sv += __shfl_down(sv, s, 64); }
+    if (lane == 0) {
+      const double fixed = c0 + sf / norm;
+      const double freev = c0 + sv / norm;
+      const double llk = ll.predict_var ? (1.0 - ll.alpha_var) * fixed + ll.alpha_var * freev : fixed;
+      stats[2 + ch] = (float)llk;
+      stats[2 + c + ch] = (float)fixed;
+      stats[2 + 2 * c + ch] = (float)(ll.predict_var ? freev : 0.0);
+      total += llk;
+    }
   }
-  const double kl = kl_sum ? 0.5 / (double)ll.n * (*kl_sum) : 0.0;
-  stats[1] = (float)kl;
-  stats[0] = (float)(-kl * ll.beta_kl + ll.likelihood_scaling * total);
+  if (lane == 0) {
+    const double kl = kl_sum ? 0.5 / (double)ll.n * (*kl_sum) : 0.0;
+    stats[1] = (float)kl;
+    stats[0] = (float)(-kl * ll.beta_kl + ll.likelihood_scaling * total);
+  }
 }
 
 struct LoglikBwdArgs {
@@ -799,7 +808,9 @@ static inline RedPlan red_plan(int c, int64_t npix) {
   RedPlan r{};
   r.CP = h_next_pow2(c < RB ? c : RB);
   r.npass = bp_ceil_div(c, r.CP);
-  int64_t nb = (npix + 2047) / 2048;
+  // (256 pixels per block at least: with 2048 the 16 x 16 latent-level tensors of the recognition / prior networks ran
+  //  on 8 workgroups, 256 dependent trips per thread: 0.14 ms for a 2 MB tensor)
+  int64_t nb = (npix + 255) / 256;
   if (nb > MAX_RBLOCKS) nb = MAX_RBLOCKS;
   if (nb < 1) nb = 1;
   r.ppb = (npix + nb - 1) / nb;

@@ -6,6 +6,7 @@
 // Arithmetic is fp32 per element (inputs are 8-bit-mantissa values; the reference's double evaluation of the
 // batch-norm backward map would be rounded away by the bf16 store), sums are double.
 #include "common.hpp"
+#include <cstdlib>
 
 namespace {
 
@@ -239,7 +240,10 @@ struct FastPlan8 { int nblk; int64_t total8, chunk8; };
 static inline FastPlan8 fast_plan8(int64_t total_elems) {
   FastPlan8 f{};
   f.total8 = total_elems / 8;
-  int64_t nb = (f.total8 + 2047) / 2048;          // >= 8 accesses per thread
+  static const int per = getenv("BP_PW8_UNITS") ? atoi(getenv("BP_PW8_UNITS")) : 16;
+  int64_t nb = (f.total8 + 256 * per - 1) / (256 * per);   // >= 16 accesses per thread: a thread's fixed costs (24
+  //                                                 activation parameters, the block's three tree reductions, a row of
+  //                                                 partial sums) were most of the launch on the 67 MB trunk tensors
   if (nb > 2048) nb = 2048;
   if (nb < 1) nb = 1;
   int64_t chunk = (f.total8 + nb - 1) / nb;
@@ -251,7 +255,8 @@ static inline FastPlan8 fast_plan8(int64_t total_elems) {
 
 static inline const uint4* u4(const bp_view* v) { return v ? reinterpret_cast<const uint4*>(v->ptr) : nullptr; }
 static inline unsigned stream_blocks(int64_t total8) {
-  int64_t nb = (total8 + RB * 4 - 1) / (RB * 4);
+  static const int per = getenv("BP_PW8_UNITS") ? atoi(getenv("BP_PW8_UNITS")) : 16;
+  int64_t nb = (total8 + RB * per - 1) / (RB * per);       // (>= 16 units per thread: 56 parameter loads per thread)
   if (nb > 4096) nb = 4096;
   if (nb < 1) nb = 1;
   return (unsigned)nb;
