@@ -40,7 +40,8 @@ class Sync:
         # BP_SYNC_FORCE=1: issue every collective even with one rank (a one-GPU box then drives the whole data-parallel
         # schedule -- the float64 statistics buffers, the gradient buffer -- through RCCL itself)
         self.active = self.world_size > 1 or os.environ.get("BP_SYNC_FORCE") == "1"
-        if grad_group is None and os.environ.get("BP_EARLY_ALLREDUCE", "0") == "1":
+        if grad_group is None and (os.environ.get("BP_EARLY_ALLREDUCE", "0") == "1"
+                                   or os.environ.get("BP_GRAD_COMM", "0") == "1"):      # (=1: experiments)
             grad_group = "new"
         self.grad_group = dist.new_group() if (grad_group == "new" and self.active) else \
             (group if grad_group in ("new", None) else grad_group)

@@ -50,10 +50,8 @@ if __name__ == "__main__":
             local_rank = 0
         compute_device = f"cuda:{local_rank}"
         torch.cuda.set_device(local_rank)
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device(compute_device))
-        else:
-            dist.init_process_group(backend)
+        # (lazy communicator creation -- no device_id=: the eager form costs ~80 us per all-reduce of a step, bench.py)
+        dist.init_process_group(backend)
         from baryon_painter_amd.dist import Sync
         sync = Sync()
 

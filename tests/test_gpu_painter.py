@@ -84,7 +84,7 @@ r = int(os.environ["RANK"])
 dev = "cuda:%d" % (r if backend == "nccl" else 0)
 torch.cuda.set_device(dev)
 if backend == "nccl":
-    dist.init_process_group("nccl", device_id=torch.device(dev))
+    dist.init_process_group("nccl")
 else:
     dist.init_process_group("gloo")
 w = dist.get_world_size()
@@ -175,7 +175,8 @@ from baryon_painter_amd.dist import Sync
 from baryon_painter_amd.models import arch as A
 from baryon_painter_amd.models.cvae import CVAE
 from baryon_painter_amd.utils import synthetic as syn
-dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1)
 size, n = 64, 4
 arch = A.fiducial_architecture(size)
 x, y, aux = syn.synthetic_batch(n, size, size, seed=21)
