@@ -585,6 +585,320 @@ __global__ __launch_bounds__(256) void flatb_s2_pack_kernel(FtPackArgs a) {
   a.dst[i] = f2bf(a.w[c * a.sa + co * a.sb + ky * 4 + kx]);
 }
 
+// ---------------------------------------------------------------------------------------------- 32 <-> 64, stride 2
+// The same two forms one level down (p_y_z_in.6: Conv 32 -> 64, p_y_z_in.19: ConvTranspose 64 -> 32, and each other's
+// data gradients).  A layer's weights (64 fragments) no longer fit one wave: the four waves of a workgroup split them
+// -- S form by halves of the 64 produced channels (two strips of 16 pixels x two halves), T form by output row phase
+// (two strips x two phases) -- 32 fragments per wave, every wave reads the staged tile's fragments itself.
+constexpr int GS_TW = 32, GS_TH = 4, GS_LW = 2 * (GS_TW - 1) + 4, GS_LH = 2 * (GS_TH - 1) + 4, GS_C = 32;
+constexpr int GS_ROWE = GS_LW * GS_C;
+constexpr size_t GS_LDS = ((size_t)GS_LH * GS_ROWE) * 2 + 3 * GS_C * sizeof(float) + 4 * 64 * sizeof(double);
+
+template <bool STATS>
+__global__ __launch_bounds__(256, 2) void flatb_s2w_kernel(FsArgs a) {
+  constexpr int NU = GS_LH * GS_LW * 4, SLOTS = (NU + 255) / 256;
+  extern __shared__ __attribute__((aligned(16))) u16 smem_fb[];
+  u16* lds = smem_fb;
+  float* lpw = reinterpret_cast<float*>(lds + GS_LH * GS_ROWE);
+  double* red = reinterpret_cast<double*>(lpw + 3 * GS_C);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lj = lane & 15, kg = lane >> 4;
+  const int per_img = a.tiles_x * a.tiles_y;
+  const int t = fb_tile_of_block(per_img * a.n);
+  const int n = t / per_img, tr = t - n * per_img;
+  const int ty0 = (tr / a.tiles_x) * GS_TH, tx0 = (tr % a.tiles_x) * GS_TW;
+
+  const int64_t img = (int64_t)n * a.h * a.w * a.in_cs + a.in_co + (tid & 3) * 8;
+  uint4 stage[SLOTS];
+  unsigned inside = 0;
+#pragma unroll
+  for (int i = 0; i < SLOTS; ++i) {
+    const int e = tid + i * 256, pi = e >> 2;
+    const int row = pi / GS_LW, px = pi - row * GS_LW;
+    const int gy = 2 * ty0 - 1 + row, gx = 2 * tx0 - 1 + px;
+    if (e < NU && gy >= 0 && gy < a.h && gx >= 0 && gx < a.w) inside |= 1u << i;
+    const int cy = min(max(gy, 0), a.h - 1), cx = min(max(gx, 0), a.w - 1);
+    stage[i] = *reinterpret_cast<const uint4*>(a.in + img + ((int64_t)cy * a.w + cx) * a.in_cs);
+  }
+  const bool on = a.pw.scale != nullptr;
+  if (on && tid < GS_C) { lpw[tid] = a.pw.scale[tid]; lpw[GS_C + tid] = a.pw.shift[tid]; lpw[2 * GS_C + tid] = a.pw.slope[tid]; }
+  __syncthreads();
+  {
+    const int c0 = (tid & 3) * 8;
+    float sc[8], sf[8], sl[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      sc[j] = on ? lpw[c0 + j] : 1.f; sf[j] = on ? lpw[GS_C + c0 + j] : 0.f; sl[j] = on ? lpw[2 * GS_C + c0 + j] : 1.f;
+    }
+#pragma unroll
+    for (int i = 0; i < SLOTS; ++i) {
+      const int e = tid + i * 256;
+      if (e >= NU) continue;
+      if (!on) {
+        *reinterpret_cast<uint4*>(lds + e * 8) = ((inside >> i) & 1u) ? stage[i] : make_uint4(0u, 0u, 0u, 0u);
+        continue;
+      }
+      const unsigned w[4] = {stage[i].x, stage[i].y, stage[i].z, stage[i].w};
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { v[2 * j] = bf2f((u16)(w[j] & 0xffffu)); v[2 * j + 1] = bf2f((u16)(w[j] >> 16)); }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float x = fmaf(v[j], sc[j], sf[j]);
+        x = x > 0.f ? x : x * sl[j];
+        v[j] = ((inside >> i) & 1u) ? x : 0.f;
+      }
+      lds_store_unit<8>(lds + e * 8, v);
+    }
+  }
+  const int x0 = (wave & 1) * 16, half = wave >> 1;
+  bf8 wf[4][4][2];                       // [tap row][K block = fine pixel of the tap row][row tile] of this channel half
+#pragma unroll
+  for (int ky = 0; ky < 4; ++ky)
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+        wf[ky][kb][mt] = __builtin_bit_cast(bf8, *reinterpret_cast<const uint4*>(
+            a.wp + (((((half * 4 + ky) * 4 + kb) * 2 + mt) * 64) + lane) * 8));
+  __syncthreads();
+
+  v4f acc[4][2];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) { acc[r][0] = v4f{0.f, 0.f, 0.f, 0.f}; acc[r][1] = v4f{0.f, 0.f, 0.f, 0.f}; }
+  const u16* base = lds + (2 * (x0 + lj)) * GS_C + kg * 8;
+#pragma unroll
+  for (int jr = 0; jr < GS_LH; ++jr)
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+      const bf8 xf = lds_frag<32>(base + jr * GS_ROWE + kb * GS_C);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ky = jr - 2 * r;
+        if (ky < 0 || ky > 3) continue;
+        acc[r][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ky][kb][0], xf, acc[r][0], 0, 0, 0);
+        acc[r][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ky][kb][1], xf, acc[r][1], 0, 0, 0);
+      }
+    }
+  float s1[8], s2[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) { s1[q] = 0.f; s2[q] = 0.f; }
+  const int ox = tx0 + x0 + lj;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int oy = ty0 + r;
+    if (oy >= a.oh || ox >= a.ow) continue;
+    const int64_t o = ((int64_t)(n * a.oh + oy) * a.ow + ox) * a.out_cs + a.out_co + half * 32 + kg * 8;
+    *reinterpret_cast<uint4*>(reinterpret_cast<u16*>(a.out) + o) =
+        make_uint4(pack2(acc[r][0][0], acc[r][0][1]), pack2(acc[r][0][2], acc[r][0][3]),
+                   pack2(acc[r][1][0], acc[r][1][1]), pack2(acc[r][1][2], acc[r][1][3]));
+    if constexpr (STATS) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) { const float v = bf2f(f2bf(acc[r][q >> 2][q & 3])); s1[q] += v; s2[q] = fmaf(v, v, s2[q]); }
+    }
+  }
+  if constexpr (STATS) {
+    double d1[8], d2[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { d1[q] = (double)s1[q]; d2[q] = (double)s2[q]; }
+#pragma unroll
+    for (int m = 8; m >= 1; m >>= 1)
+#pragma unroll
+      for (int q = 0; q < 8; ++q) { d1[q] += __shfl_xor(d1[q], m, 16); d2[q] += __shfl_xor(d2[q], m, 16); }
+    if (lj == 0) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) { red[wave * 64 + kg * 8 + q] = d1[q]; red[wave * 64 + 32 + kg * 8 + q] = d2[q]; }
+    }
+    __syncthreads();
+    if (tid < 128) {                     // (channel half, statistic, channel of the half): the two strips' waves
+      const int h = tid >> 6, st = (tid >> 5) & 1, c = tid & 31;
+      const double v = red[(2 * h) * 64 + st * 32 + c] + red[(2 * h + 1) * 64 + st * 32 + c];
+      a.stat[((int64_t)t * 2 + st) * a.stat_c + 32 * h + c] = v;
+    }
+  }
+}
+
+// [channel half][ky][K block = tap column][row tile][k octet][row][8]; produced channel = 32 half + 8 (row >> 2) + 4 mt + (row & 3)
+__global__ __launch_bounds__(256) void flatb_s2w_pack_kernel(FtPackArgs a) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= 64 * 512) return;
+  int r = i;
+  const int e = r % 8; r /= 8;
+  const int row = r % 16; r /= 16;
+  const int kg = r % 4; r /= 4;
+  const int mt = r % 2; r /= 2;
+  const int kb = r % 4; r /= 4;
+  const int ky = r % 4, half = r / 4;
+  const int co = 32 * half + 8 * (row >> 2) + 4 * mt + (row & 3);
+  a.dst[i] = f2bf(a.w[(kg * 8 + e) * a.sa + co * a.sb + ky * 4 + kb]);
+}
+
+constexpr int GT_TW = 32, GT_TH = 8, GT_LW = GT_TW + 2, GT_LH = GT_TH + 2, GT_C = 64;
+constexpr int GT_ROWE = GT_LW * GT_C;
+constexpr size_t GT_LDS = ((size_t)GT_LH * GT_ROWE) * 2 + 3 * GT_C * sizeof(float) + 4 * 64 * sizeof(double);
+
+template <bool STATS>
+__global__ __launch_bounds__(256, 2) void flatb_t2w_kernel(FtArgs a) {
+  constexpr int NU = GT_LH * GT_LW * 8, SLOTS = (NU + 255) / 256;
+  extern __shared__ __attribute__((aligned(16))) u16 smem_fb[];
+  u16* lds = smem_fb;
+  float* lpw = reinterpret_cast<float*>(lds + GT_LH * GT_ROWE);
+  double* red = reinterpret_cast<double*>(lpw + 3 * GT_C);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lj = lane & 15, kg = lane >> 4;
+  const int per_img = a.tiles_x * a.tiles_y;
+  const int t = fb_tile_of_block(per_img * a.n);
+  const int n = t / per_img, tr = t - n * per_img;
+  const int ty0 = (tr / a.tiles_x) * GT_TH, tx0 = (tr % a.tiles_x) * GT_TW;
+
+  const int64_t img = (int64_t)n * a.h * a.w * a.in_cs + a.in_co + (tid & 7) * 8;
+  uint4 stage[SLOTS];
+  unsigned inside = 0;
+#pragma unroll
+  for (int i = 0; i < SLOTS; ++i) {
+    const int e = tid + i * 256, pi = e >> 3;
+    const int row = pi / GT_LW, px = pi - row * GT_LW;
+    const int gy = ty0 - 1 + row, gx = tx0 - 1 + px;
+    if (e < NU && gy >= 0 && gy < a.h && gx >= 0 && gx < a.w) inside |= 1u << i;
+    const int cy = min(max(gy, 0), a.h - 1), cx = min(max(gx, 0), a.w - 1);
+    stage[i] = *reinterpret_cast<const uint4*>(a.in + img + ((int64_t)cy * a.w + cx) * a.in_cs);
+  }
+  const bool on = a.pw.scale != nullptr;
+  if (on && tid < GT_C) { lpw[tid] = a.pw.scale[tid]; lpw[GT_C + tid] = a.pw.shift[tid]; lpw[2 * GT_C + tid] = a.pw.slope[tid]; }
+  __syncthreads();
+  {
+    const int c0 = (tid & 7) * 8;
+    float sc[8], sf[8], sl[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      sc[j] = on ? lpw[c0 + j] : 1.f; sf[j] = on ? lpw[GT_C + c0 + j] : 0.f; sl[j] = on ? lpw[2 * GT_C + c0 + j] : 1.f;
+    }
+#pragma unroll
+    for (int i = 0; i < SLOTS; ++i) {
+      const int e = tid + i * 256;
+      if (e >= NU) continue;
+      if (!on) {
+        *reinterpret_cast<uint4*>(lds + e * 8) = ((inside >> i) & 1u) ? stage[i] : make_uint4(0u, 0u, 0u, 0u);
+        continue;
+      }
+      const unsigned w[4] = {stage[i].x, stage[i].y, stage[i].z, stage[i].w};
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { v[2 * j] = bf2f((u16)(w[j] & 0xffffu)); v[2 * j + 1] = bf2f((u16)(w[j] >> 16)); }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float x = fmaf(v[j], sc[j], sf[j]);
+        x = x > 0.f ? x : x * sl[j];
+        v[j] = ((inside >> i) & 1u) ? x : 0.f;
+      }
+      lds_store_unit<8>(lds + e * 8, v);
+    }
+  }
+  const int x0 = (wave & 1) * 16, py = wave >> 1;
+  bf8 wf[2][2][4][2];                    // [px][ty][K block = (tx, channel half)][row tile] of this wave's row phase
+#pragma unroll
+  for (int px = 0; px < 2; ++px)
+#pragma unroll
+    for (int ty = 0; ty < 2; ++ty)
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+          wf[px][ty][kb][mt] = __builtin_bit_cast(bf8, *reinterpret_cast<const uint4*>(
+              a.wp + ((((((py * 2 + px) * 2 + ty) * 4 + kb) * 2 + mt) * 64) + lane) * 8));
+  __syncthreads();
+
+  float s1[8], s2[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) { s1[q] = 0.f; s2[q] = 0.f; }
+  const int oxb = 2 * (tx0 + x0 + lj);
+#pragma unroll 1
+  for (int pass = 0; pass < 2; ++pass) {
+    const int r0 = pass * 4;
+    v4f acc[4][2][2];                    // [coarse row][px][row tile]
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int px = 0; px < 2; ++px) { acc[r][px][0] = v4f{0.f, 0.f, 0.f, 0.f}; acc[r][px][1] = v4f{0.f, 0.f, 0.f, 0.f}; }
+    const u16* base = lds + ((r0 + py) * GT_LW + x0 + lj) * GT_C + kg * 8;      // LDS row of coarse row r, tap ty: r + py + ty
+#pragma unroll
+    for (int jr = 0; jr < 5; ++jr) {
+      bf8 xf[3][2];
+#pragma unroll
+      for (int o = 0; o < 3; ++o)
+#pragma unroll
+        for (int hc = 0; hc < 2; ++hc) xf[o][hc] = lds_frag<32>(base + (jr * GT_LW + o) * GT_C + hc * 32);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ty = jr - r;
+        if (ty < 0 || ty > 1) continue;
+#pragma unroll
+        for (int px = 0; px < 2; ++px)
+#pragma unroll
+          for (int tx = 0; tx < 2; ++tx)
+#pragma unroll
+            for (int hc = 0; hc < 2; ++hc) {
+              acc[r][px][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[px][ty][tx * 2 + hc][0], xf[px + tx][hc], acc[r][px][0], 0, 0, 0);
+              acc[r][px][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[px][ty][tx * 2 + hc][1], xf[px + tx][hc], acc[r][px][1], 0, 0, 0);
+            }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int px = 0; px < 2; ++px) {
+        const int oy = 2 * (ty0 + r0 + r) + py, ox = oxb + px;
+        if (oy >= a.oh || ox >= a.ow) continue;
+        const int64_t o = ((int64_t)(n * a.oh + oy) * a.ow + ox) * a.out_cs + a.out_co + kg * 8;
+        *reinterpret_cast<uint4*>(reinterpret_cast<u16*>(a.out) + o) =
+            make_uint4(pack2(acc[r][px][0][0], acc[r][px][0][1]), pack2(acc[r][px][0][2], acc[r][px][0][3]),
+                       pack2(acc[r][px][1][0], acc[r][px][1][1]), pack2(acc[r][px][1][2], acc[r][px][1][3]));
+        if constexpr (STATS) {
+#pragma unroll
+          for (int q = 0; q < 8; ++q) { const float v = bf2f(f2bf(acc[r][px][q >> 2][q & 3])); s1[q] += v; s2[q] = fmaf(v, v, s2[q]); }
+        }
+      }
+  }
+  if constexpr (STATS) {
+    double d1[8], d2[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { d1[q] = (double)s1[q]; d2[q] = (double)s2[q]; }
+#pragma unroll
+    for (int m = 8; m >= 1; m >>= 1)
+#pragma unroll
+      for (int q = 0; q < 8; ++q) { d1[q] += __shfl_xor(d1[q], m, 16); d2[q] += __shfl_xor(d2[q], m, 16); }
+    if (lj == 0) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) { red[wave * 64 + kg * 8 + q] = d1[q]; red[wave * 64 + 32 + kg * 8 + q] = d2[q]; }
+    }
+    __syncthreads();
+    if (tid < 64) {
+      const double v = ((red[tid] + red[64 + tid]) + red[128 + tid]) + red[192 + tid];
+      a.stat[((int64_t)t * 2 + (tid >> 5)) * a.stat_c + (tid & 31)] = v;
+    }
+  }
+}
+
+// [py][px][ty][K block = (tx, channel half)][row tile][k octet][row][8]; produced channel = 8 (row >> 2) + 4 mt + (row & 3)
+__global__ __launch_bounds__(256) void flatb_t2w_pack_kernel(FtPackArgs a) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= 64 * 512) return;
+  int r = i;
+  const int e = r % 8; r /= 8;
+  const int row = r % 16; r /= 16;
+  const int kg = r % 4; r /= 4;
+  const int mt = r % 2; r /= 2;
+  const int kb = r % 4; r /= 4;
+  const int ty = r % 2; r /= 2;
+  const int px = r % 2, py = r / 2;
+  const int co = 8 * (row >> 2) + 4 * mt + (row & 3);
+  const int tx = kb >> 1, c = (kb & 1) * 32 + kg * 8 + e;
+  const int ky = bp_t_ky(py, 1, 2, 2, ty), kx = bp_t_ky(px, 1, 2, 2, tx);
+  a.dst[i] = f2bf(a.w[c * a.sa + co * a.sb + ky * 4 + kx]);
+}
+
 struct FbPackArgs {
   const float* w; u16* dst;
   int64_t sa, sb;
@@ -629,6 +943,11 @@ static FbKind fb_kind(const ConvGeom& g) {
       return FbKind{5, 4, 32, 16};
     if (!g.gather_transposed && g.nphase == 1 && g.taps == 4 && g.IS == 2 && g.OS == 1 && g.cin_g == 16 && g.cout_g == 32)
       return FbKind{6, 4, 16, 32};
+    static const bool offw = getenv("BP_BF16_NOFLAT2W") != nullptr;
+    if (!offw && g.gather_transposed && g.nphase == 2 && g.taps == 2 && g.IS == 1 && g.OS == 2 && g.cin_g == 64 && g.cout_g == 32)
+      return FbKind{7, 4, 64, 32};
+    if (!offw && !g.gather_transposed && g.nphase == 1 && g.taps == 4 && g.IS == 2 && g.OS == 1 && g.cin_g == 32 && g.cout_g == 64)
+      return FbKind{8, 4, 32, 64};
   }
   if (off || g.stride != 1 || g.nphase != 1 || g.IS != 1 || g.OS != 1 || g.taps != g.k || g.pad != g.k / 2) return none;
   if (g.k == 7 && g.cin_g == 16 && g.cout_g == 8) return FbKind{1, 7, 16, 8};
@@ -654,6 +973,7 @@ static void fb_launch(const FbArgs& a, dim3 grid, hipStream_t st) {
 int64_t bp_bf16_flat_packed_elems(const ConvGeom& g) {
   const FbKind f = fb_kind(g);
   if (!f.kind) return 0;
+  if (f.kind >= 7) return 64 * 512;
   if (f.kind >= 5) return 16 * 512;
   const int KB = (f.ks * f.cinp + 31) / 32, NP = f.ks + 16 / f.coutp - 1;
   return (int64_t)NP * KB * 64 * 8;
@@ -665,7 +985,9 @@ int bp_bf16_flat_pack(const ConvGeom& g, const WeightMap& wm, const float* w_tor
   if (f.kind >= 5) {
     FtPackArgs t{w_torch, dst, wm.sa, wm.sb};
     if (f.kind == 5) hipLaunchKernelGGL(flatb_t2_pack_kernel, dim3(32), dim3(256), 0, st, t);
-    else hipLaunchKernelGGL(flatb_s2_pack_kernel, dim3(32), dim3(256), 0, st, t);
+    else if (f.kind == 6) hipLaunchKernelGGL(flatb_s2_pack_kernel, dim3(32), dim3(256), 0, st, t);
+    else if (f.kind == 7) hipLaunchKernelGGL(flatb_t2w_pack_kernel, dim3(128), dim3(256), 0, st, t);
+    else hipLaunchKernelGGL(flatb_s2w_pack_kernel, dim3(128), dim3(256), 0, st, t);
     BP_CHECK_LAUNCH();
     return BP_OK;
   }
@@ -685,12 +1007,15 @@ static int64_t fb_tiles(const bp_view* out) {
 // tiles of the stride-2 instances: coarse-grid tiles of the gathered (T form) / produced (S form) tensor
 static int64_t f2_tiles(int kind, const bp_view* in, const bp_view* out, int* tx, int* ty) {
   if (kind == 5) { *tx = bp_ceil_div(in->w, FT_TW); *ty = bp_ceil_div(in->h, FT_TH); }
-  else { *tx = bp_ceil_div(out->w, FS_TW); *ty = bp_ceil_div(out->h, FS_TH); }
+  else if (kind == 6) { *tx = bp_ceil_div(out->w, FS_TW); *ty = bp_ceil_div(out->h, FS_TH); }
+  else if (kind == 7) { *tx = bp_ceil_div(in->w, GT_TW); *ty = bp_ceil_div(in->h, GT_TH); }
+  else { *tx = bp_ceil_div(out->w, GS_TW); *ty = bp_ceil_div(out->h, GS_TH); }
   return (int64_t)*tx * *ty * out->n;
 }
 static bool f2_ok(const FbKind& f, const bp_view* in, const bp_view* out) {
   if (in->dtype != BP_BF16 || out->dtype != BP_BF16 || in->n != out->n || in->c != f.cinp || out->c != f.coutp) return false;
-  if (f.kind == 5 ? (out->h != 2 * in->h || out->w != 2 * in->w) : (in->h != 2 * out->h || in->w != 2 * out->w)) return false;
+  const bool tform = f.kind == 5 || f.kind == 7;
+  if (tform ? (out->h != 2 * in->h || out->w != 2 * in->w) : (in->h != 2 * out->h || in->w != 2 * out->w)) return false;
   if (reinterpret_cast<uintptr_t>(in->ptr) % 16 || reinterpret_cast<uintptr_t>(out->ptr) % 16) return false;
   if (in->cstride % 8 || in->coff % 8) return false;
   const int ov = f.kind == 5 ? 4 : 8;                      // channels per vector store
@@ -740,27 +1065,29 @@ int bp_bf16_flat_run(const ConvGeom& g, const bp_view* in, const PW& pw, const u
       if (!sr->ws || sr->ws_bytes < need || !sr->sums) return BP_EWORKSPACE;
       stat = reinterpret_cast<double*>(sr->ws);
     }
-    if (f.kind == 5) {
+    const dim3 grid((unsigned)rows), block(256);
+#define BP_F2(KERNEL, ARGS, LDS_)                                                                                        \
+    do {                                                                                                               \
+      static const int once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(KERNEL<true>),                  \
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDS_)),      \
+                               (void)hipFuncSetAttribute(reinterpret_cast<const void*>(KERNEL<false>),                 \
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDS_)), 0); \
+      (void)once;                                                                                                      \
+      if (sr) hipLaunchKernelGGL(KERNEL<true>, grid, block, LDS_, st, ARGS);                                           \
+      else hipLaunchKernelGGL(KERNEL<false>, grid, block, LDS_, st, ARGS);                                             \
+    } while (0)
+    if (f.kind == 5 || f.kind == 7) {
       FtArgs t{reinterpret_cast<const u16*>(in->ptr), in->h, in->w, in->cstride, in->coff, out->ptr, out->h, out->w,
                out->cstride, out->coff, packed_flat, pw, tx, ty, in->n, stat, g.cout_g};
-      static const int once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(flatb_t2_kernel<true>),
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)FT_LDS),
-                               (void)hipFuncSetAttribute(reinterpret_cast<const void*>(flatb_t2_kernel<false>),
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)FT_LDS), 0);
-      (void)once;
-      if (sr) hipLaunchKernelGGL(flatb_t2_kernel<true>, dim3((unsigned)rows), dim3(256), FT_LDS, st, t);
-      else hipLaunchKernelGGL(flatb_t2_kernel<false>, dim3((unsigned)rows), dim3(256), FT_LDS, st, t);
+      if (f.kind == 5) BP_F2(flatb_t2_kernel, t, FT_LDS);
+      else BP_F2(flatb_t2w_kernel, t, GT_LDS);
     } else {
       FsArgs t{reinterpret_cast<const u16*>(in->ptr), in->h, in->w, in->cstride, in->coff, out->ptr, out->h, out->w,
                out->cstride, out->coff, packed_flat, pw, tx, ty, in->n, stat, g.cout_g};
-      static const int once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(flatb_s2_kernel<true>),
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)FS_LDS),
-                               (void)hipFuncSetAttribute(reinterpret_cast<const void*>(flatb_s2_kernel<false>),
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)FS_LDS), 0);
-      (void)once;
-      if (sr) hipLaunchKernelGGL(flatb_s2_kernel<true>, dim3((unsigned)rows), dim3(256), FS_LDS, st, t);
-      else hipLaunchKernelGGL(flatb_s2_kernel<false>, dim3((unsigned)rows), dim3(256), FS_LDS, st, t);
+      if (f.kind == 6) BP_F2(flatb_s2_kernel, t, FS_LDS);
+      else BP_F2(flatb_s2w_kernel, t, GS_LDS);
     }
+#undef BP_F2
     BP_CHECK_LAUNCH();
     if (!sr) return BP_OK;
     return bp_stats_rows_finish(stat, rows, g.cout_g, sr, st);
