@@ -72,13 +72,17 @@ __device__ __forceinline__ void wb_load8(const void* base, int64_t off, int cmax
 // sub-block take the rows of a tile in turn and are summed through LDS at the end.  The wide layers use 2 x 2 x 1:
 // a 64 x 64 channel block per workgroup -- every pixel tile is staged (loaded, activated, rounded to bf16) once per
 // FOUR channel-block pairs instead of once per sixteen.
-template <int KHB, int KW, int S, int NTX, int NTY, int WX, int WY, int BH, bool XB, bool YB>
+// WT ("wave per tap row", KHB = 4 = the waves of the workgroup): every wave walks ALL rows of the tile for ONE tap row and
+// the whole channel block -- no cross-wave sum, and a layer whose channels fit one block (32 <-> 64) stages every
+// pixel tile once instead of once per (channel block, tap-row group) = four times.
+template <int KHB, int KW, int S, int NTX, int NTY, int WX, int WY, int BH, bool XB, bool YB, bool WT = false>
 __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(WbArgs a) {
   using Cfg = WbCfg<KHB, KW, S, NTX, NTY, WX, WY, BH>;
   constexpr int CXC = Cfg::CXC, CYC = Cfg::CYC, XR = Cfg::XR, IWq = Cfg::IWq, XT = Cfg::XT, YT = Cfg::YT;
-  constexpr int TAPS = Cfg::TAPS, WK = Cfg::WK;
+  constexpr int TAPS = WT ? KW : Cfg::TAPS, WK = WT ? 1 : Cfg::WK;
   static_assert(BH % WK == 0, "rows are dealt to the waves of a channel sub-block");
-  static_assert(WK == 1 || (WX == 1 && WY == 1), "row-split variants own the whole channel block");
+  static_assert(WT || WK == 1 || (WX == 1 && WY == 1), "row-split variants own the whole channel block");
+  static_assert(!WT || (KHB == 4 && WX == 1 && WY == 1), "one tap row per wave");
   extern __shared__ __attribute__((aligned(16))) u16 smem[];
   u16* xs = smem;
   u16* ys = smem + CXC / 16 * XT;
@@ -86,7 +90,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(WbArgs a) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wx = wave / (WY * WK), wy = (wave / WK) % WY, wk = wave % WK;
+  const int wx = WT ? 0 : wave / (WY * WK), wy = WT ? 0 : (wave / WK) % WY, wk = WT ? 0 : wave % WK;
   const int li = lane & 15, kq = lane >> 4;
 
   // XCD-aware block coordinates (see wt_block_coords in conv_wgrad_tiles.hip)
@@ -141,6 +145,20 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(WbArgs a) {
         const u16* p = ys + (wy * NTY + j) * YT + r * 32 * 16 + trl;
         yf[j] = frag_of(lds_tr(p), lds_tr(p + 16 * 16));
       }
+      if constexpr (WT) {
+#pragma unroll
+        for (int kx = 0; kx < KW; ++kx) {
+          const int toff = (((r * S + wave) * S + kx % S) * IWq + kx / S) * 16;          // (tap row = this wave)
+#pragma unroll
+          for (int i = 0; i < NTX; ++i) {
+            const u16* p = xs + i * XT + toff + trl;
+            const bf8 xf = frag_of(lds_tr(p), lds_tr(p + 16 * 16));
+#pragma unroll
+            for (int j = 0; j < NTY; ++j)
+              acc[kx][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf, yf[j], acc[kx][i][j], 0, 0, 0);
+          }
+        }
+      } else {
 #pragma unroll
       for (int kyl = 0; kyl < KHB; ++kyl)
 #pragma unroll
@@ -155,6 +173,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(WbArgs a) {
               acc[kyl * KW + kx][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf, yf[j], acc[kyl * KW + kx][i][j], 0, 0, 0);
           }
         }
+      }
     }
   };
   // Staging, pipelined form (channel counts that are multiples of 8: 16-byte units).  A thread's units of the NEXT tile
@@ -328,7 +347,23 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(WbArgs a) {
   }
 
   // ---- partial tiles of this split: D[row = 4*kq + r : X channel][col = li : Y channel]
-  if constexpr (WK == 1) {
+  if constexpr (WT) {
+    const int ky = ky0 + wave;
+    if (ky < a.k) {
+#pragma unroll
+      for (int kx = 0; kx < KW; ++kx)
+#pragma unroll
+        for (int i = 0; i < NTX; ++i)
+#pragma unroll
+          for (int j = 0; j < NTY; ++j) {
+            const int cx = cx0 + i * 16 + 4 * kq;
+            const int cy = cy0 + j * 16 + li;
+            const v4f v = acc[kx][i][j];
+            *reinterpret_cast<float4*>(a.ws + ((((int64_t)split * a.k + ky) * a.k + kx) * a.CYP + cy) * a.CXP + cx) =
+                make_float4(v[0], v[1], v[2], v[3]);
+          }
+    }
+  } else if constexpr (WK == 1) {
 #pragma unroll
     for (int kyl = 0; kyl < KHB; ++kyl) {
       const int ky = ky0 + kyl;
@@ -382,7 +417,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(WbArgs a) {
   }
 }
 
-template <int KHB, int KW, int S, int NTX, int NTY, int WX, int WY, int BH>
+template <int KHB, int KW, int S, int NTX, int NTY, int WX, int WY, int BH, bool WT = false>
 int wb_launch(const bp_conv* cv, const bp_view* X, const PW& pwx, const bp_view* Y, const PW& pwy, float* ws,
               size_t ws_bytes, size_t* need, int* nsplit_out, int* cxp, int* cyp, hipStream_t st, bool dry) {
   using Cfg = WbCfg<KHB, KW, S, NTX, NTY, WX, WY, BH>;
@@ -415,10 +450,10 @@ int wb_launch(const bp_conv* cv, const bp_view* X, const PW& pwx, const bp_view*
 #define BP_WB(XB_, YB_)                                                                                             \
   do {                                                                                                              \
     static const hipError_t optin = hipFuncSetAttribute(                                                            \
-        reinterpret_cast<const void*>(&wgrad_bf16_kernel<KHB, KW, S, NTX, NTY, WX, WY, BH, XB_, YB_>),               \
+        reinterpret_cast<const void*>(&wgrad_bf16_kernel<KHB, KW, S, NTX, NTY, WX, WY, BH, XB_, YB_, WT>),           \
         hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);                                                     \
     if (optin != hipSuccess) return BP_ELAUNCH;                                                                     \
-    hipLaunchKernelGGL((wgrad_bf16_kernel<KHB, KW, S, NTX, NTY, WX, WY, BH, XB_, YB_>), grid, dim3(256), Cfg::LDS, st, a); \
+    hipLaunchKernelGGL((wgrad_bf16_kernel<KHB, KW, S, NTX, NTY, WX, WY, BH, XB_, YB_, WT>), grid, dim3(256), Cfg::LDS, st, a); \
   } while (0)
   if (xb && yb) BP_WB(true, true);
   else if (xb) BP_WB(true, false);
@@ -809,6 +844,8 @@ int bp_wgrad_bf16(const bp_conv* cv, const bp_view* X, const PW& pwx, const bp_v
   }
   if (k == 4 && s == 2) {
     if (cx > 32 && cy > 32) BP_WB_(2, 4, 2, 2, 2, 2, 2, 2);          // 64 x 64 channel block, two tap rows per group
+    static const bool no_wt = getenv("BP_BF16_NOWT") != nullptr;
+    if (cx > 16 && cx <= 32 && cy > 32 && cy <= 64 && !no_wt) BP_WB_(4, 4, 2, 2, 4, 1, 1, 4, true);    // 32 <-> 64: wave per tap row
     if (cx > 16 && cy > 16) BP_WB_(2, 4, 2, 2, 2, 1, 1, 4);
     if (cy > 16) BP_WB_(4, 4, 2, 1, 2, 1, 1, 4);
     if (cx > 16) BP_WB_(4, 4, 2, 2, 1, 1, 1, 4);
