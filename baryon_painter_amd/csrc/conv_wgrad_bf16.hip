@@ -847,6 +847,7 @@ int bp_wgrad_bf16(const bp_conv* cv, const bp_view* X, const PW& pwx, const bp_v
     static const bool no_wt = getenv("BP_BF16_NOWT") != nullptr;
     if (cx > 16 && cx <= 32 && cy > 32 && cy <= 64 && !no_wt) BP_WB_(4, 4, 2, 2, 4, 1, 1, 4, true);    // 32 <-> 64: wave per tap row
     if (cx > 16 && cy > 16) BP_WB_(2, 4, 2, 2, 2, 1, 1, 4);
+    if (cy > 16 && cy <= 32 && cx <= 16 && !no_wt) BP_WB_(4, 4, 2, 1, 2, 1, 1, 8, true);     // 16 <-> 32: 0.39 -> 0.34 ms
     if (cy > 16) BP_WB_(4, 4, 2, 1, 2, 1, 1, 4);
     if (cx > 16) BP_WB_(4, 4, 2, 2, 1, 1, 1, 4);
     BP_WB_(4, 4, 2, 1, 1, 1, 1, 4);
