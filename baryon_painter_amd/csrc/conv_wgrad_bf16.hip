@@ -836,7 +836,9 @@ int bp_wgrad_bf16(const bp_conv* cv, const bp_view* X, const PW& pwx, const bp_v
   const int k = cv->k, s = cv->stride, cx = X->c, cy = Y->c;
 #define BP_WB_(...) return wb_launch<__VA_ARGS__>(cv, X, pwx, Y, pwy, ws, ws_bytes, need, nsplit, cxp, cyp, st, dry)
   if (k == 3 && s == 1) {
-    if (cx > 32 && cy > 32) BP_WB_(3, 3, 1, 2, 2, 2, 2, 4);          // 64 x 64 channel block
+    // 64 x 64 channel block, 4 x 32 pixel tiles (8-row tiles need 19 staging registers per thread on top of the 144
+    // accumulators: 128 bytes of scratch, 118 -> 167 us)
+    if (cx > 32 && cy > 32) BP_WB_(3, 3, 1, 2, 2, 2, 2, 4);
     if (cx > 16 && cy > 16) BP_WB_(3, 3, 1, 2, 2, 1, 1, 8);
     if (cy > 16) BP_WB_(3, 3, 1, 1, 2, 1, 1, 8);
     if (cx > 16) BP_WB_(3, 3, 1, 2, 1, 1, 1, 8);

@@ -84,11 +84,13 @@ class SNConv2d(_NoForward, torch.nn.Conv2d):
 
     @torch.no_grad()
     def refresh(self, training):
+        """One power iteration (training) and ``weight = weight_orig / sigma``.  The three mat-vecs are written as
+        broadcast-multiply + reduce (element-wise ATen kernels): no BLAS library is on any path of this package."""
         wm = self.weight_orig.reshape(self.weight_orig.shape[0], -1)
         if training:
-            self.weight_v.copy_(torch.nn.functional.normalize(torch.mv(wm.t(), self.weight_u), dim=0, eps=1e-12))
-            self.weight_u.copy_(torch.nn.functional.normalize(torch.mv(wm, self.weight_v), dim=0, eps=1e-12))
-        self.sigma = torch.dot(self.weight_u, torch.mv(wm, self.weight_v))
+            self.weight_v.copy_(torch.nn.functional.normalize((wm * self.weight_u.unsqueeze(1)).sum(dim=0), dim=0, eps=1e-12))
+            self.weight_u.copy_(torch.nn.functional.normalize((wm * self.weight_v.unsqueeze(0)).sum(dim=1), dim=0, eps=1e-12))
+        self.sigma = (self.weight_u * (wm * self.weight_v.unsqueeze(0)).sum(dim=1)).sum()
         self.weight.copy_(self.weight_orig / self.sigma)
 
     @torch.no_grad()
