@@ -91,6 +91,7 @@ SIGNATURES = {
     "bp_view_to_nchw": (C.c_int, [_VP, _PWP, C.c_int32, _P, _P]),
     "bp_fill": (C.c_int, [_P, C.c_int64, C.c_float, _P]),
     "bp_paint_load": (C.c_int, [_P, C.c_int32, _P, _P, C.c_int32, _VP, _P]),
+    "bp_paint_load2": (C.c_int, [_P, C.c_int32, _P, _P, C.c_int32, _VP, _VP, _P]),
     "bp_paint_store": (C.c_int, [_VP, _PWP, C.c_int32, _P, _P, _P]),
     "bp_philox_normal": (C.c_int, [C.c_uint64, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P]),
     "bp_philox_normal_dev": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P]),

@@ -17,9 +17,11 @@ namespace {
 
 constexpr int RB = 256;
 
+// (out2: an optional second destination of the same pixels -- the generator reads the transformed tile in its
+//  concatenated input as well as the prior network: the double-precision logarithm is taken once, not once per view)
 __global__ __launch_bounds__(RB) void paint_load_kernel(const float* src, int c, const double* sigma_k, const float* aux,
-                                                        int caux, float* out, int out_cs, int out_co, int64_t hw,
-                                                        int64_t total) {
+                                                        int caux, float* out, int out_cs, int out_co, float* out2,
+                                                        int out2_cs, int out2_co, int64_t hw, int64_t total) {
   const int64_t i = (int64_t)blockIdx.x * RB + threadIdx.x;
   if (i >= total) return;
   const int ct = c + caux;
@@ -35,6 +37,7 @@ __global__ __launch_bounds__(RB) void paint_load_kernel(const float* src, int c,
     v = aux[n * caux + (ch - c)];
   }
   out[p * out_cs + out_co + ch] = v;
+  if (out2) out2[p * out2_cs + out2_co + ch] = v;
 }
 
 __device__ __forceinline__ float softplus_f(float x) { return x > 20.f ? x : log1pf(expf(x)); }
@@ -111,7 +114,19 @@ int bp_paint_load(const float* raw_nchw, int32_t c, const double* sigma_k, const
     return BP_EINVAL;
   const int64_t hw = (int64_t)out->h * out->w, total = (int64_t)out->n * hw * (c + caux);
   hipLaunchKernelGGL(paint_load_kernel, dim3(nblocks(total)), dim3(RB), 0, bp_stream(stream), raw_nchw, c, sigma_k, aux,
-                     caux, out->ptr, out->cstride, out->coff, hw, total);
+                     caux, out->ptr, out->cstride, out->coff, (float*)nullptr, 0, 0, hw, total);
+  BP_CHECK_LAUNCH();
+  return BP_OK;
+}
+
+int bp_paint_load2(const float* raw_nchw, int32_t c, const double* sigma_k, const float* aux, int32_t caux,
+                   const bp_view* out, const bp_view* out2, void* stream) {
+  if (!raw_nchw || !sigma_k || !bp_view_ok(out) || !bp_view_ok(out2) || c <= 0 || caux < 0 || out->c != c + caux ||
+      out2->c != out->c || out2->n != out->n || out2->h != out->h || out2->w != out->w || (caux > 0 && !aux))
+    return BP_EINVAL;
+  const int64_t hw = (int64_t)out->h * out->w, total = (int64_t)out->n * hw * (c + caux);
+  hipLaunchKernelGGL(paint_load_kernel, dim3(nblocks(total)), dim3(RB), 0, bp_stream(stream), raw_nchw, c, sigma_k, aux,
+                     caux, out->ptr, out->cstride, out->coff, out2->ptr, out2->cstride, out2->coff, hw, total);
   BP_CHECK_LAUNCH();
   return BP_OK;
 }

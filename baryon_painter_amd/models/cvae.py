@@ -843,9 +843,8 @@ class CVAE(torch.nn.Module):
             lib, sm = self._lib, _stream()
             plan.pack_all()
             auxp = L.ptr(sl["aux"][lo:lo + h]) if self.use_aux_label else None
-            for view in (plan.y2.view, plan.hy_slot.view):
-                L.check(lib.bp_paint_load(L.ptr(sl["raw"][lo:lo + h]), cy, L.ptr(sl["xf_in"][lo:lo + h]), auxp,
-                                          plan.caux, C.byref(view), sm), "paint load")
+            L.check(lib.bp_paint_load2(L.ptr(sl["raw"][lo:lo + h]), cy, L.ptr(sl["xf_in"][lo:lo + h]), auxp, plan.caux,
+                                       C.byref(plan.y2.view), C.byref(plan.hy_slot.view), sm), "paint load")
             plan.run_prior(False)
             eps = st["eps"][:, lo:lo + h]
             L.check(lib.bp_philox_normal_dev(L.ptr(sl["seed"]), L.ptr(sl["tile_ids"][lo:lo + h]), h, 1, eps.shape[-1],

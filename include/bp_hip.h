@@ -255,6 +255,10 @@ int bp_fill(float* dst, int64_t n, float value, void* stream);
  *                   NCHW (= bp_view_to_nchw + inverse transform; softplus as in bp_view_to_nchw) */
 int bp_paint_load(const float* raw_nchw, int32_t c, const double* sigma_k, const float* aux, int32_t caux,
                   const bp_view* out, void* stream);
+/* bp_paint_load into TWO views of the same shape at once (cvae.py:87-88 and :104-105 merge the same y with the aux
+ * label for the prior network and for the generator's concatenated input): one evaluation of the transform. */
+int bp_paint_load2(const float* raw_nchw, int32_t c, const double* sigma_k, const float* aux, int32_t caux,
+                   const bp_view* out, const bp_view* out2, void* stream);
 int bp_paint_store(const bp_view* src, const bp_pointwise* pw, int32_t softplus, const double* k_sigma,
                    float* dst_nchw, void* stream);
 /* eps (L, n, per_tile) standard normal for the sampler of cvae.py:64-65 from Philox4x32-10 keyed on `seed`, counter
