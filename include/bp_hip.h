@@ -110,7 +110,10 @@ int bp_conv_pack_jobs(const void* jobs_dev, const int64_t* first_block_dev, int3
 /* bf16 matrix-core path (configs[3]): impl == BP_IMPL_BF16 in the three calls below takes a bf16 packed image
  * (bp_conv_bf16_pack, bp_conv_bf16_packed_elems 2-byte elements) and views of either element type on both sides;
  * products are bf16 x bf16, accumulation and the weight gradient are fp32.  bp_conv_bf16_supported says whether
- * the kernels take a layer / direction with the given views (NULL: any). */
+ * the kernels take a layer / direction with the given views (NULL: any).  The packed image is opaque: for the thin
+ * full-resolution layers (unit-stride k7 / k5 heads and stem, stride-2 k4 16<->32 and 32<->64) it carries a second,
+ * flattened-K weight image behind the generic one (csrc/conv_bf16_flat.hip), and the run picks the kernel by the
+ * views it is given -- always size the buffer with bp_conv_bf16_packed_elems. */
 int64_t bp_conv_bf16_packed_elems(const bp_conv* cv, int dir);
 int bp_conv_bf16_pack(const bp_conv* cv, int dir, const float* w_torch, void* packed, void* stream);
 int bp_conv_bf16_supported(const bp_conv* cv, int dir, const bp_view* in, const bp_view* out);
