@@ -12,6 +12,7 @@ LIB_PATH = os.path.join(_HERE, "libbp_hip.so")
 BP_OK = 0
 IMPL_AUTO, IMPL_DIRECT, IMPL_MFMA, IMPL_BF16 = 0, 1, 2, 3
 IMPL_SHARED = 0x100
+IMPL_DEFER = 0x200
 PACK_FWD, PACK_BWD = 0, 1
 F32, BF16 = 0, 1
 
@@ -74,6 +75,8 @@ SIGNATURES = {
     "bp_conv_backward_data_stats": (C.c_int, [_CP, _VP, _P, _VP, _VP, _PWP, _P, _P, C.c_size_t, _P]),
     "bp_conv_backward_weight_workspace": (C.c_size_t, [_CP, _VP, _VP]),
     "bp_conv_backward_weight": (C.c_int, [_CP, _VP, _PWP, _VP, _P, _P, _P, C.c_size_t, C.c_int, _P]),
+    "bp_wgrad_defer_begin": (C.c_int, []),
+    "bp_wgrad_defer_flush": (C.c_int, [C.c_int, _P]),
     "bp_channel_sums_workspace": (C.c_size_t, [_VP]),
     "bp_channel_sums": (C.c_int, [_VP, _P, _P, C.c_size_t, _P]),
     "bp_bn_finalize": (C.c_int, [_P, C.c_double, C.c_int32, _P, _P, C.c_float, C.c_float, _P, _P, _P,

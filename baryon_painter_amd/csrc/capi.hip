@@ -51,6 +51,14 @@ size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 }  // namespace
 
+void bp_wgrad_private_ws(bool on);
+struct WgradPrivateWs {
+  explicit WgradPrivateWs(bool on) { bp_wgrad_private_ws(on); }
+  ~WgradPrivateWs() { bp_wgrad_private_ws(false); }
+};
+int bp_wgrad_defer_begin_impl();
+int bp_wgrad_defer_flush_impl(hipStream_t st, int end);
+
 extern "C" {
 
 int bp_version(void) { return 100; }
@@ -218,7 +226,8 @@ int bp_conv_backward_weight(const bp_conv* cv, const bp_view* x, const bp_pointw
                             float* dw_torch, float* dbias, void* workspace, size_t workspace_bytes, int impl,
                             void* stream) {
   const bool shared = (impl & BP_IMPL_SHARED) != 0;
-  impl &= ~BP_IMPL_SHARED;
+  const WgradPrivateWs priv((impl & BP_IMPL_DEFER) != 0);      // (this call's reduction may wait for the flush)
+  impl &= ~(BP_IMPL_SHARED | BP_IMPL_DEFER);
   if (!conv_ok(cv) || !shapes_ok(cv, x, dy, impl == BP_IMPL_BF16) || !dw_torch) return BP_EINVAL;
   const bp_view* X = cv->transposed ? dy : x;
   const bp_view* Y = cv->transposed ? x : dy;
@@ -256,5 +265,8 @@ int bp_conv_backward_weight(const bp_conv* cv, const bp_view* x, const bp_pointw
   }
   return rc;
 }
+
+int bp_wgrad_defer_begin(void) { return bp_wgrad_defer_begin_impl(); }
+int bp_wgrad_defer_flush(int end, void* stream) { return bp_wgrad_defer_flush_impl(bp_stream(stream), end); }
 
 }  // extern "C"

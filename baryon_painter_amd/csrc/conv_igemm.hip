@@ -1488,7 +1488,15 @@ int bp_flat_h7_pack(const ConvGeom& g, const WeightMap& wm, const float* w_torch
 int bp_flat_h7_run(const bp_view* in, const PW& pw, const float* packed, const float* bias, const bp_view* out,
                    hipStream_t st);
 
+// ... and the k8 stride-4 layer 8 -> 16 of the recognition / prior networks, forward and data gradient (conv_enc.hip)
+bool bp_enc_ok(const ConvGeom& g);
+int64_t bp_enc_packed_floats();
+int bp_enc_pack(const ConvGeom& g, const WeightMap& wm, const float* w_torch, float* packed, hipStream_t st);
+int bp_enc_run(const ConvGeom& g, const bp_view* in, const PW& pw, const float* packed, const float* bias,
+               const bp_view* out, hipStream_t st);
+
 int bp_igemm_kernel_id(const ConvGeom& g) {
+  if (bp_enc_ok(g)) return g.gather_transposed ? 770000 : 760000;
   if (bp_stem_ok(g)) return 700000;
   if (bp_flat_ok(g)) return 710000;
   if (bp_flat_t4_ok(g) && !bp_flat_t64_ok(g)) return 720000;
@@ -1502,6 +1510,7 @@ int bp_igemm_kernel_id(const ConvGeom& g) {
 }
 
 int64_t bp_igemm_packed_floats(const ConvGeom& g) {
+  if (bp_enc_ok(g)) return bp_enc_packed_floats();
   if (bp_stem_ok(g)) return bp_stem_packed_floats();
   if (bp_flat_ok(g)) return bp_flat_packed_floats();
   if (bp_flat_t4_ok(g) && !bp_flat_t64_ok(g)) return bp_flat_t4_packed_floats();
@@ -1528,6 +1537,7 @@ static bool igemm_pack_args(const ConvGeom& g, const WeightMap& wm, const float*
 
 int bp_igemm_pack(const ConvGeom& g, const WeightMap& wm, const float* w_torch, float* packed,
                   hipStream_t st) {
+  if (bp_enc_ok(g)) return bp_enc_pack(g, wm, w_torch, packed, st);
   if (bp_stem_ok(g)) return bp_stem_pack(wm, w_torch, packed, st);
   if (bp_flat_ok(g)) return bp_flat_pack(g, wm, w_torch, packed, st);
   if (bp_flat_t4_ok(g) && !bp_flat_t64_ok(g)) return bp_flat_t4_pack(wm, w_torch, packed, st);
@@ -1547,7 +1557,7 @@ size_t bp_igemm_pack_job_bytes() { return sizeof(PackArgs); }
 
 int bp_igemm_pack_job(const ConvGeom& g, const WeightMap& wm, const float* w_torch, float* packed, void* job,
                       int64_t* nblocks) {
-  if (bp_stem_ok(g) || bp_flat_ok(g) || bp_flat_t4_ok(g) || bp_flat_g4_ok(g) || bp_flat_t64_ok(g) || bp_flat_h7_ok(g) || bp_small_ok(g)) return BP_EUNSUPPORTED;       // (their own tiny pack kernels: packed by bp_conv_pack)
+  if (bp_enc_ok(g) || bp_stem_ok(g) || bp_flat_ok(g) || bp_flat_t4_ok(g) || bp_flat_g4_ok(g) || bp_flat_t64_ok(g) || bp_flat_h7_ok(g) || bp_small_ok(g)) return BP_EUNSUPPORTED;       // (their own tiny pack kernels: packed by bp_conv_pack)
   PackArgs a;
   if (!igemm_pack_args(g, wm, w_torch, packed, a)) return BP_EUNSUPPORTED;
   *reinterpret_cast<PackArgs*>(job) = a;
@@ -1641,6 +1651,7 @@ int bp_stats_rows_finish(double* ws, int64_t rows, int C, const IgemmStatsReq* s
 }
 
 size_t bp_igemm_stats_workspace(const ConvGeom& g, const bp_view* in, const bp_view* out, int mode) {
+  if (bp_enc_ok(g)) return 0;
   if (bp_stem_ok(g)) return mode == 1 ? bp_stem_stats_workspace(out) : 0;
   if (bp_flat_ok(g)) return bp_flat_stats_workspace(out, mode);
   if (bp_flat_t4_ok(g) && !bp_flat_t64_ok(g)) return mode == 1 ? bp_flat_t4_stats_workspace(out) : 0;
@@ -1658,6 +1669,7 @@ size_t bp_igemm_stats_workspace(const ConvGeom& g, const bp_view* in, const bp_v
 
 int bp_igemm_run(const ConvGeom& g, const bp_view* in, const PW& pw, const float* packed,
                  const float* bias, const bp_view* out, hipStream_t st, const IgemmStatsReq* sr) {
+  if (bp_enc_ok(g)) return sr ? BP_EUNSUPPORTED : bp_enc_run(g, in, pw, packed, bias, out, st);
   if (bp_stem_ok(g)) return bp_stem_run(in, pw, packed, bias, out, st, sr);
   if (bp_flat_ok(g)) return bp_flat_run(g, in, pw, packed, bias, out, st, sr);
   if (bp_flat_t4_ok(g) && !bp_flat_t64_ok(g)) return bp_flat_t4_run(in, pw, packed, bias, out, st, sr);

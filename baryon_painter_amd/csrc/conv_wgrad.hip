@@ -11,6 +11,7 @@
 // kernel adds them in a fixed order, so the gradient is bitwise reproducible (no float atomics).
 #include "common.hpp"
 #include <cstdlib>
+#include <vector>
 
 namespace {
 
@@ -141,14 +142,13 @@ struct WreduceArgs {
 // WR_GRP: split groups per block (threads = 64 outputs x WR_GRP): 4 for the few-way splits of the fp32 kernels, 16 for
 // the 128 ... 512-way splits of the bf16 and thin-layer kernels
 template <int WR_GRP>
-__global__ __launch_bounds__(64 * WR_GRP) void wgrad_reduce_kernel(WreduceArgs a) {
+__device__ __forceinline__ void wgrad_reduce_block(const WreduceArgs& a, int64_t block, double (*sh)[64]) {
   // 64 consecutive outputs (workspace order [ky][kx][cy][cx], cx fastest: coalesced) x WR_GRP groups of splits per
   // block: a thread adds every WR_GRP-th split (two chains, loads independent of each other), the groups are then
   // added in a fixed order -> bitwise reproducible.  (With four groups a 512-way split is 128 trips per thread:
   // latency-bound, 30 us for 25 MB; sixteen cut the chain to 32.)
-  __shared__ double sh[WR_GRP][64];
   const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
-  const int64_t i = (int64_t)blockIdx.x * 64 + lane;
+  const int64_t i = block * 64 + lane;
   const int64_t total = (int64_t)a.k * a.k * a.cy * a.cx;
   double s = 0.0;
   int cx = 0, cy = 0, t = 0;
@@ -175,6 +175,32 @@ __global__ __launch_bounds__(64 * WR_GRP) void wgrad_reduce_kernel(WreduceArgs a
     for (int g = 1; g < WR_GRP; ++g) r += sh[g][lane];
     a.dst[((int64_t)(a.cy_off + cy) * a.cx_total + a.cx_off + cx) * a.k * a.k + t] = (float)r;
   }
+}
+
+template <int WR_GRP>
+__global__ __launch_bounds__(64 * WR_GRP) void wgrad_reduce_kernel(WreduceArgs a) {
+  __shared__ double sh[WR_GRP][64];
+  wgrad_reduce_block<WR_GRP>(a, blockIdx.x, sh);
+}
+
+// Deferred reductions (bp_wgrad_defer_begin / _flush): the reductions of many layers in one launch.  A block finds its
+// job by scanning the table of first blocks (a few dozen entries, scalar loads); each job is reduced exactly as its own
+// launch would reduce it, so deferring changes no bit of dW.
+constexpr int WR_BATCH = 40;
+struct WreduceBatch {
+  int njobs;
+  int first[WR_BATCH + 1];
+  WreduceArgs job[WR_BATCH];
+};
+static_assert(sizeof(WreduceBatch) <= 4096, "kernel argument block");
+
+template <int WR_GRP>
+__global__ __launch_bounds__(64 * WR_GRP) void wgrad_reduce_batch_kernel(WreduceBatch b) {
+  __shared__ double sh[WR_GRP][64];
+  const int blk = blockIdx.x;
+  int j = 0;
+  while (j + 1 < b.njobs && blk >= b.first[j + 1]) ++j;
+  wgrad_reduce_block<WR_GRP>(b.job[j], blk - b.first[j], sh);
 }
 
 struct WgradPlan {
@@ -218,24 +244,80 @@ int bp_wgrad_tiles(const bp_conv* cv, const bp_view* X, const PW& pwx, const bp_
 int bp_wgrad_small(const bp_conv* cv, const bp_view* X, const PW& pwx, const bp_view* Y, const PW& pwy, float* ws,
                    size_t ws_bytes, size_t* need, int* nsplit, int* cxp, int* cyp, hipStream_t st, bool dry);
 
-// tap-packed few-channel kernel first, then the tap-blocked one; BP_EUNSUPPORTED -> generic kernel
+int bp_wgrad_thin(const bp_conv* cv, const bp_view* X, const PW& pwx, const bp_view* Y, const PW& pwy, float* ws,
+                  size_t ws_bytes, size_t* need, int* nsplit, int* cxp, int* cyp, hipStream_t st, bool dry);
+
+// one-channel tails (conv_wgrad_thin.hip), the tap-packed few-channel kernel, then the tap-blocked one;
+// BP_EUNSUPPORTED -> generic kernel
 static int wgrad_fast(const bp_conv* cv, const bp_view* X, const PW& pwx, const bp_view* Y, const PW& pwy, float* ws,
                       size_t ws_bytes, size_t* need, int* nsplit, int* cxp, int* cyp, hipStream_t st, bool dry) {
-  int rc = bp_wgrad_small(cv, X, pwx, Y, pwy, ws, ws_bytes, need, nsplit, cxp, cyp, st, dry);
+  int rc = bp_wgrad_thin(cv, X, pwx, Y, pwy, ws, ws_bytes, need, nsplit, cxp, cyp, st, dry);
+  if (rc == BP_EUNSUPPORTED) rc = bp_wgrad_small(cv, X, pwx, Y, pwy, ws, ws_bytes, need, nsplit, cxp, cyp, st, dry);
   if (rc == BP_EUNSUPPORTED) rc = bp_wgrad_tiles(cv, X, pwx, Y, pwy, ws, ws_bytes, need, nsplit, cxp, cyp, st, dry);
   return rc;
 }
 
+// Per host thread: between bp_wgrad_defer_begin() and bp_wgrad_defer_flush() the reductions of calls flagged
+// BP_IMPL_DEFER are collected, not launched: the flag is the caller's promise that the call's workspace is its own
+// until the flush (cvae._Plan: one per fp32 layer).
+struct DeferState { bool on = false, private_ws = false; std::vector<WreduceArgs> jobs; };
+static thread_local DeferState t_defer;
+
 static int wgrad_reduce(const float* ws, float* dst, int k, int cx, int cy, int CXP, int CYP, int nsplit,
-                        hipStream_t st, int cx_total = -1, int cx_off = 0, int cy_off = 0) {
+                        hipStream_t st, int cx_total = -1, int cx_off = 0, int cy_off = 0, bool may_defer = true) {
   WreduceArgs r{};
   r.ws = ws; r.dst = dst; r.k = k; r.cx = cx; r.cy = cy; r.CXP = CXP; r.CYP = CYP; r.nsplit = nsplit;
   r.cx_total = cx_total < 0 ? cx : cx_total; r.cx_off = cx_off; r.cy_off = cy_off;
+  if (t_defer.on && t_defer.private_ws && may_defer) {
+    t_defer.jobs.push_back(r);
+    return BP_OK;
+  }
   const int64_t total = (int64_t)cy * cx * k * k;
   if (r.nsplit > 64) hipLaunchKernelGGL(wgrad_reduce_kernel<16>, dim3((unsigned)((total + 63) / 64)), dim3(1024), 0, st, r);
   else hipLaunchKernelGGL(wgrad_reduce_kernel<4>, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, st, r);
   BP_CHECK_LAUNCH();
   return BP_OK;
+}
+
+template <int WR_GRP>
+static int wgrad_reduce_flush_class(const std::vector<WreduceArgs>& jobs, bool wide, hipStream_t st) {
+  WreduceBatch b{};
+  auto launch = [&]() {
+    if (b.njobs == 0) return;
+    hipLaunchKernelGGL(wgrad_reduce_batch_kernel<WR_GRP>, dim3((unsigned)b.first[b.njobs]), dim3(64 * WR_GRP), 0, st, b);
+    b = WreduceBatch{};
+  };
+  for (const WreduceArgs& r : jobs) {
+    if ((r.nsplit > 64) != wide) continue;
+    const int64_t nb = ((int64_t)r.cy * r.cx * r.k * r.k + 63) / 64;
+    if (b.njobs == WR_BATCH || b.first[b.njobs] + nb > 0x3fffffff) launch();
+    b.job[b.njobs] = r;
+    b.first[b.njobs + 1] = b.first[b.njobs] + (int)nb;
+    ++b.njobs;
+  }
+  launch();
+  BP_CHECK_LAUNCH();
+  return BP_OK;
+}
+
+void bp_wgrad_private_ws(bool on) { t_defer.private_ws = on; }
+
+int bp_wgrad_defer_begin_impl() {
+  t_defer.on = true;
+  t_defer.jobs.clear();
+  return BP_OK;
+}
+
+int bp_wgrad_defer_flush_impl(hipStream_t st, int end) {
+  int rc = BP_OK;
+  if (end < 0) t_defer.jobs.clear();          // abandon
+  if (!t_defer.jobs.empty()) {
+    rc = wgrad_reduce_flush_class<16>(t_defer.jobs, true, st);
+    if (rc == BP_OK) rc = wgrad_reduce_flush_class<4>(t_defer.jobs, false, st);
+    t_defer.jobs.clear();
+  }
+  if (end) t_defer.on = false;
+  return rc;
 }
 
 // One or two channels on one side and many on the other (the k9 stem / head of the CGAN generator): the tap-packed
@@ -274,7 +356,8 @@ static int wgrad_chunked(const bp_conv* cv, const bp_view* X, const PW& pwx, con
     if (rc != BP_OK) return rc;
     if (need > need_max) need_max = need;
     if (!dry) {
-      const int rr = wgrad_reduce(ws, dst, cv->k, Xc->c, Yc->c, cxp, cyp, ns, st, X->c, on_x ? c0 : 0, on_x ? 0 : c0);
+      const int rr = wgrad_reduce(ws, dst, cv->k, Xc->c, Yc->c, cxp, cyp, ns, st, X->c, on_x ? c0 : 0, on_x ? 0 : c0,
+                                  /*may_defer=*/false);      // (the chunks share one workspace)
       if (rr != BP_OK) return rr;
     }
   }

@@ -16,6 +16,7 @@
 // Workgroup = 4 waves splitting the k-steps of a BH x 32 pixel tile; pixel tiles are split over
 // workgroups; partials go to the workspace layout of conv_wgrad.hip and are reduced there.
 #include "common.hpp"
+#include <cstdlib>
 
 namespace {
 
@@ -29,6 +30,7 @@ struct WsArgs {
   float* ws;
   int nsplit, tiles_x, tiles_y;
   int xvec, yvec;
+  int dbg;
 };
 
 template <int K, int S, int CXS, int CYS, int BH>
@@ -91,7 +93,7 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(WsArgs a) {
     const int qy0 = ty_ * BH, qx0 = tx_ * 32;
     __syncthreads();
     // ---- stage X rows [qy0-p, qy0-p+XR) x cols [qx0-p, qx0-p+XW), channels padded to CXS
-    {
+    if (!(a.dbg & 2)) {
       const float* Xn = a.X + (int64_t)n * a.xh * a.xw * a.xcs + a.xco;
       if (CXS >= 4 && a.xvec) {
         constexpr int C4 = CXS >= 4 ? CXS / 4 : 1;
@@ -163,7 +165,7 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(WsArgs a) {
       }
     }
     // ---- stage Y rows [qy0, qy0+BH) x cols [qx0, qx0+32)
-    {
+    if (!(a.dbg & 2)) {
       const float* Yn = a.Y + (int64_t)n * a.yh * a.yw * a.ycs + a.yco;
       if (CYS >= 4 && a.yvec) {
         constexpr int C4 = CYS >= 4 ? CYS / 4 : 1;
@@ -226,6 +228,7 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(WsArgs a) {
     }
     __syncthreads();
     // ---- k-steps: row r' (0..RS-1), pixel group g (0..7); this wave takes every 4th
+    if (!(a.dbg & 1))
     for (int s = wk; s < RS * 8; s += 4) {
       const int r = s >> 3, g = s & 7;
       const float bf = ys[((PADR + r) * YWS + 4 * g) * CYS + b_lane];
@@ -276,7 +279,10 @@ int launch(const bp_view* X, const PW& pwx, const bp_view* Y, const PW& pwy, int
   a.tiles_x = bp_ceil_div(Y->w, 32);
   a.tiles_y = bp_ceil_div(Y->h, BH);
   int64_t ntiles = (int64_t)Y->n * a.tiles_x * a.tiles_y;
-  int64_t ns = ntiles < 1024 ? ntiles : 1024;          // ~4 workgroups per CU
+  static const int dbg = getenv("BP_WS_DEBUG") ? atoi(getenv("BP_WS_DEBUG")) : 0;
+  static const int cap = getenv("BP_WS_NSPLIT") ? atoi(getenv("BP_WS_NSPLIT")) : 1024;
+  a.dbg = dbg;
+  int64_t ns = ntiles < cap ? ntiles : cap;          // ~4 workgroups per CU
   a.nsplit = (int)ns;
   *need = (size_t)a.nsplit * K * K * CYS * CXS * sizeof(float);
   *nsplit = a.nsplit; *cxp = CXS; *cyp = CYS;

@@ -154,6 +154,18 @@ class _Plan:
         # Weight gradients on a second stream: they depend only on a layer's d_raw and its input, not on the
         # chain act-backward -> data gradient -> act-backward of the layers below, so their MFMA work can run
         # beside that chain's HBM-bound passes.  They get their own workspace.
+        # Split-K reductions of the weight gradients: recorded during the backward pass and launched together at its
+        # end (bp_wgrad_defer_*: two launches instead of ~30 latency-bound ones).  Such a layer keeps its partial sums
+        # until the flush, in a workspace of its own.  fp32 layers only: the 128 ... 512-way splits of the bf16 kernels
+        # are cheaper reduced at once, out of L2 (measured: deferring them costs the bf16 step 0.15 ms).
+        self.marks = [] if os.environ.get("BP_PHASE_EVENTS") == "1" else None
+        self.deferring = False
+        self.defer_reduce = with_grad and os.environ.get("BP_DEFER_REDUCE", "1") != "0"
+        if self.defer_reduce:
+            for u in self._flat([u for us in self.q_units for u in us] + list(self.p_units)
+                                + [u for us in self.g_units for u in us] + list(self.mu_units) + list(self.var_units)):
+                if isinstance(u, ConvUnit) and getattr(u, "_wgrad_ws_bytes", 0) > 0 and not u.bf16:
+                    u.ws_own = torch.empty(u._wgrad_ws_bytes // 8 + 32, device=dev, dtype=torch.float64)
         self.side = self._side_stream = None
         if with_grad and os.environ.get("BP_SIDE_WGRAD", "1") != "0":
             self.side = self._side_stream = torch.cuda.Stream(device=dev, priority=int(os.environ.get("BP_SIDE_PRIORITY", "0")))
@@ -356,7 +368,10 @@ class _Plan:
                                       L.ptr(self.ws), self.ws_bytes, st), "latent forward")
 
     def run_generator(self, training):
-        for us in self.g_units:
+        for i, us in enumerate(self.g_units):
+            if i == 1 and getattr(self, "_own_packed", None) is not None:
+                torch.cuda.current_stream(self.device).wait_event(self._own_packed)    # graph.PackBatch: bf16 images
+                self._own_packed = None
             for u in us:
                 u.forward(training)
         for u in self.mu_units:
@@ -364,9 +379,18 @@ class _Plan:
         for u in self.var_units:
             u.forward(training)
 
+    def mark(self, name):
+        """Phase mark on the main stream (BP_PHASE_EVENTS=1; tools/phase_times.py): a timed event in ``self.marks``."""
+        if self.marks is not None:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record(torch.cuda.current_stream(self.device))
+            self.marks.append((name, ev))
+
     def forward_train(self, x, y, aux, eps, training=True):
         m = self.model
+        self.mark("step")
         self.load_inputs(y, aux, x)
+        self.mark("inputs+packs")
         if self.levels is not None and training:
             self._run_levels(self.levels, lambda u: u.forward_steps(training))
         elif self.branch is None:
@@ -390,8 +414,11 @@ class _Plan:
             for u in uo:
                 u.forward(training)
             main.wait_stream(sp)                                    # the KL term reads the prior
+        self.mark("encoders fwd")
         self.run_latent(eps, use_q=True)
+        self.mark("latent fwd")
         self.run_generator(training)
+        self.mark("generator fwd")
         self.ll.alpha_var = float(m.alpha_var)
         self.ll.beta_kl = float(m.beta_KL)
         lib, st = self.lib, _stream()
@@ -399,9 +426,33 @@ class _Plan:
                                       None if self.var_head is None else C.byref(self.var_head.view),
                                       L.ptr(self.kl_sum), L.ptr(self.x_mu), L.ptr(self.x_log_var),
                                       L.ptr(self.stats), L.ptr(self.ws), self.ws_bytes, st), "log-likelihood")
+        self.mark("loss fwd")
 
     def backward(self, seed, grads):
         """d(seed*ELBO)/d(parameters) into ``grads`` (id(param) -> tensor)."""
+        if self.defer_reduce and not getattr(self, "skip_wgrad", False):
+            L.check(self.lib.bp_wgrad_defer_begin(), "defer weight-gradient reductions")
+            self.deferring = True
+        try:
+            self._backward(seed, grads)
+        finally:
+            if self.deferring:          # (an exception above: drop what was recorded, stop deferring)
+                self.deferring = False
+                self.lib.bp_wgrad_defer_flush(-1, None)
+
+    def _flush_reductions(self, end):
+        """Launch the recorded split-K reductions behind the weight-gradient kernels (their stream)."""
+        if not self.deferring:
+            return
+        if self.side is not None:
+            with torch.cuda.stream(self.side):
+                L.check(self.lib.bp_wgrad_defer_flush(1 if end else 0, _stream()), "weight-gradient reductions")
+        else:
+            L.check(self.lib.bp_wgrad_defer_flush(1 if end else 0, _stream()), "weight-gradient reductions")
+        if end:
+            self.deferring = False
+
+    def _backward(self, seed, grads):
         lib, st = self.lib, _stream()
         self.seed.copy_(seed.reshape(1))
         self.mu_head.ensure_grad()
@@ -412,11 +463,14 @@ class _Plan:
                                        L.ptr(self.seed), C.byref(self.mu_head.grad),
                                        None if self.var_head is None else C.byref(self.var_head.grad), st),
                 "log-likelihood backward")
+        self.mark("loss bwd")
         for us in (self.var_units, self.mu_units):
             for u in reversed(us):
                 u.backward(grads)
+        self.mark("heads bwd")
         for u in reversed(self.g_units[1]):              # generator trunk p_y_z_in
             u.backward(grads)
+        self.mark("trunk bwd")
         early = self._reduce_trunk_gradients()
         for u in reversed(self.g_units[0]):              # p_z_in
             u.backward(grads)
@@ -450,8 +504,11 @@ class _Plan:
             for u in reversed(ux):
                 u.backward(grads)
             main.wait_stream(sy); main.wait_stream(sp)
+        self.mark("p_z_in + latent + encoders bwd")
+        self._flush_reductions(end=True)
         if self.side is not None:
             torch.cuda.current_stream(self.device).wait_stream(self.side)    # join: every weight gradient is written
+        self.mark("join weight gradients")
         sync, flat = self.model.sync, self.model._flat_grads
         if sync is not None:
             if early is None:
@@ -472,6 +529,7 @@ class _Plan:
                 or os.environ.get("BP_EARLY_ALLREDUCE", "0") != "1":
             return None
         main = torch.cuda.current_stream(self.device)
+        self._flush_reductions(end=False)    # the trunk's weight gradients must be complete
         self.side.wait_stream(main)          # batch-norm / PReLU parameter gradients are written on the main stream
         with torch.cuda.stream(self.side):
             sync.all_reduce_mean(self.model._flat_grads[sl[0]:sl[1]])

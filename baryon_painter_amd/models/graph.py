@@ -373,6 +373,7 @@ class ConvUnit:
                      "packed": torch.zeros(n_bwd, device=dev, dtype=torch.bfloat16 if self.bf16 else torch.float32)}
         self.packed_bwd = None
 
+    ws_own = None       # this layer's own split-K workspace when the plan defers the reductions (cvae._Plan)
     ws_name = "ws"      # which of the plan's workspaces this unit's reductions use (branches that run on
                         # their own stream get their own: cvae._Plan)
 
@@ -527,8 +528,9 @@ class ConvUnit:
         lib = self.plan.lib
         self.out.ensure_grad()
         self.plan.need_ws(lib.bp_act_backward_workspace(C.byref(self.out.view)))
-        self.plan.need_ws(lib.bp_conv_backward_weight_workspace(C.byref(self.cv), C.byref(self.inp.view),
-                                                                C.byref(self.out.view)))
+        self._wgrad_ws_bytes = int(lib.bp_conv_backward_weight_workspace(C.byref(self.cv), C.byref(self.inp.view),
+                                                                         C.byref(self.out.view)))
+        self.plan.need_ws(self._wgrad_ws_bytes)
         self.dx = self.inp.claim_grad() if self.need_dgrad else None
         if self.dx is not None and self._sub is None and EPILOGUE_BWD and not self.bf16 and self.inp.dt == L.F32 \
                 and (_BWD_KERNEL_IDS is None
@@ -640,10 +642,14 @@ class ConvUnit:
 
         def wgrad(ws):
             t0 = plan.prof_begin()
+            nbytes, flags = plan.ws_bytes, (L.IMPL_SHARED if side is not None else 0)
+            if self.ws_own is not None and getattr(plan, "deferring", False):
+                ws, nbytes = self.ws_own, self.ws_own.numel() * 8      # (its reduction waits for the plan's flush)
+                flags |= L.IMPL_DEFER
             L.check(lib.bp_conv_backward_weight(C.byref(self.cv), C.byref(self.inp.view), self.inp.pw_struct(),
                                                 C.byref(g), L.ptr(grads[id(hold.weight)]), L.ptr(dbias),
-                                                L.ptr(ws), plan.ws_bytes,
-                                                self._impl("wgrad") | (L.IMPL_SHARED if side is not None else 0), _stream()),
+                                                L.ptr(ws), nbytes,
+                                                self._impl("wgrad") | flags, _stream()),
                     f"{self.name} backward_weight")
             plan.prof_end(t0, self, "backward_weight")
 
@@ -722,9 +728,23 @@ class PackBatch:
         if storage != self._storage:
             self._build()
             self._storage = storage
-        for u in self.own:
-            u._packed_version = None
-            u.maybe_pack()
+        # bf16 images keep their own pack launches (two per layer).  In a training plan they go to the weight-gradient
+        # stream, idle during the forward pass: the first bf16 layer (run_generator) waits for them, the recognition /
+        # prior networks in front of it do not.
+        side = getattr(plan, "side", None)
+        plan._own_packed = None
+        if side is not None and self.own and not torch.cuda.is_current_stream_capturing():
+            side.wait_stream(torch.cuda.current_stream(plan.device))          # the optimizer's update
+            with torch.cuda.stream(side):
+                for u in self.own:
+                    u._packed_version = None
+                    u.maybe_pack()
+                plan._own_packed = torch.cuda.Event()
+                plan._own_packed.record(side)
+        else:
+            for u in self.own:
+                u._packed_version = None
+                u.maybe_pack()
         for u in self.units:
             if u._sub is not None and not u.bf16:
                 c0, c1 = u.dgrad_slice

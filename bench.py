@@ -74,6 +74,8 @@ def kernel_name(kind, unit, lib):
             return "wgrad_flat_kernel"
         if (cx, cy, cv.k, cv.stride, cv.pad) == (16, 32, 4, 2, 1):
             return "wgrad_flat_s2_kernel"
+        if cy == 1 and cv.stride == 1 and ((cx == 1 and cv.k in (3, 5)) or (4 < cx <= 8 and cv.k == 5)):
+            return "wgrad_c1_kernel<%d>" % cv.k if cx == 1 else "wgrad_cy1_kernel<%d,8,16>" % cv.k
         if cx <= 16 and cy <= 16 and not (cx == 16 and cy == 16) and (cv.k, cv.stride) in ((3, 1), (5, 1), (7, 1), (4, 2), (8, 4)):
             return "wgrad_small_kernel[k%ds%d %d,%d]" % (cv.k, cv.stride, cx, cy)
         return "wgrad_tiles_kernel[k%ds%d %s]" % (cv.k, cv.stride, "wide" if (cx > 16 and cy > 16) else "thin")
@@ -81,6 +83,10 @@ def kernel_name(kind, unit, lib):
     if kind == "backward_data" and getattr(unit, "_sub", None) is not None:
         cv = unit._sub["cv"]           # data gradient restricted to a channel slice
     kid = lib.bp_conv_kernel_id(C.byref(cv), L.PACK_FWD if kind == "forward" else L.PACK_BWD)
+    if kid == 760000:
+        return "enc_fwd_kernel"
+    if kid == 770000:
+        return "enc_dgrad_kernel"
     if kid == 700000:
         return "stem_forward_kernel"
     if kid == 750000:

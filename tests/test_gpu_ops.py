@@ -152,6 +152,9 @@ DMA_CASES = [
     (1, 32, 16, 4, 2, 1, (24, 40, 80)),       # ... more tiles than workgroups
     (0, 32, 64, 4, 2, 1, (40, 64, 96)),       # conv_flat.hip stride-2 gather 32 -> 64: more tiles than workgroups
     (1, 64, 32, 4, 2, 1, (5, 31, 50)),        # ... as the data gradient of the transposed layer, ragged tiles
+    (0, 8, 16, 8, 4, 2, (3, 37, 70)),         # conv_enc.hip: k8 stride-4 layer of the recognition / prior networks
+    (0, 8, 16, 8, 4, 2, (100, 64, 128)),      # ... more tiles than workgroups (forward)
+    (1, 16, 8, 8, 4, 2, (3, 9, 17)),          # ... the same two kernels with the roles swapped (transposed layer)
 ]
 
 
@@ -253,6 +256,88 @@ def test_small_channel_kernels_ragged_views_and_activation(case):
     dx_ref = ops.conv2d_bwd_data(dy.astype(np.float64), w64, 1, p, h, w)
     assert G.rel_err(G.from_nhwc(dxb, ci, coff=1), dx_ref) < 2e-5
     assert torch.isnan(dxb[..., :1]).all() and torch.isnan(dxb[..., 1 + ci:]).all(), "stores outside the view"
+
+@pytest.mark.parametrize("tr", [0, 1], ids=["conv", "transposed"])
+def test_encoder_k8s4_kernels_unaligned_views_and_bias(tr):
+    """conv_enc.hip through views whose channel slices are not 16-byte aligned (scalar loads / stores) and with a
+    bias, forward and data gradient, against the float64 oracle."""
+    lib = L.load()
+    ci, co, k, s, p = (16, 8, 8, 4, 2) if tr else (8, 16, 8, 4, 2)
+    n, h, w = (2, 7, 19) if tr else (2, 30, 77)
+    rng = np.random.default_rng(5 + tr)
+    x = rng.standard_normal((n, ci, h, w)).astype(np.float32)
+    wt = (rng.standard_normal(((ci, co) if tr else (co, ci)) + (k, k)) * 0.1).astype(np.float32)
+    bias = rng.standard_normal(co).astype(np.float32)
+    scale = rng.uniform(0.5, 1.5, ci).astype(np.float32)
+    shift = rng.uniform(-0.2, 0.6, ci).astype(np.float32)
+    slope = rng.uniform(0.0, 0.3, ci).astype(np.float32)
+    t = x * scale[None, :, None, None] + shift[None, :, None, None]
+    xa = np.where(t > 0, t, t * slope[None, :, None, None]).astype(np.float64)
+    w64 = wt.astype(np.float64)
+    y_ref = (ops.convT2d_fwd(xa, w64, s, p, 0) if tr else ops.conv2d_fwd(xa, w64, s, p)) + bias[None, :, None, None]
+    _, _, ho, wo = y_ref.shape
+    cv = L.Conv(tr, ci, co, k, s, p, 0)
+    assert sorted(lib.bp_conv_kernel_id(C.byref(cv), d) for d in (L.PACK_FWD, L.PACK_BWD)) == [760000, 770000]
+    st = G.stream()
+    xb, xv = G.to_nhwc(x, cstride=ci + 3, coff=1)
+    yb, yv = G.empty_nhwc(n, ho, wo, co, cstride=co + 3, coff=2)
+    keep, pw = G.pointwise(scale, shift, slope)
+    wd, bd = G.dev(wt), G.dev(bias)
+    pf = torch.zeros(lib.bp_conv_packed_floats(C.byref(cv), L.PACK_FWD), device="cuda")
+    pb = torch.zeros(lib.bp_conv_packed_floats(C.byref(cv), L.PACK_BWD), device="cuda")
+    L.check(lib.bp_conv_pack(C.byref(cv), L.PACK_FWD, L.ptr(wd), L.ptr(pf), st))
+    L.check(lib.bp_conv_pack(C.byref(cv), L.PACK_BWD, L.ptr(wd), L.ptr(pb), st))
+    L.check(lib.bp_conv_forward(C.byref(cv), C.byref(xv), C.byref(pw), L.ptr(pf), L.ptr(wd), L.ptr(bd), C.byref(yv),
+                                L.IMPL_MFMA, st), "forward")
+    assert G.rel_err(G.from_nhwc(yb, co, coff=2), y_ref) < 2e-5
+    assert torch.isnan(yb[..., :2]).all() and torch.isnan(yb[..., 2 + co:]).all(), "stores outside the view"
+    dy = rng.standard_normal(y_ref.shape).astype(np.float32)
+    dyb, dyv = G.to_nhwc(dy, cstride=co + 1, coff=1)
+    dxb, dxv = G.empty_nhwc(n, h, w, ci, cstride=ci + 2, coff=1)
+    L.check(lib.bp_conv_backward_data(C.byref(cv), C.byref(dyv), L.ptr(pb), L.ptr(wd), C.byref(dxv), L.IMPL_MFMA,
+                                      st), "backward_data")
+    dx_ref = ops.convT2d_bwd_data(dy.astype(np.float64), w64, s, p) if tr \
+        else ops.conv2d_bwd_data(dy.astype(np.float64), w64, s, p, h, w)
+    assert G.rel_err(G.from_nhwc(dxb, ci, coff=1), dx_ref) < 2e-5
+    assert torch.isnan(dxb[..., :1]).all() and torch.isnan(dxb[..., 1 + ci:]).all(), "stores outside the view"
+
+
+# weight gradients of unit-stride layers that end in ONE channel (conv_wgrad_thin.hip): the (ky, gx)-column MFMA kernel
+# for 5..8 -> 1 k5 and the register-band kernel for 1 -> 1 k3 / k5; a transposed layer swaps the roles (its input is
+# the one-channel "Y" of the kernel and carries the pending activation)
+THIN_CASES = [(0, 8, 1, 5, 2), (0, 6, 1, 5, 2), (0, 1, 1, 3, 1), (0, 1, 1, 5, 2), (1, 1, 1, 3, 1), (1, 1, 7, 5, 2)]
+
+
+@pytest.mark.parametrize("shape", [(3, 37, 70), (2, 64, 96)], ids=["ragged", "tiles"])
+@pytest.mark.parametrize("case", THIN_CASES, ids=lambda c: "%s%d_%d_k%d" % ("T" if c[0] else "C", *c[1:4]))
+def test_one_channel_tail_weight_gradients(case, shape):
+    lib = L.load()
+    tr, ci, co, k, p = case
+    n, h, w = shape
+    rng = np.random.default_rng(ci * 17 + co + k)
+    x = rng.standard_normal((n, ci, h, w)).astype(np.float32)
+    scale = rng.uniform(0.5, 1.5, ci).astype(np.float32)
+    shift = rng.uniform(-0.3, 0.6, ci).astype(np.float32)
+    slope = rng.uniform(0.0, 0.3, ci).astype(np.float32)
+    t = x * scale[None, :, None, None] + shift[None, :, None, None]
+    xa = np.where(t > 0, t, t * slope[None, :, None, None]).astype(np.float64)
+    dy = rng.standard_normal((n, co, h, w)).astype(np.float32)
+    cv = L.Conv(tr, ci, co, k, 1, p, 0)
+    st = G.stream()
+    for cs_extra, coff in ((0, 0), (3, 2)):
+        xb, xv = G.to_nhwc(x, cstride=ci + cs_extra, coff=coff if cs_extra else 0)
+        dyb, dyv = G.to_nhwc(dy, cstride=co + cs_extra, coff=1 if cs_extra else 0)
+        keep, pw = G.pointwise(scale, shift, slope)
+        ws_bytes = lib.bp_conv_backward_weight_workspace(C.byref(cv), C.byref(xv), C.byref(dyv))
+        ws = torch.zeros(ws_bytes // 8 + 8, dtype=torch.float64, device="cuda")
+        shape_w = (ci, co, k, k) if tr else (co, ci, k, k)
+        dw = torch.full(shape_w, float("nan"), device="cuda")
+        L.check(lib.bp_conv_backward_weight(C.byref(cv), C.byref(xv), C.byref(pw), C.byref(dyv), L.ptr(dw), None,
+                                            L.ptr(ws), ws.numel() * 8, L.IMPL_MFMA, st), "backward_weight")
+        dw_ref = ops.convT2d_bwd_weight(xa, dy.astype(np.float64), 1, p, k, k) if tr \
+            else ops.conv2d_bwd_weight(xa, dy.astype(np.float64), 1, p, k, k)
+        assert G.rel_err(dw.cpu().numpy(), dw_ref) < 2e-5, (cs_extra, coff)
+
 
 # strided layers with one or two channels on one side, served by the per-pixel kernels of conv_small.hip
 # (transposed, cin, cout, k, stride, pad)
