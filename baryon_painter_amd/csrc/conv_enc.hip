@@ -310,6 +310,125 @@ __global__ void enc_dgrad_pack_kernel(const float* w, int64_t sa, int64_t sb, fl
   wp[idx] = w[co * sa + ci * sb + ky * 8 + kx];
 }
 
+// ------------------------------------------------------------------------------------------------ weight gradient
+//   dW[co][ci][ky][kx] = sum_{n,oy,ox} act(X)[n, 4 oy - 2 + ky, 4 ox - 2 + kx, ci] * dY[n, oy, ox, co]
+// GEMM K = output pixels.  MFMA rows = the 16 channels of dY, columns = 16 consecutive floats (kx, ci) of X's tap row
+// (four column tiles per ky, 32 in all).  Wave w owns ky = 2w, 2w+1 -- eight accumulator tiles, outputs no other
+// wave touches -- and walks ALL 32 pixels of the 2 x 16 tile; X is staged in groups of 4 pixels (one group per
+// output pixel) at a pitch of 48 floats: the four pixels of a k-step then read bank quarters 0, 3, 2, 1.
+// (conv_wgrad_small.hip held all 32 tiles in every wave: 128 accumulator registers, one wave per SIMD, 0.10 ms.)
+constexpr int EW_R = 2;
+constexpr int EW_XR = 4 * EW_R + 4, EW_XP = 68, EW_RP = 17 * 48;
+constexpr int EW_NUX = EW_XR * EW_XP * 2, EW_UX = (EW_NUX + 255) / 256;
+constexpr int EW_XF = EW_XR * EW_RP, EW_YF = EW_R * 16 * 16;
+constexpr size_t EW_LDS = (size_t)(EW_XF + EW_YF) * 4;
+
+struct EncWArgs {
+  const float* X; int xh, xw, xcs, xco;
+  const float* Y; int yh, yw, ycs, yco;
+  PW pwx, pwy;
+  float* ws;
+  int n, tiles_x, tiles_y, ntiles, xvec, yvec;
+};
+
+__global__ __launch_bounds__(256) void enc_wgrad_kernel(EncWArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* xs = smem;
+  float* ys = smem + EW_XF;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wk = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, kq = lane >> 4;
+  const int c4 = tid & 1;
+  const PW4 px4 = pw4_load(a.pwx, 4 * c4, 8);
+  const PW4 py4 = pw4_load(a.pwy, 4 * (tid & 3), 16);
+  const int tiles_per_img = a.tiles_x * a.tiles_y;
+  float4 xv[EW_UX], yv = make_float4(0.f, 0.f, 0.f, 0.f);
+  unsigned okx = 0;
+  bool oky = false;
+
+  auto issue = [&](int tile) {
+    const int n = tile / tiles_per_img;
+    const int trem = tile - n * tiles_per_img;
+    const int ty_ = trem / a.tiles_x, tx_ = trem - ty_ * a.tiles_x;
+    const int iy0 = 4 * EW_R * ty_ - 2, ix0 = 64 * tx_ - 2;
+    const float* base = a.X + (int64_t)n * a.xh * a.xw * a.xcs + a.xco + 4 * c4;
+    okx = 0;
+#pragma unroll
+    for (int j = 0; j < EW_UX; ++j) {
+      const int e = min(tid + j * 256, EW_NUX - 1);
+      const int p = e >> 1;
+      const int r = p / EW_XP, c = p - r * EW_XP;
+      const int iy = iy0 + r, ix = ix0 + c;
+      if (iy >= 0 && iy < a.xh && ix >= 0 && ix < a.xw) okx |= 1u << j;
+      const float* q = base + ((int64_t)min(max(iy, 0), a.xh - 1) * a.xw + min(max(ix, 0), a.xw - 1)) * a.xcs;
+      if (a.xvec) xv[j] = *reinterpret_cast<const float4*>(q);
+      else xv[j] = make_float4(q[0], q[1], q[2], q[3]);
+    }
+    if (tid < EW_R * 16 * 4) {
+      const int p = tid >> 2;
+      const int oy = EW_R * ty_ + (p >> 4), ox = 16 * tx_ + (p & 15);
+      oky = oy < a.yh && ox < a.yw;
+      const float* q = a.Y + (((int64_t)n * a.yh + min(oy, a.yh - 1)) * a.yw + min(ox, a.yw - 1)) * a.ycs + a.yco + 4 * (tid & 3);
+      if (a.yvec) yv = *reinterpret_cast<const float4*>(q);
+      else yv = make_float4(q[0], q[1], q[2], q[3]);
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int j = 0; j < EW_UX; ++j) {
+      const int e = tid + j * 256;
+      if (e < EW_NUX) {
+        const int p = e >> 1;
+        const int r = p / EW_XP, c = p - r * EW_XP;
+        float4 w = pw4_apply4(px4, xv[j]);
+        if (!((okx >> j) & 1)) w = make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4*>(xs + r * EW_RP + (c >> 2) * 48 + (c & 3) * 8 + 4 * c4) = w;
+      }
+    }
+    if (tid < EW_R * 16 * 4)
+      *reinterpret_cast<float4*>(ys + 4 * tid) = oky ? pw4_apply4(py4, yv) : make_float4(0.f, 0.f, 0.f, 0.f);
+  };
+
+  v4f acc[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[i][t] = v4f{0.f, 0.f, 0.f, 0.f};
+
+  int tile = blockIdx.x;
+  if (tile < a.ntiles) issue(tile);
+  for (; tile < a.ntiles; tile += gridDim.x) {
+    __syncthreads();
+    commit();
+    __syncthreads();
+    const int next = tile + gridDim.x;
+    if (next < a.ntiles) issue(next);
+#pragma unroll
+    for (int s = 0; s < EW_R * 4; ++s) {
+      const float af = ys[(4 * s + kq) * 16 + li];
+      const float* xp = xs + (4 * (s >> 2) + 2 * wk) * EW_RP + (4 * (s & 3) + kq) * 48 + li;
+#pragma unroll
+      for (int kyi = 0; kyi < 2; ++kyi)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const float bf = xp[kyi * EW_RP + (t >> 1) * 48 + (t & 1) * 16];
+          acc[kyi][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(af, bf, acc[kyi][t], 0, 0, 0);
+        }
+    }
+  }
+  // D[co = 4*(lane>>4) + r][n = lane & 15], n-tile (ky, t): tap-row float 16 t + n = (kx, ci) -> ws[split][ky][kx][co][ci]
+#pragma unroll
+  for (int kyi = 0; kyi < 2; ++kyi)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int nf = 16 * t + li;
+      const int ky = 2 * wk + kyi, kx = nf >> 3, ci = nf & 7;
+      float* o = a.ws + (((int64_t)blockIdx.x * 64 + ky * 8 + kx) * 16 + 4 * kq) * 8 + ci;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[8 * r] = acc[kyi][t][r];
+    }
+}
+
 bool enc_off() {
   static const bool off = getenv("BP_NOENC") != nullptr;
   return off;
@@ -360,6 +479,34 @@ int bp_enc_run(const ConvGeom& g, const bp_view* in, const PW& pw, const float* 
     const int grid = a.ntiles < 256 * 4 ? a.ntiles : 256 * 4;
     hipLaunchKernelGGL(enc_dgrad_kernel, dim3(grid), dim3(256), 0, st, a);
   }
+  BP_CHECK_LAUNCH();
+  return BP_OK;
+}
+
+// Weight gradient of the same layer (either orientation: X is the 8-channel tensor at 4x the resolution of the
+// 16-channel Y).  Same contract as bp_wgrad_small (conv_wgrad.hip reduces the partials).
+int bp_wgrad_enc(const bp_conv* cv, const bp_view* X, const PW& pwx, const bp_view* Y, const PW& pwy, float* ws,
+                 size_t ws_bytes, size_t* need, int* nsplit, int* cxp, int* cyp, hipStream_t st, bool dry) {
+  if (enc_off() || cv->k != 8 || cv->stride != 4 || cv->pad != 2 || X->c != 8 || Y->c != 16) return BP_EUNSUPPORTED;
+  EncWArgs a{};
+  a.X = X->ptr; a.xh = X->h; a.xw = X->w; a.xcs = X->cstride; a.xco = X->coff;
+  a.Y = Y->ptr; a.yh = Y->h; a.yw = Y->w; a.ycs = Y->cstride; a.yco = Y->coff;
+  a.pwx = pwx; a.pwy = pwy; a.n = X->n;
+  a.tiles_x = bp_ceil_div(Y->w, 16);
+  a.tiles_y = bp_ceil_div(Y->h, EW_R);
+  const int64_t nt = (int64_t)X->n * a.tiles_x * a.tiles_y;
+  if (nt > 0x7fffffff) return BP_EUNSUPPORTED;
+  a.ntiles = (int)nt;
+  static const int cap = getenv("BP_ENC_WSPLIT") ? atoi(getenv("BP_ENC_WSPLIT")) : 768;      // (41 KB of LDS: three workgroups per CU)
+  const int grid = a.ntiles < cap ? a.ntiles : cap;
+  *need = (size_t)grid * 8192 * sizeof(float);
+  *nsplit = grid; *cxp = 8; *cyp = 16;
+  if (dry) return BP_OK;
+  if (!ws || ws_bytes < *need) return BP_EWORKSPACE;
+  a.ws = ws;
+  a.xvec = bp_view_vec4(X) ? 1 : 0;
+  a.yvec = bp_view_vec4(Y) ? 1 : 0;
+  hipLaunchKernelGGL(enc_wgrad_kernel, dim3(grid), dim3(256), EW_LDS, st, a);
   BP_CHECK_LAUNCH();
   return BP_OK;
 }

@@ -244,14 +244,18 @@ int bp_wgrad_tiles(const bp_conv* cv, const bp_view* X, const PW& pwx, const bp_
 int bp_wgrad_small(const bp_conv* cv, const bp_view* X, const PW& pwx, const bp_view* Y, const PW& pwy, float* ws,
                    size_t ws_bytes, size_t* need, int* nsplit, int* cxp, int* cyp, hipStream_t st, bool dry);
 
+int bp_wgrad_enc(const bp_conv* cv, const bp_view* X, const PW& pwx, const bp_view* Y, const PW& pwy, float* ws,
+                 size_t ws_bytes, size_t* need, int* nsplit, int* cxp, int* cyp, hipStream_t st, bool dry);
 int bp_wgrad_thin(const bp_conv* cv, const bp_view* X, const PW& pwx, const bp_view* Y, const PW& pwy, float* ws,
                   size_t ws_bytes, size_t* need, int* nsplit, int* cxp, int* cyp, hipStream_t st, bool dry);
 
-// one-channel tails (conv_wgrad_thin.hip), the tap-packed few-channel kernel, then the tap-blocked one;
+// the k8 stride-4 encoder layer (conv_enc.hip), one-channel tails (conv_wgrad_thin.hip), the tap-packed few-channel
+// kernel, then the tap-blocked one;
 // BP_EUNSUPPORTED -> generic kernel
 static int wgrad_fast(const bp_conv* cv, const bp_view* X, const PW& pwx, const bp_view* Y, const PW& pwy, float* ws,
                       size_t ws_bytes, size_t* need, int* nsplit, int* cxp, int* cyp, hipStream_t st, bool dry) {
-  int rc = bp_wgrad_thin(cv, X, pwx, Y, pwy, ws, ws_bytes, need, nsplit, cxp, cyp, st, dry);
+  int rc = bp_wgrad_enc(cv, X, pwx, Y, pwy, ws, ws_bytes, need, nsplit, cxp, cyp, st, dry);
+  if (rc == BP_EUNSUPPORTED) rc = bp_wgrad_thin(cv, X, pwx, Y, pwy, ws, ws_bytes, need, nsplit, cxp, cyp, st, dry);
   if (rc == BP_EUNSUPPORTED) rc = bp_wgrad_small(cv, X, pwx, Y, pwy, ws, ws_bytes, need, nsplit, cxp, cyp, st, dry);
   if (rc == BP_EUNSUPPORTED) rc = bp_wgrad_tiles(cv, X, pwx, Y, pwy, ws, ws_bytes, need, nsplit, cxp, cyp, st, dry);
   return rc;

@@ -86,147 +86,163 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(WsArgs a) {
   const PW4 py4 = pw4_load(a.pwy, (tid % (CYS >= 4 ? CYS / 4 : 1)) * 4, a.cy);
   const int tiles_per_img = a.tiles_x * a.tiles_y;
   const int ntiles = a.n * tiles_per_img;
-  for (int tile = split; tile < ntiles; tile += a.nsplit) {
+
+  // The 3*S slack columns of each X row are only read by k-steps whose outputs are discarded, but must hold finite
+  // numbers: zeroed once, never written again.
+  for (int e = tid; e < XR * 3 * S * CXS; e += 256) {
+    const int ch = e % CXS, c = XW + (e / CXS) % (3 * S), r = e / (3 * S * CXS);
+    xs[(r * XWS + c) * CXS + ch] = 0.f;
+  }
+
+  // Staging in two halves: issue() loads a tile's X and Y into registers (clamped addresses, validity in bit masks),
+  // commit() applies the pending activations and writes LDS.  The loop below issues tile t+1 before the k-steps of
+  // tile t, so the loads fly behind the MFMAs instead of in front of them (this kernel used to spend as long waiting
+  // for its three or four dependent load trips per tile as computing).
+  constexpr bool XV = CXS >= 4, YV = CYS >= 4;
+  constexpr int C4X = XV ? CXS / 4 : 1, C4Y = YV ? CYS / 4 : 1;
+  constexpr int NUX = XV ? XR * XW * C4X : XR * XW * CXS;       // float4 units (vector path) / floats (scalar path)
+  constexpr int NUY = YV ? BH * 32 * C4Y : BH * 32 * CYS;
+  constexpr int UX = (NUX + 255) / 256, UY = (NUY + 255) / 256;
+  static_assert(UX <= 32 && UY <= 32, "validity masks");
+  float4 xv4[XV ? UX : 1];
+  float xv1[XV ? 1 : UX];
+  float4 yv4[YV ? UY : 1];
+  float yv1[YV ? 1 : UY];
+  unsigned okx = 0, oky = 0;
+  const bool xvec = XV && a.xvec, yvec = YV && a.yvec;
+
+  auto issue = [&](int tile) {
     const int n = tile / tiles_per_img;
     const int trem = tile - n * tiles_per_img;
     const int ty_ = trem / a.tiles_x, tx_ = trem - ty_ * a.tiles_x;
     const int qy0 = ty_ * BH, qx0 = tx_ * 32;
-    __syncthreads();
-    // ---- stage X rows [qy0-p, qy0-p+XR) x cols [qx0-p, qx0-p+XW), channels padded to CXS
-    if (!(a.dbg & 2)) {
-      const float* Xn = a.X + (int64_t)n * a.xh * a.xw * a.xcs + a.xco;
-      if (CXS >= 4 && a.xvec) {
-        constexpr int C4 = CXS >= 4 ? CXS / 4 : 1;
-        const int c4 = tid % C4, ch = c4 * 4;
-        // four units per trip, loaded unconditionally from clamped coordinates before the first is used (a load
-        // under a per-lane condition is waited for on the spot)
-        constexpr int NUX = XR * XW * C4;
-        const int chs = ch < a.cx ? ch : 0;                  // (a quad past the view is zeroed below: any address inside it)
-        for (int e0 = tid; e0 < NUX; e0 += 4 * 256) {
-          float4 v[4];
-          bool ok[4];
+    const float* Xn = a.X + (int64_t)n * a.xh * a.xw * a.xcs + a.xco;
+    const float* Yn = a.Y + (int64_t)n * a.yh * a.yw * a.ycs + a.yco;
+    okx = oky = 0;
+    if (XV) {
+      const int ch = (tid % C4X) * 4;
+      const int chs = ch < a.cx ? ch : 0;                  // (a quad past the view is zeroed in commit: any address inside it)
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const int e = min(e0 + j * 256, NUX - 1);
-            const int pix = e / C4;
-            const int c = pix % XW, r = pix / XW;
-            const int iy = S * qy0 - a.pad + r, ix = S * qx0 - a.pad + c;
-            ok[j] = ch < a.cx && iy >= 0 && iy < a.xh && ix >= 0 && ix < a.xw;
-            const int cy = min(max(iy, 0), a.xh - 1), cx_ = min(max(ix, 0), a.xw - 1);
-            v[j] = *reinterpret_cast<const float4*>(Xn + ((int64_t)cy * a.xw + cx_) * a.xcs + chs);
-          }
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const int e = e0 + j * 256;
-            if (e < NUX) {
-              const int pix = e / C4;
-              const int c = pix % XW, r = pix / XW;
-              float4 w = pw4_apply4(px4, v[j]);
-              if (ch + 1 >= a.cx) w.y = 0.f;
-              if (ch + 2 >= a.cx) w.z = 0.f;
-              if (ch + 3 >= a.cx) w.w = 0.f;
-              *reinterpret_cast<float4*>(xs + (r * XWS + c) * CXS + ch) = ok[j] ? w : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-          }
-        }
-      } else {
-        constexpr int NEX = XR * XW * CXS;
-        for (int e0 = tid; e0 < NEX; e0 += 4 * 256) {
-          float v[4];
-          bool ok[4];
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const int e = min(e0 + j * 256, NEX - 1);
-            const int ch = e % CXS;
-            const int pix = e / CXS;
-            const int c = pix % XW, r = pix / XW;
-            const int iy = S * qy0 - a.pad + r, ix = S * qx0 - a.pad + c;
-            ok[j] = ch < a.cx && iy >= 0 && iy < a.xh && ix >= 0 && ix < a.xw;
-            const int cy = min(max(iy, 0), a.xh - 1), cx_ = min(max(ix, 0), a.xw - 1);
-            v[j] = Xn[((int64_t)cy * a.xw + cx_) * a.xcs + (ch < a.cx ? ch : 0)];
-          }
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const int e = e0 + j * 256;
-            if (e < NEX) {
-              const int ch = e % CXS;
-              const int pix = e / CXS;
-              const int c = pix % XW, r = pix / XW;
-              xs[(r * XWS + c) * CXS + ch] = ok[j] ? pw_apply(a.pwx, ch, v[j]) : 0.f;
-            }
-          }
-        }
+      for (int j = 0; j < UX; ++j) {
+        const int e = min(tid + j * 256, NUX - 1);
+        const int pix = e / C4X;
+        const int c = pix % XW, r = pix / XW;
+        const int iy = S * qy0 - a.pad + r, ix = S * qx0 - a.pad + c;
+        if (ch < a.cx && iy >= 0 && iy < a.xh && ix >= 0 && ix < a.xw) okx |= 1u << j;
+        const float* p = Xn + ((int64_t)min(max(iy, 0), a.xh - 1) * a.xw + min(max(ix, 0), a.xw - 1)) * a.xcs + chs;
+        if (xvec) xv4[XV ? j : 0] = *reinterpret_cast<const float4*>(p);
+        else      // (unaligned view: channels past it are masked in commit; clamp their addresses into it)
+          xv4[XV ? j : 0] = make_float4(p[0], p[chs + 1 < a.cx ? 1 : 0], p[chs + 2 < a.cx ? 2 : 0], p[chs + 3 < a.cx ? 3 : 0]);
       }
-      // the 3 slack columns of each row are only read by k-steps whose outputs are discarded,
-      // but must hold finite numbers
-      for (int e = tid; e < XR * 3 * S * CXS; e += 256) {
-        const int ch = e % CXS, c = XW + (e / CXS) % (3 * S), r = e / (3 * S * CXS);
-        xs[(r * XWS + c) * CXS + ch] = 0.f;
+    } else {
+#pragma unroll
+      for (int j = 0; j < UX; ++j) {
+        const int e = min(tid + j * 256, NUX - 1);
+        const int ch = e % CXS;
+        const int pix = e / CXS;
+        const int c = pix % XW, r = pix / XW;
+        const int iy = S * qy0 - a.pad + r, ix = S * qx0 - a.pad + c;
+        if (ch < a.cx && iy >= 0 && iy < a.xh && ix >= 0 && ix < a.xw) okx |= 1u << j;
+        xv1[XV ? 0 : j] = Xn[((int64_t)min(max(iy, 0), a.xh - 1) * a.xw + min(max(ix, 0), a.xw - 1)) * a.xcs + (ch < a.cx ? ch : 0)];
       }
     }
-    // ---- stage Y rows [qy0, qy0+BH) x cols [qx0, qx0+32)
-    if (!(a.dbg & 2)) {
-      const float* Yn = a.Y + (int64_t)n * a.yh * a.yw * a.ycs + a.yco;
-      if (CYS >= 4 && a.yvec) {
-        constexpr int C4 = CYS >= 4 ? CYS / 4 : 1;
-        const int c4 = tid % C4, ch = c4 * 4;
-        constexpr int NUY = BH * 32 * C4;
-        const int chs = ch < a.cy ? ch : 0;
-        for (int e0 = tid; e0 < NUY; e0 += 4 * 256) {
-          float4 v[4];
-          bool ok[4];
+    if (YV) {
+      const int ch = (tid % C4Y) * 4;
+      const int chs = ch < a.cy ? ch : 0;
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const int e = min(e0 + j * 256, NUY - 1);
-            const int pix = e / C4;
-            const int c = pix & 31, r = pix >> 5;
-            const int qy = qy0 + r, qx = qx0 + c;
-            ok[j] = ch < a.cy && qy < a.yh && qx < a.yw;
-            v[j] = *reinterpret_cast<const float4*>(Yn + ((int64_t)min(qy, a.yh - 1) * a.yw + min(qx, a.yw - 1)) * a.ycs + chs);
-          }
+      for (int j = 0; j < UY; ++j) {
+        const int e = min(tid + j * 256, NUY - 1);
+        const int pix = e / C4Y;
+        const int c = pix & 31, r = pix >> 5;
+        const int qy = qy0 + r, qx = qx0 + c;
+        if (ch < a.cy && qy < a.yh && qx < a.yw) oky |= 1u << j;
+        const float* p = Yn + ((int64_t)min(qy, a.yh - 1) * a.yw + min(qx, a.yw - 1)) * a.ycs + chs;
+        if (yvec) yv4[YV ? j : 0] = *reinterpret_cast<const float4*>(p);
+        else
+          yv4[YV ? j : 0] = make_float4(p[0], p[chs + 1 < a.cy ? 1 : 0], p[chs + 2 < a.cy ? 2 : 0], p[chs + 3 < a.cy ? 3 : 0]);
+      }
+    } else {
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const int e = e0 + j * 256;
-            if (e < NUY) {
-              const int pix = e / C4;
-              const int c = pix & 31, r = pix >> 5;
-              float4 w = pw4_apply4(py4, v[j]);
-              if (ch + 1 >= a.cy) w.y = 0.f;
-              if (ch + 2 >= a.cy) w.z = 0.f;
-              if (ch + 3 >= a.cy) w.w = 0.f;
-              *reinterpret_cast<float4*>(ys + ((PADR + r) * YWS + c) * CYS + ch) = ok[j] ? w : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-          }
+      for (int j = 0; j < UY; ++j) {
+        const int e = min(tid + j * 256, NUY - 1);
+        const int ch = e % CYS;
+        const int pix = e / CYS;
+        const int c = pix & 31, r = pix >> 5;
+        const int qy = qy0 + r, qx = qx0 + c;
+        if (ch < a.cy && qy < a.yh && qx < a.yw) oky |= 1u << j;
+        yv1[YV ? 0 : j] = Yn[((int64_t)min(qy, a.yh - 1) * a.yw + min(qx, a.yw - 1)) * a.ycs + (ch < a.cy ? ch : 0)];
+      }
+    }
+  };
+
+  auto commit = [&]() {
+    if (XV) {
+      const int ch = (tid % C4X) * 4;
+#pragma unroll
+      for (int j = 0; j < UX; ++j) {
+        const int e = tid + j * 256;
+        if (e < NUX) {
+          const int pix = e / C4X;
+          const int c = pix % XW, r = pix / XW;
+          float4 w = pw4_apply4(px4, xv4[XV ? j : 0]);
+          if (ch + 1 >= a.cx) w.y = 0.f;
+          if (ch + 2 >= a.cx) w.z = 0.f;
+          if (ch + 3 >= a.cx) w.w = 0.f;
+          *reinterpret_cast<float4*>(xs + (r * XWS + c) * CXS + ch) = ((okx >> j) & 1) ? w : make_float4(0.f, 0.f, 0.f, 0.f);
         }
-      } else {
-        constexpr int NEY = BH * 32 * CYS;
-        for (int e0 = tid; e0 < NEY; e0 += 4 * 256) {
-          float v[4];
-          bool ok[4];
+      }
+    } else {
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const int e = min(e0 + j * 256, NEY - 1);
-            const int ch = e % CYS;
-            const int pix = e / CYS;
-            const int c = pix & 31, r = pix >> 5;
-            const int qy = qy0 + r, qx = qx0 + c;
-            ok[j] = ch < a.cy && qy < a.yh && qx < a.yw;
-            v[j] = Yn[((int64_t)min(qy, a.yh - 1) * a.yw + min(qx, a.yw - 1)) * a.ycs + (ch < a.cy ? ch : 0)];
-          }
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const int e = e0 + j * 256;
-            if (e < NEY) {
-              const int ch = e % CYS;
-              const int pix = e / CYS;
-              const int c = pix & 31, r = pix >> 5;
-              ys[((PADR + r) * YWS + c) * CYS + ch] = ok[j] ? pw_apply(a.pwy, ch, v[j]) : 0.f;
-            }
-          }
+      for (int j = 0; j < UX; ++j) {
+        const int e = tid + j * 256;
+        if (e < NUX) {
+          const int ch = e % CXS;
+          const int pix = e / CXS;
+          const int c = pix % XW, r = pix / XW;
+          xs[(r * XWS + c) * CXS + ch] = ((okx >> j) & 1) ? pw_apply(a.pwx, ch, xv1[XV ? 0 : j]) : 0.f;
         }
       }
     }
+    if (YV) {
+      const int ch = (tid % C4Y) * 4;
+#pragma unroll
+      for (int j = 0; j < UY; ++j) {
+        const int e = tid + j * 256;
+        if (e < NUY) {
+          const int pix = e / C4Y;
+          const int c = pix & 31, r = pix >> 5;
+          float4 w = pw4_apply4(py4, yv4[YV ? j : 0]);
+          if (ch + 1 >= a.cy) w.y = 0.f;
+          if (ch + 2 >= a.cy) w.z = 0.f;
+          if (ch + 3 >= a.cy) w.w = 0.f;
+          *reinterpret_cast<float4*>(ys + ((PADR + r) * YWS + c) * CYS + ch) = ((oky >> j) & 1) ? w : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < UY; ++j) {
+        const int e = tid + j * 256;
+        if (e < NUY) {
+          const int ch = e % CYS;
+          const int pix = e / CYS;
+          const int c = pix & 31, r = pix >> 5;
+          ys[((PADR + r) * YWS + c) * CYS + ch] = ((oky >> j) & 1) ? pw_apply(a.pwy, ch, yv1[YV ? 0 : j]) : 0.f;
+        }
+      }
+    }
+  };
+
+  // (with 32 accumulator tiles -- k8 stride 4, 8 x 16 channels -- the prefetch registers cost the second wave per SIMD
+  //  and more than the overlap wins: 0.10 -> 0.15 ms; such shapes load and commit back to back)
+  constexpr bool PIPE = GY * GX <= 16;
+  int tile = split;
+  if (PIPE && tile < ntiles && !(a.dbg & 2)) issue(tile);
+  for (; tile < ntiles; tile += a.nsplit) {
+    if (!PIPE && !(a.dbg & 2)) issue(tile);
     __syncthreads();
+    if (!(a.dbg & 2)) commit();
+    __syncthreads();
+    if (PIPE && tile + a.nsplit < ntiles && !(a.dbg & 2)) issue(tile + a.nsplit);
     // ---- k-steps: row r' (0..RS-1), pixel group g (0..7); this wave takes every 4th
     if (!(a.dbg & 1))
     for (int s = wk; s < RS * 8; s += 4) {

@@ -141,7 +141,9 @@ class _Plan:
         # ---- loss
         self.ll = L.Loglik(n, Lr, cx, H, W, 1 if self.mu_softplus else 0, 1 if model.predict_var else 0,
                            1.0, 1.0, float(model.likelihood_scaling))
-        self.x_nchw = torch.zeros((n, cx, H, W), device=dev)
+        # (one channel: NCHW and NHWC are the same bytes -- the loss reads x from the recognition network's input slot)
+        self.x_nchw = self.x_in.buf.view(n, cx, H, W) if cx == 1 and self.x_in.cstride == 1 \
+            else torch.zeros((n, cx, H, W), device=dev)
         self.x_mu = torch.zeros((nL, cx, H, W), device=dev)
         self.x_log_var = torch.zeros((nL, cx, H, W), device=dev) if model.predict_var else None
         self.stats = torch.zeros(2 + 3 * cx, device=dev)
@@ -191,6 +193,10 @@ class _Plan:
                 u.ws_name = "ws_b"
             for u in self._flat(self.p_units):
                 u.ws_name = "ws_c"
+            # ... and their weight gradients get streams of their own too: nine small launches that would otherwise
+            # queue behind each other on the one weight-gradient stream after the main stream has finished
+            if self.side is not None and os.environ.get("BP_BRANCH_SIDE", "1") != "0":
+                self.side_branch = {k: (torch.cuda.Stream(device=dev), torch.zeros_like(self.ws)) for k in ("ws_b", "ws_c")}
 
     # ---- bf16 policy (dtype="bf16", BASELINE.json configs[3]).  The generator trunk p_y_z_in and the first layer of
     # each head run on the bf16 matrix-core kernels and every p_y_z_in activation / gradient is stored as bf16: that
@@ -214,6 +220,16 @@ class _Plan:
 
     def need_ws(self, nbytes):
         self.ws_bytes = max(self.ws_bytes, int(nbytes))
+
+    side_branch = None
+
+    def side_of(self, unit):
+        """(stream, workspace) for a unit's weight gradient, or (None, None): serial schedule."""
+        if self.side is None:
+            return None, None
+        if self.side_branch is not None and self.branch is not None and unit.ws_name in self.side_branch:
+            return self.side_branch[unit.ws_name]
+        return self.side, self.ws2
 
     def impl_of(self, kind, unit=None):
         """Kernel family per operation; BP_IMPL_FWD / BP_IMPL_DGRAD / BP_IMPL_WGRAD (auto|direct|mfma)
@@ -347,8 +363,9 @@ class _Plan:
             if not self.with_q:
                 raise RuntimeError("this plan was built without the recognition network")
             self.x_nchw.copy_(x)
-            L.check(lib.bp_nchw_to_view(L.ptr(self.x_nchw), m.dim_x[0], None, 0, C.byref(self.x_in.view), st),
-                    "x layout")
+            if self.x_nchw.data_ptr() != self.x_in.buf.data_ptr():
+                L.check(lib.bp_nchw_to_view(L.ptr(self.x_nchw), m.dim_x[0], None, 0, C.byref(self.x_in.view), st),
+                        "x layout")
 
     def run_prior(self, training):
         for u in self.p_units:
@@ -440,8 +457,15 @@ class _Plan:
                 self.deferring = False
                 self.lib.bp_wgrad_defer_flush(-1, None)
 
+    def _join_branch_sides(self):
+        if self.side is not None and self.side_branch is not None:
+            for st, _ in self.side_branch.values():
+                self.side.wait_stream(st)
+
     def _flush_reductions(self, end):
         """Launch the recorded split-K reductions behind the weight-gradient kernels (their stream)."""
+        if end:
+            self._join_branch_sides()
         if not self.deferring:
             return
         if self.side is not None:

@@ -638,7 +638,9 @@ class ConvUnit:
         plan, lib, st = self.plan, self.plan.lib, _stream()
         g, hold = self.out.grad, self.holder
         dbias = None if hold.bias is None else grads[id(hold.bias)]
-        side = getattr(plan, "side", None)
+        side, side_ws = plan.side_of(self) if hasattr(plan, "side_of") else (getattr(plan, "side", None), None)
+        if side is not None and side_ws is None:
+            side_ws = plan.ws2
 
         def wgrad(ws):
             t0 = plan.prof_begin()
@@ -660,7 +662,7 @@ class ConvUnit:
         else:
             side.wait_stream(torch.cuda.current_stream())     # fork: d_raw of this layer is complete
             with torch.cuda.stream(side):
-                wgrad(plan.ws2)
+                wgrad(side_ws)
         if self.dx is not None:
             prod = self._producer_to_fuse()
             t0 = plan.prof_begin()

@@ -300,6 +300,14 @@ def test_encoder_k8s4_kernels_unaligned_views_and_bias(tr):
         else ops.conv2d_bwd_data(dy.astype(np.float64), w64, s, p, h, w)
     assert G.rel_err(G.from_nhwc(dxb, ci, coff=1), dx_ref) < 2e-5
     assert torch.isnan(dxb[..., :1]).all() and torch.isnan(dxb[..., 1 + ci:]).all(), "stores outside the view"
+    ws_bytes = lib.bp_conv_backward_weight_workspace(C.byref(cv), C.byref(xv), C.byref(dyv))
+    ws = torch.zeros(ws_bytes // 8 + 8, dtype=torch.float64, device="cuda")
+    dw = torch.full(wt.shape, float("nan"), device="cuda")
+    L.check(lib.bp_conv_backward_weight(C.byref(cv), C.byref(xv), C.byref(pw), C.byref(dyv), L.ptr(dw), None,
+                                        L.ptr(ws), ws.numel() * 8, L.IMPL_MFMA, st), "backward_weight")
+    dw_ref = ops.convT2d_bwd_weight(xa, dy.astype(np.float64), s, p, k, k) if tr \
+        else ops.conv2d_bwd_weight(xa, dy.astype(np.float64), s, p, k, k)
+    assert G.rel_err(dw.cpu().numpy(), dw_ref) < 2e-5
 
 
 # weight gradients of unit-stride layers that end in ONE channel (conv_wgrad_thin.hip): the (ky, gx)-column MFMA kernel
