@@ -1038,7 +1038,7 @@ bool bp_bf16_flat_ok(const ConvGeom& g, const bp_view* in, const bp_view* out, c
   if (f.kind == 3) {
     if (in->cstride % 4 || in->coff % 4 || in->coff + 4 > in->cstride) return false;      // (reads a whole channel quad)
   } else if ((in->cstride * (ib ? 2 : 4)) % 16 || (in->coff * (ib ? 2 : 4)) % 16) return false;
-  if (out->cstride % 4 || out->coff % 4) return false;                                    // 4-channel vector stores
+  if (g.cout_g >= 4 && (out->cstride % 4 || out->coff % 4)) return false;                 // 4-channel vector stores
   return fb_tiles(out) < (1ll << 31);
 }
 

@@ -29,6 +29,7 @@ struct EncArgs {
   float* out; int oh, ow, ocs, oco;
   const float* wp;
   const float* bias;
+  double* stat;       // forward: per-workgroup rows [2 x 16] of {sum y, sum y^2} (nullptr: none)
   PW pw;
   int n, tiles_x, tiles_y, ntiles;
   int in_vec, out_vec;
@@ -109,6 +110,7 @@ __global__ __launch_bounds__(256) void enc_fwd_kernel(EncArgs a) {
     }
   };
 
+  float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};     // this thread's pixels, its 4 channels
   int tile = blockIdx.x;
   if (tile < a.ntiles) issue(tile);
   for (; tile < a.ntiles; tile += gridDim.x) {
@@ -165,8 +167,30 @@ __global__ __launch_bounds__(256) void enc_fwd_kernel(EncArgs a) {
         float* o = a.out + (((int64_t)n * a.oh + oy) * a.ow + ox) * a.ocs + a.oco + 4 * cq;
         if (a.out_vec) *reinterpret_cast<float4*>(o) = s;
         else { o[0] = s.x; o[1] = s.y; o[2] = s.z; o[3] = s.w; }
+        ssum[0] += s.x; ssum[1] += s.y; ssum[2] += s.z; ssum[3] += s.w;
+        ssq[0] = fmaf(s.x, s.x, ssq[0]); ssq[1] = fmaf(s.y, s.y, ssq[1]);
+        ssq[2] = fmaf(s.z, s.z, ssq[2]); ssq[3] = fmaf(s.w, s.w, ssq[3]);
       }
     }
+  }
+  // batch-norm statistics of what was stored: a thread's few pixels in fp32, everything beyond in double, fixed order
+  if (a.stat) {
+    double v[8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { v[j] = (double)ssum[j]; v[4 + j] = (double)ssq[j]; }
+#pragma unroll
+    for (int sh = 4; sh < 64; sh <<= 1)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] += __shfl_xor(v[j], sh, 64);
+    __syncthreads();
+    double* red = reinterpret_cast<double*>(smem);          // [wave][which 0..1][16 channels]
+    if (lane < 4) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { red[(wk * 2 + 0) * 16 + 4 * lane + j] = v[j]; red[(wk * 2 + 1) * 16 + 4 * lane + j] = v[4 + j]; }
+    }
+    __syncthreads();
+    if (tid < 32)
+      a.stat[(int64_t)blockIdx.x * 32 + tid] = (red[0 * 32 + tid] + red[1 * 32 + tid]) + (red[2 * 32 + tid] + red[3 * 32 + tid]);
   }
 }
 
@@ -452,8 +476,29 @@ int bp_enc_pack(const ConvGeom& g, const WeightMap& wm, const float* w_torch, fl
   return BP_OK;
 }
 
+size_t bp_stats_rows_bytes(int64_t rows, int C);
+int bp_stats_rows_finish(double* ws, int64_t rows, int C, const IgemmStatsReq* sr, hipStream_t st);
+
+static int enc_fwd_grid(const bp_view* in, const bp_view* out, int* tiles_x, int* tiles_y, int* ntiles) {
+  static const int per_cu = getenv("BP_ENC_WGS") ? atoi(getenv("BP_ENC_WGS")) : 2;   // (188 VGPRs: two waves per SIMD)
+  *tiles_x = bp_ceil_div(out->w, 16);
+  *tiles_y = bp_ceil_div(out->h, EF_R);
+  const int64_t nt = (int64_t)in->n * *tiles_x * *tiles_y;
+  if (nt > 0x7fffffff) return -1;
+  *ntiles = (int)nt;
+  return *ntiles < 256 * per_cu ? *ntiles : 256 * per_cu;
+}
+
+// forward only: {sum y, sum y^2} per produced channel (mode 1), one row per workgroup
+size_t bp_enc_stats_workspace(const ConvGeom& g, const bp_view* in, const bp_view* out, int mode) {
+  if (!bp_enc_fwd_ok(g) || mode != 1) return 0;
+  int tx, ty, nt;
+  const int grid = enc_fwd_grid(in, out, &tx, &ty, &nt);
+  return grid > 0 ? bp_stats_rows_bytes(grid, 16) : 0;
+}
+
 int bp_enc_run(const ConvGeom& g, const bp_view* in, const PW& pw, const float* packed, const float* bias,
-               const bp_view* out, hipStream_t st) {
+               const bp_view* out, hipStream_t st, const IgemmStatsReq* sr) {
   EncArgs a{};
   a.bias = bias;
   a.in = in->ptr; a.ih = in->h; a.iw = in->w; a.ics = in->cstride; a.ico = in->coff;
@@ -461,16 +506,19 @@ int bp_enc_run(const ConvGeom& g, const bp_view* in, const PW& pw, const float* 
   a.wp = packed; a.pw = pw; a.n = in->n;
   a.in_vec = bp_view_vec4(in) ? 1 : 0;
   a.out_vec = bp_view_vec4(out) ? 1 : 0;
-  static const int per_cu = getenv("BP_ENC_WGS") ? atoi(getenv("BP_ENC_WGS")) : 2;   // (188 VGPRs: two waves per SIMD)
   if (bp_enc_fwd_ok(g)) {
-    a.tiles_x = bp_ceil_div(out->w, 16);
-    a.tiles_y = bp_ceil_div(out->h, EF_R);
-    const int64_t nt = (int64_t)in->n * a.tiles_x * a.tiles_y;
-    if (nt > 0x7fffffff) return BP_EUNSUPPORTED;
-    a.ntiles = (int)nt;
-    const int grid = a.ntiles < 256 * per_cu ? a.ntiles : 256 * per_cu;
+    const int grid = enc_fwd_grid(in, out, &a.tiles_x, &a.tiles_y, &a.ntiles);
+    if (grid <= 0) return BP_EUNSUPPORTED;
+    if (sr) {
+      if (bias || sr->mode != 1) return BP_EUNSUPPORTED;
+      if (!sr->ws || sr->ws_bytes < bp_stats_rows_bytes(grid, 16) || !sr->sums) return BP_EWORKSPACE;
+      a.stat = reinterpret_cast<double*>(sr->ws);
+    }
     hipLaunchKernelGGL(enc_fwd_kernel, dim3(grid), dim3(256), EF_LDS, st, a);
+    BP_CHECK_LAUNCH();
+    return sr ? bp_stats_rows_finish(a.stat, grid, 16, sr, st) : BP_OK;
   } else {
+    if (sr) return BP_EUNSUPPORTED;
     a.tiles_x = bp_ceil_div(bp_ceil_div(out->w, 4), 16);
     a.tiles_y = bp_ceil_div(bp_ceil_div(out->h, 4), ED_RQ);
     const int64_t nt = (int64_t)in->n * a.tiles_x * a.tiles_y;

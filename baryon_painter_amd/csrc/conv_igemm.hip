@@ -1492,8 +1492,9 @@ int bp_flat_h7_run(const bp_view* in, const PW& pw, const float* packed, const f
 bool bp_enc_ok(const ConvGeom& g);
 int64_t bp_enc_packed_floats();
 int bp_enc_pack(const ConvGeom& g, const WeightMap& wm, const float* w_torch, float* packed, hipStream_t st);
+size_t bp_enc_stats_workspace(const ConvGeom& g, const bp_view* in, const bp_view* out, int mode);
 int bp_enc_run(const ConvGeom& g, const bp_view* in, const PW& pw, const float* packed, const float* bias,
-               const bp_view* out, hipStream_t st);
+               const bp_view* out, hipStream_t st, const IgemmStatsReq* sr);
 
 int bp_igemm_kernel_id(const ConvGeom& g) {
   if (bp_enc_ok(g)) return g.gather_transposed ? 770000 : 760000;
@@ -1651,7 +1652,7 @@ int bp_stats_rows_finish(double* ws, int64_t rows, int C, const IgemmStatsReq* s
 }
 
 size_t bp_igemm_stats_workspace(const ConvGeom& g, const bp_view* in, const bp_view* out, int mode) {
-  if (bp_enc_ok(g)) return 0;
+  if (bp_enc_ok(g)) return bp_enc_stats_workspace(g, in, out, mode);
   if (bp_stem_ok(g)) return mode == 1 ? bp_stem_stats_workspace(out) : 0;
   if (bp_flat_ok(g)) return bp_flat_stats_workspace(out, mode);
   if (bp_flat_t4_ok(g) && !bp_flat_t64_ok(g)) return mode == 1 ? bp_flat_t4_stats_workspace(out) : 0;
@@ -1669,7 +1670,7 @@ size_t bp_igemm_stats_workspace(const ConvGeom& g, const bp_view* in, const bp_v
 
 int bp_igemm_run(const ConvGeom& g, const bp_view* in, const PW& pw, const float* packed,
                  const float* bias, const bp_view* out, hipStream_t st, const IgemmStatsReq* sr) {
-  if (bp_enc_ok(g)) return sr ? BP_EUNSUPPORTED : bp_enc_run(g, in, pw, packed, bias, out, st);
+  if (bp_enc_ok(g)) return bp_enc_run(g, in, pw, packed, bias, out, st, sr);
   if (bp_stem_ok(g)) return bp_stem_run(in, pw, packed, bias, out, st, sr);
   if (bp_flat_ok(g)) return bp_flat_run(g, in, pw, packed, bias, out, st, sr);
   if (bp_flat_t4_ok(g) && !bp_flat_t64_ok(g)) return bp_flat_t4_run(in, pw, packed, bias, out, st, sr);

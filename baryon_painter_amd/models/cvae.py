@@ -110,7 +110,8 @@ class _Plan:
         ccat = c_hz + c_hy
         self.p_in = Slot.new(nL, H, W, ccat, dev, cstride=((ccat + 3) // 4) * 4)
         self.p_in.pw = PW.identity(ccat, dev)
-        hz_slot = self.p_in.sub(0, c_hz, pw=self.p_in.pw.slice(0, c_hz))
+        hz_slot = self.p_in.sub(0, c_hz, pw=self.p_in.pw.slice(0, c_hz),
+                                dense_grad=os.environ.get("BP_DENSE_ZGRAD", "1") != "0")
         self.hy_slot = self.p_in.sub(c_hz, ccat)
         uz, sz, tr = compile_sequential(self, "p_z_in.", a["p_z_in"], model.p_z_in, self.z,
                                         out_slot=hz_slot, out_pw=hz_slot.pw)
@@ -120,7 +121,7 @@ class _Plan:
         ub, sb, tr = compile_sequential(self, "p_y_z_in.", a["p_y_z_in"], model.p_y_z_in, self.p_in)
         self._no_trailing(tr, "p_y_z_in")
         if ub and isinstance(ub[0], ConvUnit):
-            ub[0].restrict_dgrad(0, c_hz)      # y and the aux label are data: only h_z carries a gradient
+            ub[0].restrict_dgrad(0, c_hz, target=hz_slot)   # y and the aux label are data: only h_z carries a gradient
         self.g_units = [uz, ub]
         self.h = sb
         um, sm, tr = compile_sequential(self, "p_mu_out.", a["p_y_z_out"][0], model.p_mu_out, sb)
@@ -354,10 +355,23 @@ class _Plan:
             aux = aux.reshape(self.n, self.caux).to(torch.float32).contiguous()
             auxp = L.ptr(aux)
         L.check(lib.bp_nchw_to_view(L.ptr(y), cy, auxp, self.caux, C.byref(self.y2.view), st), "merge_aux_label")
-        for l in range(m.L):
-            v = L.View(self.p_in.buf[l * self.n:].data_ptr(), self.n, self.hy_slot.h, self.hy_slot.w,
-                       self.hy_slot.c, self.hy_slot.cstride, self.hy_slot.coff)
-            L.check(lib.bp_nchw_to_view(L.ptr(y), cy, auxp, self.caux, C.byref(v), st), "merge_aux_label (P)")
+
+        def generator_copy(stream):
+            for l in range(m.L):
+                v = L.View(self.p_in.buf[l * self.n:].data_ptr(), self.n, self.hy_slot.h, self.hy_slot.w,
+                           self.hy_slot.c, self.hy_slot.cstride, self.hy_slot.coff)
+                L.check(lib.bp_nchw_to_view(L.ptr(y), cy, auxp, self.caux, C.byref(v), stream), "merge_aux_label (P)")
+        # the generator's copy of y is not read before run_generator: in a training plan it goes to the weight-
+        # gradient stream (idle during the forward pass), beside the recognition / prior networks
+        self._gen_inputs = None
+        if self.side is not None and not torch.cuda.is_current_stream_capturing():
+            self.side.wait_stream(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(self.side):
+                generator_copy(_stream())
+                self._gen_inputs = torch.cuda.Event()
+                self._gen_inputs.record(self.side)
+        else:
+            generator_copy(st)
         self._keep = (y, aux)
         if x is not None:
             if not self.with_q:
@@ -386,6 +400,9 @@ class _Plan:
 
     def run_generator(self, training):
         for i, us in enumerate(self.g_units):
+            if i == 0 and getattr(self, "_gen_inputs", None) is not None:
+                torch.cuda.current_stream(self.device).wait_event(self._gen_inputs)    # load_inputs: y for the generator
+                self._gen_inputs = None
             if i == 1 and getattr(self, "_own_packed", None) is not None:
                 torch.cuda.current_stream(self.device).wait_event(self._own_packed)    # graph.PackBatch: bf16 images
                 self._own_packed = None

@@ -213,9 +213,12 @@ class Slot:
         return Slot(torch.zeros((n, h, w, cs), device=device, dtype=torch.bfloat16 if bf16 else torch.float32),
                     n, h, w, c, 0, pw)
 
-    def sub(self, c0, c1, pw=None):
-        """Channel slice sharing storage (and gradient storage)."""
-        return Slot(self.buf, self.n, self.h, self.w, c1 - c0, self.coff + c0, pw, parent=self)
+    def sub(self, c0, c1, pw=None, dense_grad=False):
+        """Channel slice sharing storage (and gradient storage, unless ``dense_grad``: a one-channel slice of a
+        four-channel buffer costs every streaming pass over its gradient four times the bytes)."""
+        s = Slot(self.buf, self.n, self.h, self.w, c1 - c0, self.coff + c0, pw, parent=self)
+        s.dense_grad = dense_grad
+        return s
 
     def pw_struct(self):
         return None if self.pw is None else C.byref(self.pw.struct)
@@ -224,8 +227,14 @@ class Slot:
         return (self.n, self.h, self.w, self.c)
 
     # ---- gradients
+    dense_grad = False       # a channel slice that keeps d(loss)/d(slot) in a dense buffer of its own (see sub())
+
     def ensure_grad(self):
         if self.grad is None:
+            if self.parent is not None and self.dense_grad:
+                self.grad_buf = torch.zeros((self.n, self.h, self.w, self.c), device=self.buf.device, dtype=self.buf.dtype)
+                self.grad = L.View(self.grad_buf.data_ptr(), self.n, self.h, self.w, self.c, self.c, 0, self.dt)
+                return self.grad
             if self.parent is not None:
                 self.parent.ensure_grad()
                 self.grad_buf = self.parent.grad_buf
@@ -350,13 +359,19 @@ class ConvUnit:
                 self.fwd_stats = True
                 plan.need_ws(nb)
 
-    def restrict_dgrad(self, c0, c1):
+    def restrict_dgrad(self, c0, c1, target=None):
         """Only input channels [c0, c1) carry a gradient (the rest of a concatenated input is data): the data
-        gradient then runs as a (c1-c0)-channel layer on a copy of that weight slice."""
+        gradient then runs as a (c1-c0)-channel layer on a copy of that weight slice.  ``target``: the sub-slot
+        of those channels when it keeps a DENSE gradient buffer of its own (``Slot.dense_grad``): the gradient is
+        written there instead of into a channel slice of the wide buffer."""
         cv = self.cv
         if not (0 <= c0 < c1 <= cv.cin) or self.dx is not None:
             raise ValueError(f"{self.name}: bad gradient channel range or backward already prepared")
+        if target is not None and target.grad is not None:
+            raise ValueError(f"{self.name}: the target slot's gradient buffer already exists")
         if (c0, c1) == (0, cv.cin) or not self.need_dgrad:
+            if target is not None:
+                target.dense_grad = False       # (the gradient stays in the wide buffer)
             return
         lib, dev = self.plan.lib, self.plan.device
         sub = L.Conv(cv.transposed, c1 - c0, cv.cout, cv.k, cv.stride, cv.pad, cv.out_pad)
@@ -365,12 +380,15 @@ class ConvUnit:
         else:
             n_bwd = lib.bp_conv_packed_floats(C.byref(sub), L.PACK_BWD)
         if n_bwd <= 0:
+            if target is not None:
+                target.dense_grad = False
             return                      # no kernel for the narrower layer: keep the full data gradient
         w = self.holder.weight
         shape = (c1 - c0, cv.cout, cv.k, cv.k) if cv.transposed else (cv.cout, c1 - c0, cv.k, cv.k)
         self.dgrad_slice = (c0, c1)
         self._sub = {"cv": sub, "w": torch.zeros(shape, device=dev, dtype=w.dtype),
-                     "packed": torch.zeros(n_bwd, device=dev, dtype=torch.bfloat16 if self.bf16 else torch.float32)}
+                     "packed": torch.zeros(n_bwd, device=dev, dtype=torch.bfloat16 if self.bf16 else torch.float32),
+                     "target": target if target is not None and target.dense_grad else None}
         self.packed_bwd = None
 
     ws_own = None       # this layer's own split-K workspace when the plan defers the reductions (cvae._Plan)
@@ -531,13 +549,17 @@ class ConvUnit:
         self._wgrad_ws_bytes = int(lib.bp_conv_backward_weight_workspace(C.byref(self.cv), C.byref(self.inp.view),
                                                                          C.byref(self.out.view)))
         self.plan.need_ws(self._wgrad_ws_bytes)
-        self.dx = self.inp.claim_grad() if self.need_dgrad else None
+        if self.need_dgrad and self._sub is not None and self._sub["target"] is not None:
+            self.inp.n_consumers += 1          # (the wide slot itself gets no gradient buffer)
+            self.dx = self._sub["dx"] = self._sub["target"].ensure_grad()
+        else:
+            self.dx = self.inp.claim_grad() if self.need_dgrad else None
         if self.dx is not None and self._sub is None and EPILOGUE_BWD and not self.bf16 and self.inp.dt == L.F32 \
                 and (_BWD_KERNEL_IDS is None
                      or lib.bp_conv_kernel_id(C.byref(self.cv), L.PACK_BWD) in _BWD_KERNEL_IDS):
             self.plan.need_ws(lib.bp_conv_stats_workspace(C.byref(self.cv), L.PACK_BWD, C.byref(self.inp.view),
                                                           C.byref(self.out.view), L.IMPL_MFMA))
-        if self.dx is not None and self._sub is not None:
+        if self.dx is not None and self._sub is not None and self._sub["target"] is None:
             c0, c1 = self.dgrad_slice
             full = self.dx
             self._sub["dx"] = L.View(full.ptr, full.n, full.h, full.w, c1 - c0, full.cstride, full.coff + c0,

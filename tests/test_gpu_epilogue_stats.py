@@ -41,6 +41,8 @@ CASES = [
     (0, 32, 64, 4, 2, 1, (40, 64, 96)),        # conv_flat.hip stride-2 gather 32 -> 64: sums kept per lane in LDS
     (1, 64, 32, 4, 2, 1, (11, 40, 70)),        # ... and the transposed form 64 -> 32 (four phases x two channel blocks)
     (0, 3, 16, 5, 1, 2, (40, 130, 200)),      # ... with more tiles than workgroups (grid-stride walk)
+    (0, 8, 16, 8, 4, 2, (3, 37, 70)),         # conv_enc.hip: sums kept per thread over its tiles, one row per workgroup
+    (0, 8, 16, 8, 4, 2, (100, 64, 128)),      # ... more tiles than workgroups
 ]
 
 

@@ -239,7 +239,12 @@ def test_flat_adam_equals_torch_adam():
     assert first[0][0] == first[1][0]
     assert G.rel_err(first[1][1].cpu().numpy(), first[0][1].cpu().numpy()) < 1e-6
     assert abs(finals[0][0] - finals[1][0]) <= 1e-4 * abs(finals[0][0])
-    assert (finals[1][1] - finals[0][1]).abs().max().item() < 0.5e-3       # half of the first (largest) step
+    # Adam moves a parameter by ~lr per step whatever the size of its gradient, so a parameter whose gradient is at the
+    # rounding floor may take steps two and three (0.5e-3 + 0.25e-3) in opposite directions in the two runs: 1.5e-3 is
+    # the bound for any single parameter, and all but a handful stay within half of the first (largest) step
+    d = (finals[1][1] - finals[0][1]).abs()
+    assert d.max().item() < 1.5e-3
+    assert (d > 0.5e-3).float().mean().item() < 1e-4
 
 
 def test_forward_is_deterministic_and_shape_checked():
