@@ -73,6 +73,8 @@ SIGNATURES = {
     "bp_conv_forward_stats": (C.c_int, [_CP, _VP, _PWP, _P, _VP, _P, _P, C.c_size_t, C.c_int, _P]),
     "bp_conv_forward_bn": (C.c_int, [_CP, _VP, _PWP, _P, _VP, _P, C.POINTER(BnTrain), _P, C.c_size_t, C.c_int, _P]),
     "bp_conv_backward_data_stats": (C.c_int, [_CP, _VP, _P, _VP, _VP, _PWP, _P, _P, C.c_size_t, _P]),
+    "bp_conv_backward_data_act_workspace": (C.c_size_t, [_CP, _VP, _VP]),
+    "bp_conv_backward_data_act": (C.c_int, [_CP, _VP, _P, _VP, _VP, _PWP, _P, _P, C.c_size_t, _P]),
     "bp_conv_backward_weight_workspace": (C.c_size_t, [_CP, _VP, _VP]),
     "bp_conv_backward_weight": (C.c_int, [_CP, _VP, _PWP, _VP, _P, _P, _P, C.c_size_t, C.c_int, _P]),
     "bp_wgrad_defer_begin": (C.c_int, []),

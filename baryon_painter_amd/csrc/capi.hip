@@ -188,6 +188,21 @@ int bp_conv_backward_data_stats(const bp_conv* cv, const bp_view* dy, const floa
                       bp_stream(stream), &sr);
 }
 
+size_t bp_conv_backward_data_act_workspace(const bp_conv* cv, const bp_view* dy, const bp_view* g) {
+  if (!conv_ok(cv) || !shapes_ok(cv, g, dy)) return 0;
+  return bp_igemm_stats_workspace(bp_geom_backward_data(cv), dy, g, 3);
+}
+
+int bp_conv_backward_data_act(const bp_conv* cv, const bp_view* dy, const float* packed_bwd, const bp_view* g,
+                              const bp_view* x_raw, const bp_pointwise* x_pw, double* sums, void* workspace,
+                              size_t workspace_bytes, void* stream) {
+  if (!conv_ok(cv) || !shapes_ok(cv, g, dy) || !packed_bwd || !sums || !bp_view_ok(x_raw)) return BP_EINVAL;
+  if (x_raw->n != g->n || x_raw->h != g->h || x_raw->w != g->w || x_raw->c != g->c) return BP_EINVAL;
+  const IgemmStatsReq sr{3, x_raw, bp_pw(x_pw), sums, workspace, workspace_bytes};
+  return bp_igemm_run(bp_geom_backward_data(cv), dy, PW{nullptr, nullptr, nullptr}, packed_bwd, nullptr, g,
+                      bp_stream(stream), &sr);
+}
+
 int bp_conv_backward_data(const bp_conv* cv, const bp_view* dy, const float* packed_bwd, const float* w_torch,
                           const bp_view* dx, int impl, void* stream) {
   if (!conv_ok(cv) || !shapes_ok(cv, dx, dy, impl == BP_IMPL_BF16)) return BP_EINVAL;

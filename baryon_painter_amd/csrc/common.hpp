@@ -44,6 +44,8 @@ static inline PW bp_pw(const bp_pointwise* p) {
 // Request for per-channel sums out of an igemm epilogue (conv_igemm.hip, IgemmArgs::stat).  mode 1: {sum y,
 // sum y^2} of the produced tensor; mode 2: the produced tensor is d(loss)/d(activated slot), `raw` / `spw` are that
 // slot's raw values and pending activation: {sum g, sum g*raw} with g = d * act'(spw(raw)).  sums[2c].
+// mode 3: as mode 2, but g ITSELF is stored instead of d (the slot has no batch-norm: g is what its layer's gradients
+// read) and sums[3c] = {sum g, sum g*raw, sum_{t<=0} d*t} as bp_act_backward leaves them (conv_small.hip only).
 // Training-mode batch-norm finalize (bp_bn_finalize's arguments) folded into the launch that sums the partial rows
 // of a mode-1 request: one small launch less per batch-norm layer and step.
 struct BnFin {
@@ -64,6 +66,7 @@ struct IgemmStatsReq {
   const BnFin* fin;         // mode 1 only; nullptr: sums only
 };
 int bp_sum_partials(const double* partial, int nblk, int n, double* out, hipStream_t st);
+int bp_sum_partials_strided(const double* partial, int nblk, int stride, int n, double* out, hipStream_t st);
 // the last stage of a statistics request: partial[nblk][n] -> sr->sums (and, with sr->fin, the finalize)
 int bp_sum_partials_req(const double* partial, int nblk, int n, const IgemmStatsReq* sr, hipStream_t st);
 

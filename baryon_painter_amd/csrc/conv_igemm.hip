@@ -1440,8 +1440,9 @@ bool bp_small_ok(const ConvGeom& g);
 int64_t bp_small_packed_floats(const ConvGeom& g);
 int bp_small_kernel_id(const ConvGeom& g);
 int bp_small_pack(const ConvGeom& g, const WeightMap& wm, const float* w_torch, float* packed, hipStream_t st);
+size_t bp_small_stats_workspace(const ConvGeom& g, const bp_view* in, const bp_view* out, int mode);
 int bp_small_run(const ConvGeom& g, const bp_view* in, const PW& pw, const float* packed, const float* bias,
-                 const bp_view* out, hipStream_t st);
+                 const bp_view* out, hipStream_t st, const IgemmStatsReq* sr);
 
 // conv_stem.hip: the 3 -> 16 k5 stem (flattened (tap column, channel) K, weights in registers)
 bool bp_stem_ok(const ConvGeom& g);
@@ -1644,6 +1645,33 @@ size_t bp_stats_rows_bytes(int64_t rows, int C) {
   stats_fold_plan(p);
   return p.bytes;
 }
+// ... the same for rows of which n doubles are wanted (the three sums of an activation backward: n = 3 C).  The fold
+// needs a power-of-two row: the kernel writes rows of bp_stats_row_stride(n) doubles, zero beyond n.
+int bp_stats_row_stride(int n) {
+  int s = 1;
+  while (s < n) s <<= 1;
+  return s;
+}
+size_t bp_stats_rows_bytes_n(int64_t rows, int n) {
+  StatsPlan p{};
+  p.rows = rows; p.n = bp_stats_row_stride(n);
+  stats_fold_plan(p);
+  return p.bytes;
+}
+int bp_stats_rows_finish_n(double* ws, int64_t rows, int n, const IgemmStatsReq* sr, hipStream_t st) {
+  StatsPlan p{};
+  p.rows = rows; p.n = bp_stats_row_stride(n);
+  stats_fold_plan(p);
+  const double* src = ws;
+  int64_t nrows = p.rows;
+  if (p.nfold) {
+    double* folded = ws + p.rows * p.n;
+    hipLaunchKernelGGL(stats_fold_kernel, dim3((unsigned)p.nfold), dim3(256), 0, st, src, p.rows, p.R, p.n, folded);
+    BP_CHECK_LAUNCH();
+    src = folded; nrows = p.nfold;
+  }
+  return bp_sum_partials_strided(src, (int)nrows, p.n, n, sr->sums, st);
+}
 int bp_stats_rows_finish(double* ws, int64_t rows, int C, const IgemmStatsReq* sr, hipStream_t st) {
   StatsPlan p{};
   p.rows = rows; p.n = 2 * C;
@@ -1659,7 +1687,8 @@ size_t bp_igemm_stats_workspace(const ConvGeom& g, const bp_view* in, const bp_v
   if (bp_flat_g4_ok(g)) return mode == 1 ? bp_flat_g4_stats_workspace(out) : 0;
   if (bp_flat_t64_ok(g)) return mode == 1 ? bp_flat_t64_stats_workspace(out) : 0;
   if (bp_flat_h7_ok(g)) return 0;
-  if (bp_small_ok(g)) return 0;
+  if (bp_small_ok(g)) return bp_small_stats_workspace(g, in, out, mode);
+  if (mode != 1 && mode != 2) return 0;
   const IgemmConfig c = igemm_config(g);
   IgemmLaunch l;
   StatsPlan p;
@@ -1677,7 +1706,7 @@ int bp_igemm_run(const ConvGeom& g, const bp_view* in, const PW& pw, const float
   if (bp_flat_g4_ok(g)) return bp_flat_g4_run(g, in, pw, packed, bias, out, st, sr);
   if (bp_flat_t64_ok(g)) return bp_flat_t64_run(g, in, pw, packed, bias, out, st, sr);
   if (bp_flat_h7_ok(g)) return sr ? BP_EUNSUPPORTED : bp_flat_h7_run(in, pw, packed, bias, out, st);
-  if (bp_small_ok(g)) return sr ? BP_EUNSUPPORTED : bp_small_run(g, in, pw, packed, bias, out, st);
+  if (bp_small_ok(g)) return bp_small_run(g, in, pw, packed, bias, out, st, sr);
   const IgemmConfig c = igemm_config(g);
   if (!c.ok) return BP_EUNSUPPORTED;
   IgemmLaunch l;
@@ -1701,7 +1730,7 @@ int bp_igemm_run(const ConvGeom& g, const bp_view* in, const PW& pw, const float
   a.in_pad4 = l.wres ? c.w_in_pad4 : c.in_pad4; a.ts = c.ts; a.in_bufs = c.in_bufs;
   StatsPlan sp{};
   if (sr) {
-    if (bias || !stats_plan(g, c, l, sp) || (l.wres && sr->mode != 1)) return BP_EUNSUPPORTED;
+    if (bias || (sr->mode != 1 && sr->mode != 2) || !stats_plan(g, c, l, sp) || (l.wres && sr->mode != 1)) return BP_EUNSUPPORTED;
     if (!sr->ws || sr->ws_bytes < sp.bytes || !sr->sums) return BP_EWORKSPACE;
     a.stat = reinterpret_cast<double*>(sr->ws); a.stat_c = g.cout_g; a.stat_mode = sr->mode;
     if (sr->mode == 2) {

@@ -15,6 +15,11 @@
 #include "common.hpp"
 #include <cstdlib>
 
+// conv_igemm.hip: fold of per-workgroup rows of n doubles into sr->sums
+int bp_stats_row_stride(int n);
+size_t bp_stats_rows_bytes_n(int64_t rows, int n);
+int bp_stats_rows_finish_n(double* ws, int64_t rows, int n, const IgemmStatsReq* sr, hipStream_t st);
+
 namespace {
 
 struct SmallArgs {
@@ -26,9 +31,14 @@ struct SmallArgs {
   int ci_total;      // gathered channels of the layer (a multiple of the kernel's CI: it loops over chunks)
   int tiles_x, tiles_y;
   int in_vec, out_vec;
+  // ACT epilogue (data gradient into a layer WITHOUT batch-norm): what is stored is g = d * act'(spw(raw)) -- the
+  // producer's activation backward -- and stat gets one row {sum g, sum g*raw, sum_{t<=0} d*t} per workgroup
+  const float* raw; int raw_cs, raw_co, raw_vec;
+  PW spw;
+  double* stat; int stat_stride;
 };
 
-template <int K, int CI, int CO, int TH, bool CHUNKED>
+template <int K, int CI, int CO, int TH, bool CHUNKED, bool ACT = false>
 __global__ __launch_bounds__(256) void small_conv_kernel(SmallArgs a) {
   const int CT = CHUNKED ? a.ci_total : CI;     // gathered channels of the layer (compile-time when one tile holds them)
   constexpr int TW = 64, PXR = TH / 4;   // 4 waves x PXR rows
@@ -154,11 +164,44 @@ __global__ __launch_bounds__(256) void small_conv_kernel(SmallArgs a) {
 
   float* out_n = a.out + (int64_t)n * a.out_h * a.out_w * a.out_cs + a.out_co;
   const int X = x0 + col;
+  float es[ACT ? 3 : 1][ACT ? CO : 1];
+  if constexpr (ACT) {
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+#pragma unroll
+      for (int co = 0; co < CO; ++co) es[q][co] = 0.f;
+  }
   if (X < a.out_w) {
 #pragma unroll
     for (int j = 0; j < PXR; ++j) {
       const int Y = y0 + r0 + j;
       if (Y < a.out_h) {
+        if constexpr (ACT) {
+          // (the activation parameters are wave-uniform: scalar loads)
+          const float* rp = a.raw + (((int64_t)n * a.out_h + Y) * a.out_w + X) * a.raw_cs + a.raw_co;
+          float r[CO];
+          if (CO % 4 == 0 && a.raw_vec) {
+#pragma unroll
+            for (int q = 0; q < CO / 4; ++q) {
+              const float4 t4 = *reinterpret_cast<const float4*>(rp + 4 * q);
+              r[4 * q] = t4.x; r[4 * q + 1] = t4.y; r[4 * q + 2] = t4.z; r[4 * q + 3] = t4.w;
+            }
+          } else {
+#pragma unroll
+            for (int co = 0; co < CO; ++co) r[co] = rp[co];
+          }
+#pragma unroll
+          for (int co = 0; co < CO; ++co) {
+            const float d = acc[j][co];
+            const float t = a.spw.scale ? fmaf(r[co], a.spw.scale[co], a.spw.shift[co]) : r[co];
+            const bool pos = t > 0.f;
+            const float g = pos ? d : d * (a.spw.scale ? a.spw.slope[co] : 1.f);
+            acc[j][co] = g;
+            es[0][co] += g;
+            es[1][co] = fmaf(g, r[co], es[1][co]);
+            if (!pos) es[2][co] = fmaf(d, t, es[2][co]);
+          }
+        }
         float* o = out_n + ((int64_t)Y * a.out_w + X) * a.out_cs;
         if (CO % 4 == 0 && a.out_vec) {
 #pragma unroll
@@ -170,6 +213,26 @@ __global__ __launch_bounds__(256) void small_conv_kernel(SmallArgs a) {
           for (int co = 0; co < CO; ++co) o[co] = acc[j][co];
         }
       }
+    }
+  }
+  if constexpr (ACT) {
+    // a thread's PXR pixels and a wave's 64 columns in fp32 (256 terms), waves and workgroups in double, fixed order
+    __shared__ float ered[4][3 * CO];
+    const int lane = tid & 63, wk = tid >> 6;
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+#pragma unroll
+      for (int co = 0; co < CO; ++co) {
+        float v = es[q][co];
+#pragma unroll
+        for (int sh = 32; sh > 0; sh >>= 1) v += __shfl_down(v, sh, 64);
+        if (lane == 0) ered[wk][q * CO + co] = v;
+      }
+    __syncthreads();
+    if (tid < a.stat_stride) {                 // (rows of a power-of-two width for the fold: zero beyond 3 CO)
+      const int64_t row = (int64_t)blockIdx.y * gridDim.x + blockIdx.x;
+      a.stat[row * a.stat_stride + tid] =
+          tid < 3 * CO ? ((double)ered[0][tid] + (double)ered[1][tid]) + ((double)ered[2][tid] + (double)ered[3][tid]) : 0.0;
     }
   }
 }
@@ -344,15 +407,23 @@ __global__ void small_pack_kernel(SmallPackArgs a) {
   a.dst[i] = a.w[ci * a.sa + co * a.sb + ky * a.k + kx];
 }
 
-template <int K, int CI, int CO, int TH, bool CHUNKED = false>
+template <int K, int CI, int CO, int TH, bool CHUNKED = false, bool ACT = false>
 int launch(SmallArgs a, const bp_view* out, int n, hipStream_t st) {
   a.tiles_x = bp_ceil_div(out->w, 64);
   a.tiles_y = bp_ceil_div(out->h, TH);
-  hipLaunchKernelGGL((small_conv_kernel<K, CI, CO, TH, CHUNKED>), dim3((unsigned)(a.tiles_x * a.tiles_y), (unsigned)n),
+  hipLaunchKernelGGL((small_conv_kernel<K, CI, CO, TH, CHUNKED, ACT>), dim3((unsigned)(a.tiles_x * a.tiles_y), (unsigned)n),
                      dim3(256), 0, st, a);
   BP_CHECK_LAUNCH();
   return BP_OK;
 }
+
+// the ACT epilogue exists for the data gradient of the heads' 8 -> 1 k5 layer (gathers 1 channel, produces 8)
+bool act_geom(const ConvGeom& g) {
+  static const bool off = getenv("BP_NOACTEPI") != nullptr;
+  return !off && g.IS == 1 && g.OS == 1 && g.nphase == 1 && g.stride == 1 && g.cin_g == 1 &&
+         ((g.k == 5 && g.cout_g == 8) || (g.k == 3 && g.cout_g == 1));      // (... and of the 1 -> 1 k3 layer behind it)
+}
+int64_t act_rows(const bp_view* out) { return (int64_t)bp_ceil_div(out->w, 64) * bp_ceil_div(out->h, 16) * out->n; }
 
 }  // namespace
 
@@ -385,8 +456,15 @@ int bp_small_pack(const ConvGeom& g, const WeightMap& wm, const float* w_torch, 
   return BP_OK;
 }
 
+// mode 3 (IgemmStatsReq): activation backward of the produced slot in the epilogue; 0 = this layer has none
+size_t bp_small_stats_workspace(const ConvGeom& g, const bp_view* in, const bp_view* out, int mode) {
+  if (mode != 3 || tiny_ok(g) || !act_geom(g)) return 0;
+  return bp_stats_rows_bytes_n(act_rows(out), 3 * g.cout_g);
+}
+
 int bp_small_run(const ConvGeom& g, const bp_view* in, const PW& pw, const float* packed, const float* bias,
-                 const bp_view* out, hipStream_t st) {
+                 const bp_view* out, hipStream_t st, const IgemmStatsReq* sr) {
+  if (sr && (sr->mode != 3 || tiny_ok(g) || !act_geom(g) || bias)) return BP_EUNSUPPORTED;
   if (tiny_ok(g)) return tiny_run(g, in, pw, packed, bias, out, st);
   SmallArgs a{};
   a.in = in->ptr; a.in_h = in->h; a.in_w = in->w; a.in_cs = in->cstride; a.in_co = in->coff;
@@ -397,6 +475,18 @@ int bp_small_run(const ConvGeom& g, const bp_view* in, const PW& pw, const float
   a.out_vec = bp_view_vec4(out) ? 1 : 0;
   if (in->n > 65535) return BP_EUNSUPPORTED;
   if (g.k == 5 && g.cin_g == 8 && g.cout_g == 1) return launch<5, 8, 1, 16>(a, out, in->n, st);
+  if (sr) {
+    const bp_view* r = sr->raw;
+    const int64_t rows = act_rows(out);
+    if (!r || r->n != out->n || r->h != out->h || r->w != out->w || r->c != out->c || !sr->sums) return BP_EINVAL;
+    const int ns = 3 * g.cout_g;
+    if (!sr->ws || sr->ws_bytes < bp_stats_rows_bytes_n(rows, ns)) return BP_EWORKSPACE;
+    a.raw = r->ptr; a.raw_cs = r->cstride; a.raw_co = r->coff; a.raw_vec = bp_view_vec4(r) ? 1 : 0;
+    a.spw = sr->spw; a.stat = reinterpret_cast<double*>(sr->ws); a.stat_stride = bp_stats_row_stride(ns);
+    const int rc = g.k == 5 ? launch<5, 1, 8, 16, false, true>(a, out, in->n, st)
+                            : launch<3, 1, 1, 16, false, true>(a, out, in->n, st);
+    return rc != BP_OK ? rc : bp_stats_rows_finish_n(a.stat, rows, ns, sr, st);
+  }
   if (g.k == 5 && g.cin_g == 1 && g.cout_g == 8) return launch<5, 1, 8, 16>(a, out, in->n, st);
   if (g.k == 5 && g.cin_g == 16 && g.cout_g == 1) return launch<5, 16, 1, 8>(a, out, in->n, st);
   if (g.k == 3 && g.cin_g == 1 && g.cout_g == 1) return launch<3, 1, 1, 16>(a, out, in->n, st);

@@ -255,6 +255,16 @@ __global__ __launch_bounds__(64) void sum_partials_wave_kernel(const double* par
   if (threadIdx.x == 0) out[i] = t;
 }
 
+// ... rows of `stride` doubles of which the first n are wanted
+__global__ __launch_bounds__(64) void sum_partials_strided_kernel(const double* partial, int nblk, int stride, double* out) {
+  const int i = blockIdx.x;
+  double t = 0.0;
+  for (int b = threadIdx.x; b < nblk; b += 64) t += partial[(int64_t)b * stride + i];
+#pragma unroll
+  for (int s = 32; s > 0; s >>= 1) t += __shfl_down(t, s, 64);
+  if (threadIdx.x == 0) out[i] = t;
+}
+
 struct FastPlan { int nblk; int64_t total4, chunk4; };
 static inline FastPlan fast_plan(int64_t total_elems) {
   FastPlan f{};
@@ -868,6 +878,12 @@ __global__ __launch_bounds__(128) void sum_partials_bn_kernel(const double* part
 int bp_sum_partials_req(const double* partial, int nblk, int n, const IgemmStatsReq* sr, hipStream_t st) {
   if (!sr->fin) return bp_sum_partials(partial, nblk, n, sr->sums, st);
   hipLaunchKernelGGL(sum_partials_bn_kernel, dim3(n / 2), dim3(128), 0, st, partial, nblk, n / 2, sr->sums, *sr->fin);
+  BP_CHECK_LAUNCH();
+  return BP_OK;
+}
+
+int bp_sum_partials_strided(const double* partial, int nblk, int stride, int n, double* out, hipStream_t st) {
+  hipLaunchKernelGGL(sum_partials_strided_kernel, dim3(n), dim3(64), 0, st, partial, nblk, stride, out);
   BP_CHECK_LAUNCH();
   return BP_OK;
 }

@@ -350,6 +350,8 @@ class ConvUnit:
         self.fwd_stats = False
         self._fused_producer = None          # None: undecided; False: separate pass; a ConvUnit: fused
         self._sums_ready = False             # a consumer's data gradient has already filled self.sums
+        self._g_ready = False                # ... and stored g itself (layers without batch-norm)
+        self._act_producer = None            # None: undecided; False: separate pass; a ConvUnit: fused
         self._stats_impl = L.IMPL_BF16 if self.bf16 else L.IMPL_MFMA
         if EPILOGUE_FWD and bn is not None and holder.bias is None \
                 and (self.bf16 or (self.out.dt == L.F32 and self._impl("fwd") in (L.IMPL_AUTO, L.IMPL_MFMA))):
@@ -559,6 +561,9 @@ class ConvUnit:
                      or lib.bp_conv_kernel_id(C.byref(self.cv), L.PACK_BWD) in _BWD_KERNEL_IDS):
             self.plan.need_ws(lib.bp_conv_stats_workspace(C.byref(self.cv), L.PACK_BWD, C.byref(self.inp.view),
                                                           C.byref(self.out.view), L.IMPL_MFMA))
+        if self.dx is not None and self._sub is None and EPILOGUE_BWD and not self.bf16 and self.inp.dt == L.F32:
+            self.plan.need_ws(lib.bp_conv_backward_data_act_workspace(C.byref(self.cv), C.byref(self.out.view),
+                                                                      C.byref(self.inp.view)))
         if self.dx is not None and self._sub is not None and self._sub["target"] is None:
             c0, c1 = self.dgrad_slice
             full = self.dx
@@ -596,7 +601,11 @@ class ConvUnit:
         nstreams = 2 + (dout2 is not None) + (act_out is not None)       # tensors this pass and the apply pass read
         if self._sums_ready and g_out is None and dout2 is None and act_out is None:
             self._sums_ready = False         # the consumer's data gradient left {sum g, sum g*raw} in self.sums
+        elif self._g_ready and bn is None and dout2 is None and act_out is None and g_out is dout:
+            self._g_ready = False            # ... or did the whole pass (bp_conv_backward_data_act): g is in place
         else:
+            if self._g_ready:
+                raise RuntimeError(f"{self.name}: the fused activation backward does not match this call")
             if self._sums_ready:
                 raise RuntimeError(f"{self.name}: fused statistics do not match this activation backward")
             t0 = plan.prof_begin()
@@ -650,6 +659,24 @@ class ConvUnit:
                     self._fused_producer = p
         return self._fused_producer
 
+    def _producer_act_to_fuse(self):
+        """The producer WITHOUT batch-norm whose whole activation backward this layer's data gradient can do in its
+        epilogue (bp_conv_backward_data_act): only producer / only consumer of ``inp``, fp32, and a kernel that has
+        the epilogue (the vector-ALU data gradient of the heads' 8 -> 1 k5 layer)."""
+        if self._act_producer is None:
+            self._act_producer = False
+            p = getattr(self.inp, "producer", None)
+            if EPILOGUE_BWD and isinstance(p, ConvUnit) and p.out is self.inp and p.bn is None and p.has_pw \
+                    and p.act in ("relu", "leaky relu", "prelu") and p.plan is self.plan and p.ws_name == self.ws_name \
+                    and self.inp.n_consumers == 1 and self.inp.grad2 is None and self.inp.dt == L.F32 \
+                    and self.out.dt == L.F32 and self._sub is None and not self.bf16 and self.packed_bwd is not None \
+                    and self._impl("dgrad") in (L.IMPL_AUTO, L.IMPL_MFMA) and self.dx is not None:
+                nb = self.plan.lib.bp_conv_backward_data_act_workspace(C.byref(self.cv), C.byref(self.out.view),
+                                                                       C.byref(self.inp.view))
+                if 0 < nb <= self.plan.ws_bytes:
+                    self._act_producer = p
+        return self._act_producer
+
     def conv_backward(self, grads):
         """Weight gradient and data gradient of this layer from d_raw (``out.grad``).
 
@@ -687,8 +714,15 @@ class ConvUnit:
                 wgrad(side_ws)
         if self.dx is not None:
             prod = self._producer_to_fuse()
+            aprod = None if prod else self._producer_act_to_fuse()
             t0 = plan.prof_begin()
-            if prod:
+            if aprod:
+                L.check(lib.bp_conv_backward_data_act(C.byref(self.cv), C.byref(g), L.ptr(self.packed_bwd),
+                                                      C.byref(self.dx), C.byref(self.inp.view), self.inp.pw_struct(),
+                                                      L.ptr(aprod.sums), L.ptr(self._ws()), plan.ws_bytes, st),
+                        f"{self.name} backward_data + {aprod.name} activation backward")
+                aprod._g_ready = True
+            elif prod:
                 L.check(lib.bp_conv_backward_data_stats(C.byref(self.cv), C.byref(g), L.ptr(self.packed_bwd),
                                                         C.byref(self.dx), C.byref(self.inp.view),
                                                         self.inp.pw_struct(), L.ptr(prod.sums), L.ptr(self._ws()),

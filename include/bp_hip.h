@@ -151,6 +151,18 @@ int bp_conv_backward_data_stats(const bp_conv* cv, const bp_view* dy, const floa
                                 const bp_view* x_raw, const bp_pointwise* x_pw, double* sums, void* workspace,
                                 size_t workspace_bytes, void* stream);
 
+/* Data gradient + the producer's WHOLE activation backward in one launch, for a producer without batch-norm (the
+ * heads' PReLU layers, cvae.py:57-58 via utils.py:135): what is stored is g = dx * act'(x_pw(x_raw)) -- exactly what
+ * bp_act_backward(dx, NULL, x_raw, x_pw, NULL, g = dx, ...) would leave in place of dx -- and sums[3*cin] are its
+ * three sums {sum g, sum g*x_raw, sum_{t<=0} dx*t} (the last is the PReLU slope gradient, bp_prelu_slope_grad).
+ * Saves the separate pass' read of dx and its write of g (x_raw is read either way).
+ * bp_conv_backward_data_act_workspace: bytes of workspace, 0 = this layer's kernel has no such epilogue (only the
+ * vector-ALU kernel of the 8 -> 1 k5 layer has one: 0.35 ms of a 15 ms bf16 step). */
+size_t bp_conv_backward_data_act_workspace(const bp_conv* cv, const bp_view* dy, const bp_view* g);
+int bp_conv_backward_data_act(const bp_conv* cv, const bp_view* dy, const float* packed_bwd, const bp_view* g,
+                              const bp_view* x_raw, const bp_pointwise* x_pw, double* sums, void* workspace,
+                              size_t workspace_bytes, void* stream);
+
 /* bp_conv_forward_stats followed by bp_bn_finalize(sums, ...) of the produced tensor, with the finalize folded into
  * the launch that sums the epilogue's partial rows (one small launch less per batch-norm layer and step; the same
  * numbers bit for bit).  Single-device training only: under data parallelism the sums are all-reduced between the two

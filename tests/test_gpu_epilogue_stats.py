@@ -158,6 +158,78 @@ def test_activation_backward_sums_from_the_data_gradient_epilogue(case):
     assert _close(got[ci:2 * ci], ref[ci:2 * ci], np.abs(g_ref * raw64).sum(axis=(0, 2, 3)), 1e-6)
 
 
+@pytest.mark.parametrize("shape", [(3, 37, 70), (2, 64, 128), (5, 130, 200)], ids=["ragged", "tiles", "fold"])
+@pytest.mark.parametrize("aligned", [True, False], ids=["vec", "scalar"])
+@pytest.mark.parametrize("layer", [(8, 5, 2), (1, 3, 1)], ids=["8to1_k5", "1to1_k3"])
+def test_data_gradient_with_the_whole_activation_backward(shape, aligned, layer):
+    """bp_conv_backward_data_act (the heads' 8 -> 1 k5 and 1 -> 1 k3 layers): g = dx * act'(pw(raw)) stored in place
+    of dx and the three sums of bp_act_backward, against the two separate launches and the float64 oracle."""
+    lib = L.load()
+    ci, k, p = layer
+    co, s = 1, 1
+    n, h, w = shape
+    rng = np.random.default_rng(11)
+    wt = (rng.standard_normal((co, ci, k, k)) * 0.1).astype(np.float32)
+    dy = rng.standard_normal((n, co, h, w)).astype(np.float32)
+    raw = rng.standard_normal((n, ci, h, w)).astype(np.float32)
+    scale = rng.uniform(0.5, 1.5, ci).astype(np.float32)
+    shift = rng.uniform(-0.4, 0.4, ci).astype(np.float32)
+    slope = rng.uniform(0.05, 0.3, ci).astype(np.float32)
+    dx_ref = ops.conv2d_bwd_data(dy.astype(np.float64), wt.astype(np.float64), s, p, h, w)
+    t = raw.astype(np.float64) * scale[None, :, None, None] + shift[None, :, None, None]
+    g_ref = np.where(t > 0, dx_ref, dx_ref * slope[None, :, None, None])
+    cv = L.Conv(0, ci, co, k, s, p, 0)
+    st = G.stream()
+    dyb, dyv = G.to_nhwc(dy)
+    rb, rv = G.to_nhwc(raw) if aligned else G.to_nhwc(raw, cstride=ci + 3, coff=1)
+    gb, gv = G.empty_nhwc(n, h, w, ci) if aligned else G.empty_nhwc(n, h, w, ci, cstride=ci + 2, coff=1)
+    keep, pw = G.pointwise(scale, shift, slope)
+    wd = G.dev(wt)
+    pb = torch.zeros(lib.bp_conv_packed_floats(C.byref(cv), L.PACK_BWD), device="cuda")
+    L.check(lib.bp_conv_pack(C.byref(cv), L.PACK_BWD, L.ptr(wd), L.ptr(pb), st))
+    nb = lib.bp_conv_backward_data_act_workspace(C.byref(cv), C.byref(dyv), C.byref(gv))
+    assert nb > 0
+    sums = torch.full((3 * ci,), float("nan"), dtype=torch.float64, device="cuda")
+    ws = torch.full((nb // 8 + 8,), float("nan"), dtype=torch.float64, device="cuda")
+    L.check(lib.bp_conv_backward_data_act(C.byref(cv), C.byref(dyv), L.ptr(pb), C.byref(gv), C.byref(rv), C.byref(pw),
+                                          L.ptr(sums), L.ptr(ws), nb, st), "backward_data + activation backward")
+    coff = 0 if aligned else 1
+    assert G.rel_err(G.from_nhwc(gb, ci, coff=coff), g_ref) < 2e-5
+    if not aligned:
+        assert torch.isnan(gb[..., :1]).all() and torch.isnan(gb[..., 1 + ci:]).all(), "stores outside the view"
+    got = sums.cpu().numpy()
+    raw64 = raw.astype(np.float64)
+    refs = [g_ref.sum(axis=(0, 2, 3)), (g_ref * raw64).sum(axis=(0, 2, 3)), np.where(t > 0, 0.0, dx_ref * t).sum(axis=(0, 2, 3))]
+    mags = [np.abs(g_ref).sum(axis=(0, 2, 3)), np.abs(g_ref * raw64).sum(axis=(0, 2, 3)),
+            np.abs(np.where(t > 0, 0.0, dx_ref * t)).sum(axis=(0, 2, 3))]
+    for q in range(3):
+        assert _close(got[q * ci:(q + 1) * ci], refs[q], mags[q]), q
+    # the two separate launches: data gradient, then bp_act_backward writing g over it
+    dxb, dxv = G.empty_nhwc(n, h, w, ci)
+    L.check(lib.bp_conv_backward_data(C.byref(cv), C.byref(dyv), L.ptr(pb), L.ptr(wd), C.byref(dxv), L.IMPL_MFMA, st))
+    ref = torch.zeros(3 * ci, dtype=torch.float64, device="cuda")
+    r2b, r2v = G.to_nhwc(raw)
+    nb2 = lib.bp_act_backward_workspace(C.byref(r2v))
+    ws2 = torch.zeros(nb2 // 8 + 8, dtype=torch.float64, device="cuda")
+    L.check(lib.bp_act_backward(C.byref(dxv), None, C.byref(r2v), C.byref(pw), None, C.byref(dxv), L.ptr(ref),
+                                L.ptr(ws2), nb2, st))
+    assert torch.equal(G_from(dxb), G_from(gb[..., coff:coff + ci])), "g differs from the two-pass result"
+    ref = ref.cpu().numpy()
+    for q in range(3):
+        assert _close(got[q * ci:(q + 1) * ci], ref[q * ci:(q + 1) * ci], mags[q], 1e-6), q
+    assert lib.bp_conv_backward_data_act(C.byref(cv), C.byref(dyv), L.ptr(pb), C.byref(gv), C.byref(rv), C.byref(pw),
+                                         L.ptr(sums), L.ptr(ws), nb - 8, st) == -4
+    # a layer whose kernel has no such epilogue says so
+    cv2 = L.Conv(0, 16, 8, 7, 1, 3, 0)
+    d2b, d2v = G.empty_nhwc(n, h, w, 8)
+    g2b, g2v = G.empty_nhwc(n, h, w, 16)
+    assert lib.bp_conv_backward_data_act_workspace(C.byref(cv2), C.byref(d2v), C.byref(g2v)) == 0
+
+
+def G_from(t):
+    return t.contiguous()
+
+
 def test_statistics_are_refused_where_the_kernel_has_none():
     """Pixel-packed heads (<= 8 produced channels) and the vector-ALU layers keep the separate passes."""
     lib = L.load()

@@ -28,3 +28,4 @@ unset BP_SIDE_WGRAD BP_BRANCH_STREAMS
 cd $R
 python bench.py --steps 20 --warmup 5 > $F/bench_default.json 2> $F/bench_default.err; echo "bench rc=$?"
 tail -c 600 $F/bench_default.json
+for d in f32 bf16; do python tools/phase_times.py $d 20 > $F/phase_times_$d.txt 2>/dev/null; cat $F/phase_times_$d.txt; done
