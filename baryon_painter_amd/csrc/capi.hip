@@ -27,7 +27,7 @@ int64_t bp_bf16_packed_elems(const ConvGeom& g);
 int bp_bf16_pack(const ConvGeom& g, const WeightMap& wm, const float* w_torch, void* packed, hipStream_t st);
 int bp_bf16_igemm_run(const ConvGeom& g, const bp_view* in, const PW& pw, const void* packed, const float* bias,
                       const bp_view* out, hipStream_t st, const IgemmStatsReq* stats = nullptr);
-size_t bp_bf16_stats_workspace(const ConvGeom& g, const bp_view* in, const bp_view* out);
+size_t bp_bf16_stats_workspace(const ConvGeom& g, const bp_view* in, const bp_view* out, int mode);
 size_t bp_wgrad_bf16_workspace(const bp_conv* cv, const bp_view* X, const bp_view* Y);
 int bp_wgrad_bf16_run(const bp_conv* cv, const bp_view* X, const PW& pwx, const bp_view* Y, const PW& pwy, float* dst,
                       void* workspace, size_t workspace_bytes, hipStream_t st);
@@ -149,7 +149,9 @@ int bp_conv_forward(const bp_conv* cv, const bp_view* x, const bp_pointwise* x_p
 
 size_t bp_conv_stats_workspace(const bp_conv* cv, int dir, const bp_view* x, const bp_view* y, int impl) {
   if (!conv_ok(cv) || !shapes_ok(cv, x, y, impl == BP_IMPL_BF16) || (dir != BP_PACK_FWD && dir != BP_PACK_BWD)) return 0;
-  if (impl == BP_IMPL_BF16) return dir == BP_PACK_FWD ? bp_bf16_stats_workspace(bp_geom_forward(cv), x, y) : 0;
+  if (impl == BP_IMPL_BF16)
+    return dir == BP_PACK_FWD ? bp_bf16_stats_workspace(bp_geom_forward(cv), x, y, 1)
+                              : bp_bf16_stats_workspace(bp_geom_backward_data(cv), y, x, 2);
   return dir == BP_PACK_FWD ? bp_igemm_stats_workspace(bp_geom_forward(cv), x, y, 1)
                             : bp_igemm_stats_workspace(bp_geom_backward_data(cv), y, x, 2);
 }
@@ -181,9 +183,14 @@ int bp_conv_forward_bn(const bp_conv* cv, const bp_view* x, const bp_pointwise* 
 int bp_conv_backward_data_stats(const bp_conv* cv, const bp_view* dy, const float* packed_bwd, const bp_view* dx,
                                 const bp_view* x_raw, const bp_pointwise* x_pw, double* sums, void* workspace,
                                 size_t workspace_bytes, void* stream) {
-  if (!conv_ok(cv) || !shapes_ok(cv, dx, dy) || !packed_bwd || !sums || !bp_view_ok(x_raw)) return BP_EINVAL;
+  const bool b16 = (dy && dy->dtype == BP_BF16) || (dx && dx->dtype == BP_BF16);        // the bf16 kernels' epilogue
+  if (!conv_ok(cv) || !shapes_ok(cv, dx, dy, b16) || !packed_bwd || !sums || !bp_view_ok_any(x_raw)) return BP_EINVAL;
   if (x_raw->n != dx->n || x_raw->h != dx->h || x_raw->w != dx->w || x_raw->c != dx->c) return BP_EINVAL;
   const IgemmStatsReq sr{2, x_raw, bp_pw(x_pw), sums, workspace, workspace_bytes};
+  if (b16)
+    return bp_bf16_igemm_run(bp_geom_backward_data(cv), dy, PW{nullptr, nullptr, nullptr}, packed_bwd, nullptr, dx,
+                             bp_stream(stream), &sr);
+  if (!bp_view_ok(x_raw)) return BP_EINVAL;
   return bp_igemm_run(bp_geom_backward_data(cv), dy, PW{nullptr, nullptr, nullptr}, packed_bwd, nullptr, dx,
                       bp_stream(stream), &sr);
 }

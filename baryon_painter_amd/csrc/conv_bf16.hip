@@ -12,8 +12,8 @@ int bp_bf16_launch_cc32(const BConfig& c, const BArgs& a, bool in_bf16, bool out
 // conv_bf16_flat.hip: flattened-K kernel for the unit-stride k7 head layers; its weight image follows the generic one
 int64_t bp_bf16_flat_packed_elems(const ConvGeom& g);
 int bp_bf16_flat_pack(const ConvGeom& g, const WeightMap& wm, const float* w_torch, u16* dst, hipStream_t st);
-bool bp_bf16_flat_ok(const ConvGeom& g, const bp_view* in, const bp_view* out, const float* bias, bool stats);
-size_t bp_bf16_flat_stats_workspace(const ConvGeom& g, const bp_view* in, const bp_view* out);
+bool bp_bf16_flat_ok(const ConvGeom& g, const bp_view* in, const bp_view* out, const float* bias, int stats);
+size_t bp_bf16_flat_stats_workspace(const ConvGeom& g, const bp_view* in, const bp_view* out, int mode);
 int bp_bf16_flat_run(const ConvGeom& g, const bp_view* in, const PW& pw, const u16* packed_flat, const bp_view* out,
                      hipStream_t st, const IgemmStatsReq* sr);
 
@@ -118,10 +118,11 @@ static int64_t bf16_stat_rows(const ConvGeom& g, const BConfig& c, const bp_view
 }
 
 // workspace for bp_bf16_igemm_run with statistics (0: not available for this layer / these views)
-size_t bp_bf16_stats_workspace(const ConvGeom& g, const bp_view* in, const bp_view* out) {
+size_t bp_bf16_stats_workspace(const ConvGeom& g, const bp_view* in, const bp_view* out, int mode) {
   const BConfig c = b_config(g);
   if (!c.ok || !bp_bf16_igemm_ok(g, in, out)) return 0;
-  if (bp_bf16_flat_ok(g, in, out, nullptr, true)) return bp_bf16_flat_stats_workspace(g, in, out);
+  if (bp_bf16_flat_ok(g, in, out, nullptr, mode)) return bp_bf16_flat_stats_workspace(g, in, out, mode);
+  if (mode != 1) return 0;                                    // (mode 2: the two flattened-K kernels only)
   return bp_stats_rows_bytes(bf16_stat_rows(g, c, in, out), g.cout_g);
 }
 
@@ -129,7 +130,7 @@ int bp_bf16_igemm_run(const ConvGeom& g, const bp_view* in, const PW& pw, const 
                       const bp_view* out, hipStream_t st, const IgemmStatsReq* sr) {
   const BConfig c = b_config(g);
   if (!c.ok || !bp_bf16_igemm_ok(g, in, out)) return BP_EUNSUPPORTED;
-  if (bp_bf16_flat_ok(g, in, out, bias, sr != nullptr))
+  if (bp_bf16_flat_ok(g, in, out, bias, sr ? sr->mode : 0))
     return bp_bf16_flat_run(g, in, pw, reinterpret_cast<const u16*>(packed) + generic_packed_elems(g, c), out, st, sr);
   BArgs a{};
   a.in = in->ptr; a.in_h = in->h; a.in_w = in->w; a.in_cs = in->cstride; a.in_co = in->coff; a.cin = g.cin_g;

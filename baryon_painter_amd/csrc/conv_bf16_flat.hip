@@ -43,6 +43,10 @@ struct FbArgs {
   PW pw;
   int tiles_x, tiles_y, n;
   double* stat; int stat_c;
+  // STATS == 2 (data gradient into a bf16 slot with batch-norm): the produced tensor is d(loss)/d(activated slot);
+  // raw / spw = the slot's raw values and pending activation -> rows of {sum g, sum g*raw}, g = d * act'(spw(raw))
+  const u16* raw; int raw_cs, raw_co;
+  PW spw;
 };
 
 constexpr int FB_TW = 64, FB_TH = 16, FB_R = 4;
@@ -65,7 +69,7 @@ __device__ __forceinline__ int fb_tile_of_block(int n) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
-template <int KS, int CIN, int COUTP, bool IN_BF16, bool OUT_BF16, bool STATS>
+template <int KS, int CIN, int COUTP, bool IN_BF16, bool OUT_BF16, int STATS>
 __global__ __launch_bounds__(256, 3) void flatb_kernel(FbArgs a) {
   using S = FbShape<KS, CIN>;
   constexpr int KB = S::KB, ROWE = S::ROWE, LH = S::LH, PAD = KS / 2;
@@ -182,11 +186,28 @@ __global__ __launch_bounds__(256, 3) void flatb_kernel(FbArgs a) {
   const int rs_l = (kg * 4) / COUTP;            // which output row of an MFMA this lane's 4 accumulator rows hold
   const int co_l = (kg * 4) % COUTP;
   float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};       // STATS: this lane's 4 channels
+  float psc[4] = {1.f, 1.f, 1.f, 1.f}, psf[4] = {0.f, 0.f, 0.f, 0.f}, psl[4] = {1.f, 1.f, 1.f, 1.f};
+  if constexpr (STATS == 2) {
+    if (a.spw.scale) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { psc[r] = a.spw.scale[co_l + r]; psf[r] = a.spw.shift[co_l + r]; psl[r] = a.spw.slope[co_l + r]; }
+    }
+  }
 #pragma unroll 1
   for (int pass = 0; pass < FB_TH / FB_R; ++pass) {
     v4f acc[NS];
 #pragma unroll
     for (int s = 0; s < NS; ++s) acc[s] = v4f{0.f, 0.f, 0.f, 0.f};
+    // STATS == 2: the slot's raw values under this pass's outputs, requested ahead of the MFMA chain
+    uint2 rw[STATS == 2 ? NS : 1];
+    if constexpr (STATS == 2) {
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        const int oy = min(ty0 + pass * FB_R + s * RS + rs_l, a.h - 1), oxc = min(ox, a.w - 1);
+        rw[s] = *reinterpret_cast<const uint2*>(a.raw + ((int64_t)(n * a.h + oy) * a.w + oxc) * a.raw_cs + a.raw_co + co_l);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
     const u16* base = lds + (pass * FB_R) * ROWE + fbase;
 #pragma unroll
     for (int jr = 0; jr < FB_R + KS - 1; ++jr) {
@@ -219,12 +240,24 @@ __global__ __launch_bounds__(256, 3) void flatb_kernel(FbArgs a) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) if (co_l + r < a.cout) q[r] = acc[s][r];
       }
-      if constexpr (STATS) {
+      if constexpr (STATS == 1) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           float v = acc[s][r];
           if constexpr (OUT_BF16) v = bf2f(f2bf(v));
           s1[r] += v; s2[r] = fmaf(v, v, s2[r]);
+        }
+      }
+      if constexpr (STATS == 2) {
+        const float rv[4] = {bf2f((u16)(rw[s].x & 0xffffu)), bf2f((u16)(rw[s].x >> 16)), bf2f((u16)(rw[s].y & 0xffffu)),
+                             bf2f((u16)(rw[s].y >> 16))};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float d = acc[s][r];
+          if constexpr (OUT_BF16) d = bf2f(f2bf(d));                 // (what the separate pass would read back)
+          const float t = fmaf(rv[r], psc[r], psf[r]);
+          const float g = t > 0.f ? d : d * psl[r];
+          s1[r] += g; s2[r] = fmaf(g, rv[r], s2[r]);
         }
       }
     }
@@ -270,19 +303,22 @@ struct FtArgs {
   PW pw;
   int tiles_x, tiles_y, n;
   double* stat; int stat_c;
+  const u16* raw; int raw_cs, raw_co;             // STATS == 2 (see FbArgs)
+  PW spw;
 };
 
 constexpr int FT_TW = 32, FT_TH = 16, FT_LW = FT_TW + 2, FT_LH = FT_TH + 2, FT_C = 32;
 constexpr int FT_ROWE = FT_LW * FT_C;
-constexpr size_t FT_LDS = ((size_t)FT_LH * FT_ROWE) * 2 + 3 * FT_C * sizeof(float) + 4 * 32 * sizeof(double);
+constexpr size_t FT_LDS = ((size_t)FT_LH * FT_ROWE) * 2 + 3 * FT_C * sizeof(float) + 4 * 32 * sizeof(double) + 3 * 16 * sizeof(float);
 
-template <bool STATS>
+template <int STATS>
 __global__ __launch_bounds__(256, 3) void flatb_t2_kernel(FtArgs a) {
   constexpr int NU = FT_LH * FT_LW * 4, SLOTS = (NU + 255) / 256;       // 8-channel units
   extern __shared__ __attribute__((aligned(16))) u16 smem_fb[];
   u16* lds = smem_fb;
   float* lpw = reinterpret_cast<float*>(lds + FT_LH * FT_ROWE);
   double* red = reinterpret_cast<double*>(lpw + 3 * FT_C);
+  float* lspw = reinterpret_cast<float*>(red + 4 * 32);      // STATS == 2: the produced slot's activation (registers are full)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lj = lane & 15, kg = lane >> 4;
@@ -305,6 +341,12 @@ __global__ __launch_bounds__(256, 3) void flatb_t2_kernel(FtArgs a) {
   }
   const bool on = a.pw.scale != nullptr;
   if (on && tid < FT_C) { lpw[tid] = a.pw.scale[tid]; lpw[FT_C + tid] = a.pw.shift[tid]; lpw[2 * FT_C + tid] = a.pw.slope[tid]; }
+  if constexpr (STATS == 2) {
+    if (tid < 16) {
+      const bool son = a.spw.scale != nullptr;
+      lspw[tid] = son ? a.spw.scale[tid] : 1.f; lspw[16 + tid] = son ? a.spw.shift[tid] : 0.f; lspw[32 + tid] = son ? a.spw.slope[tid] : 1.f;
+    }
+  }
   __syncthreads();
   {
     const int c0 = (tid & 3) * 8;
@@ -376,7 +418,15 @@ __global__ __launch_bounds__(256, 3) void flatb_t2_kernel(FtArgs a) {
         }
     }
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
+    for (int r = 0; r < 4; ++r) {
+      uint2 rw[STATS == 2 ? 4 : 1];
+      if constexpr (STATS == 2) {          // the slot's raw values under this coarse row's four phases, loaded together
+#pragma unroll
+        for (int ph = 0; ph < 4; ++ph) {
+          const int oy = min(2 * (ty0 + r0 + r) + (ph >> 1), a.oh - 1), ox = min(oxb + (ph & 1), a.ow - 1);
+          rw[ph] = *reinterpret_cast<const uint2*>(a.raw + ((int64_t)(n * a.oh + oy) * a.ow + ox) * a.raw_cs + a.raw_co + kg * 4);
+        }
+      }
 #pragma unroll
       for (int ph = 0; ph < 4; ++ph) {
         const int oy = 2 * (ty0 + r0 + r) + (ph >> 1), ox = oxb + (ph & 1);
@@ -384,11 +434,23 @@ __global__ __launch_bounds__(256, 3) void flatb_t2_kernel(FtArgs a) {
         const int64_t o = ((int64_t)(n * a.oh + oy) * a.ow + ox) * a.out_cs + a.out_co + kg * 4;
         *reinterpret_cast<uint2*>(reinterpret_cast<u16*>(a.out) + o) =
             make_uint2(pack2(acc[r][ph][0], acc[r][ph][1]), pack2(acc[r][ph][2], acc[r][ph][3]));
-        if constexpr (STATS) {
+        if constexpr (STATS == 1) {
 #pragma unroll
           for (int q = 0; q < 4; ++q) { const float v = bf2f(f2bf(acc[r][ph][q])); s1[q] += v; s2[q] = fmaf(v, v, s2[q]); }
         }
+        if constexpr (STATS == 2) {
+          const float rv[4] = {bf2f((u16)(rw[ph].x & 0xffffu)), bf2f((u16)(rw[ph].x >> 16)), bf2f((u16)(rw[ph].y & 0xffffu)),
+                               bf2f((u16)(rw[ph].y >> 16))};
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float d = bf2f(f2bf(acc[r][ph][q]));
+            const float t = fmaf(rv[q], lspw[kg * 4 + q], lspw[16 + kg * 4 + q]);
+            const float g = t > 0.f ? d : d * lspw[32 + kg * 4 + q];
+            s1[q] += g; s2[q] = fmaf(g, rv[q], s2[q]);
+          }
+        }
       }
+    }
   }
   if constexpr (STATS) {
     double d1[4], d2[4];
@@ -957,7 +1019,7 @@ static FbKind fb_kind(const ConvGeom& g) {
   return none;
 }
 
-template <int KS, int CIN, int COUTP, bool IB, bool OB, bool ST>
+template <int KS, int CIN, int COUTP, bool IB, bool OB, int ST>
 static void fb_launch(const FbArgs& a, dim3 grid, hipStream_t st) {
   auto k = flatb_kernel<KS, CIN, COUTP, IB, OB, ST>;
   constexpr size_t lds = FbShape<KS, CIN>::LDS;
@@ -1024,11 +1086,13 @@ static bool f2_ok(const FbKind& f, const bp_view* in, const bp_view* out) {
   return f2_tiles(f.kind, in, out, &tx, &ty) < (1ll << 31);
 }
 
-bool bp_bf16_flat_ok(const ConvGeom& g, const bp_view* in, const bp_view* out, const float* bias, bool stats) {
+// stats: 0 none, 1 {sum y, sum y^2} of the produced tensor, 2 {sum g, sum g*raw} of a data gradient (IgemmStatsReq)
+bool bp_bf16_flat_ok(const ConvGeom& g, const bp_view* in, const bp_view* out, const float* bias, int stats) {
   const FbKind f = fb_kind(g);
   if (!f.kind || bias || !in || !out) return false;
-  if (f.kind >= 5) return f2_ok(f, in, out);
-  if (stats && f.kind != 3) return false;
+  if (f.kind >= 5) return f2_ok(f, in, out) && (stats != 2 || f.kind == 5);
+  if (stats == 1 && f.kind != 3) return false;
+  if (stats == 2 && f.kind != 2) return false;
   if (in->c != g.cin_g || out->c != g.cout_g || in->h != out->h || in->w != out->w || in->n != out->n) return false;
   const bool ib = in->dtype == BP_BF16, ob = out->dtype == BP_BF16;
   // element types of the instances: the bf16 trunk on one side, the fp32 few-channel edge on the other
@@ -1042,8 +1106,8 @@ bool bp_bf16_flat_ok(const ConvGeom& g, const bp_view* in, const bp_view* out, c
   return fb_tiles(out) < (1ll << 31);
 }
 
-size_t bp_bf16_flat_stats_workspace(const ConvGeom& g, const bp_view* in, const bp_view* out) {
-  if (!bp_bf16_flat_ok(g, in, out, nullptr, true)) return 0;
+size_t bp_bf16_flat_stats_workspace(const ConvGeom& g, const bp_view* in, const bp_view* out, int mode) {
+  if (!bp_bf16_flat_ok(g, in, out, nullptr, mode)) return 0;
   const FbKind f = fb_kind(g);
   if (f.kind >= 5) {
     int tx, ty;
@@ -1061,11 +1125,26 @@ int bp_bf16_flat_run(const ConvGeom& g, const bp_view* in, const PW& pw, const u
     double* stat = nullptr;
     if (sr) {
       const size_t need = bp_stats_rows_bytes(rows, g.cout_g);
-      if (sr->mode != 1 || !need) return BP_EUNSUPPORTED;
+      if ((sr->mode != 1 && !(sr->mode == 2 && f.kind == 5)) || !need) return BP_EUNSUPPORTED;
       if (!sr->ws || sr->ws_bytes < need || !sr->sums) return BP_EWORKSPACE;
       stat = reinterpret_cast<double*>(sr->ws);
     }
     const dim3 grid((unsigned)rows), block(256);
+    if (sr && sr->mode == 2) {          // T form 32 -> 16 as a data gradient: the producer's activation sums
+      const bp_view* r = sr->raw;
+      if (!r || r->dtype != BP_BF16 || r->n != out->n || r->h != out->h || r->w != out->w || r->c != out->c ||
+          r->cstride % 4 || r->coff % 4 || reinterpret_cast<uintptr_t>(r->ptr) % 8)
+        return BP_EUNSUPPORTED;
+      FtArgs t{reinterpret_cast<const u16*>(in->ptr), in->h, in->w, in->cstride, in->coff, out->ptr, out->h, out->w,
+               out->cstride, out->coff, packed_flat, pw, tx, ty, in->n, stat, g.cout_g,
+               reinterpret_cast<const u16*>(r->ptr), r->cstride, r->coff, sr->spw};
+      static const int once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(flatb_t2_kernel<2>),
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)FT_LDS), 0);
+      (void)once;
+      hipLaunchKernelGGL(flatb_t2_kernel<2>, grid, block, FT_LDS, st, t);
+      BP_CHECK_LAUNCH();
+      return bp_stats_rows_finish(stat, rows, g.cout_g, sr, st);
+    }
 #define BP_F2(KERNEL, ARGS, LDS_)                                                                                        \
     do {                                                                                                               \
       static const int once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(KERNEL<true>),                  \
@@ -1078,7 +1157,7 @@ int bp_bf16_flat_run(const ConvGeom& g, const bp_view* in, const PW& pw, const u
     } while (0)
     if (f.kind == 5 || f.kind == 7) {
       FtArgs t{reinterpret_cast<const u16*>(in->ptr), in->h, in->w, in->cstride, in->coff, out->ptr, out->h, out->w,
-               out->cstride, out->coff, packed_flat, pw, tx, ty, in->n, stat, g.cout_g};
+               out->cstride, out->coff, packed_flat, pw, tx, ty, in->n, stat, g.cout_g, nullptr, 0, 0, PW{nullptr, nullptr, nullptr}};
       if (f.kind == 5) BP_F2(flatb_t2_kernel, t, FT_LDS);
       else BP_F2(flatb_t2w_kernel, t, GT_LDS);
     } else {
@@ -1100,18 +1179,27 @@ int bp_bf16_flat_run(const ConvGeom& g, const bp_view* in, const PW& pw, const u
   const int64_t rows = fb_tiles(out);
   if (sr) {
     const size_t need = bp_stats_rows_bytes(rows, g.cout_g);
-    if (sr->mode != 1 || !need) return BP_EUNSUPPORTED;
+    if (!((sr->mode == 1 && f.kind == 3) || (sr->mode == 2 && f.kind == 2)) || !need) return BP_EUNSUPPORTED;
     if (!sr->ws || sr->ws_bytes < need || !sr->sums) return BP_EWORKSPACE;
     a.stat = reinterpret_cast<double*>(sr->ws); a.stat_c = g.cout_g;
+    if (sr->mode == 2) {
+      const bp_view* r = sr->raw;
+      if (!r || r->dtype != BP_BF16 || r->n != out->n || r->h != out->h || r->w != out->w || r->c != out->c ||
+          r->cstride % 4 || r->coff % 4 || reinterpret_cast<uintptr_t>(r->ptr) % 8)
+        return BP_EUNSUPPORTED;
+      a.raw = reinterpret_cast<const u16*>(r->ptr); a.raw_cs = r->cstride; a.raw_co = r->coff; a.spw = sr->spw;
+    }
   }
   const dim3 grid((unsigned)rows);
   switch (f.kind) {
-    case 1: fb_launch<7, 16, 8, true, false, false>(a, grid, st); break;
-    case 2: fb_launch<7, 8, 16, false, true, false>(a, grid, st); break;
-    case 3: if (sr) fb_launch<5, 4, 16, false, true, true>(a, grid, st);
-            else fb_launch<5, 4, 16, false, true, false>(a, grid, st);
+    case 1: fb_launch<7, 16, 8, true, false, 0>(a, grid, st); break;
+    case 2: if (sr) fb_launch<7, 8, 16, false, true, 2>(a, grid, st);
+            else fb_launch<7, 8, 16, false, true, 0>(a, grid, st);
             break;
-    case 4: fb_launch<5, 16, 4, true, false, false>(a, grid, st); break;
+    case 3: if (sr) fb_launch<5, 4, 16, false, true, 1>(a, grid, st);
+            else fb_launch<5, 4, 16, false, true, 0>(a, grid, st);
+            break;
+    case 4: fb_launch<5, 16, 4, true, false, 0>(a, grid, st); break;
     default: return BP_EUNSUPPORTED;
   }
   BP_CHECK_LAUNCH();

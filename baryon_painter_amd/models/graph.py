@@ -561,6 +561,10 @@ class ConvUnit:
                      or lib.bp_conv_kernel_id(C.byref(self.cv), L.PACK_BWD) in _BWD_KERNEL_IDS):
             self.plan.need_ws(lib.bp_conv_stats_workspace(C.byref(self.cv), L.PACK_BWD, C.byref(self.inp.view),
                                                           C.byref(self.out.view), L.IMPL_MFMA))
+        if self.dx is not None and self._sub is None and EPILOGUE_BWD and self.bf16 and self.inp.dt == L.BF16 \
+                and os.environ.get("BP_BF16_BWD_STATS", "1") != "0":
+            self.plan.need_ws(lib.bp_conv_stats_workspace(C.byref(self.cv), L.PACK_BWD, C.byref(self.inp.view),
+                                                          C.byref(self.out.view), L.IMPL_BF16))
         if self.dx is not None and self._sub is None and EPILOGUE_BWD and not self.bf16 and self.inp.dt == L.F32:
             self.plan.need_ws(lib.bp_conv_backward_data_act_workspace(C.byref(self.cv), C.byref(self.out.view),
                                                                       C.byref(self.inp.view)))
@@ -645,16 +649,22 @@ class ConvUnit:
         if self._fused_producer is None:
             self._fused_producer = False
             p = getattr(self.inp, "producer", None)
-            if EPILOGUE_BWD and isinstance(p, ConvUnit) and p.out is self.inp and p.bn is not None \
-                    and p.act in (None, "relu", "leaky relu") and p.plan is self.plan and p.ws_name == self.ws_name \
-                    and self.inp.n_consumers == 1 and self.inp.grad2 is None and self.inp.dt == L.F32 \
-                    and self._sub is None and not self.bf16 and self.packed_bwd is not None \
-                    and self._impl("dgrad") in (L.IMPL_AUTO, L.IMPL_MFMA):
+            common = EPILOGUE_BWD and isinstance(p, ConvUnit) and p.out is self.inp and p.bn is not None \
+                and p.act in (None, "relu", "leaky relu") and p.plan is self.plan and p.ws_name == self.ws_name \
+                and self.inp.n_consumers == 1 and self.inp.grad2 is None and self._sub is None \
+                and self.packed_bwd is not None
+            if common and not self.bf16 and self.inp.dt == L.F32 and self._impl("dgrad") in (L.IMPL_AUTO, L.IMPL_MFMA):
                 nb = self.plan.lib.bp_conv_stats_workspace(C.byref(self.cv), L.PACK_BWD, C.byref(self.inp.view),
                                                            C.byref(self.out.view), L.IMPL_MFMA)
                 if _BWD_KERNEL_IDS is not None \
                         and self.plan.lib.bp_conv_kernel_id(C.byref(self.cv), L.PACK_BWD) not in _BWD_KERNEL_IDS:
                     nb = 0
+                if 0 < nb <= self.plan.ws_bytes:
+                    self._fused_producer = p
+            elif common and self.bf16 and self.inp.dt == L.BF16 and os.environ.get("BP_BF16_BWD_STATS", "1") != "0":
+                # the two full-resolution flattened-K bf16 data gradients (conv_bf16_flat.hip, STATS == 2)
+                nb = self.plan.lib.bp_conv_stats_workspace(C.byref(self.cv), L.PACK_BWD, C.byref(self.inp.view),
+                                                           C.byref(self.out.view), L.IMPL_BF16)
                 if 0 < nb <= self.plan.ws_bytes:
                     self._fused_producer = p
         return self._fused_producer

@@ -142,7 +142,10 @@ int bp_conv_backward_data(const bp_conv* cv, const bp_view* dy, const float* pac
  *       use the separate passes.
  *   bp_conv_forward_stats        y_raw = conv(act(x)); sums[2*cout] = {sum y, sum y^2} as bp_channel_sums(y).
  *   bp_conv_backward_data_stats  dx = d(loss)/d(act(x)) as bp_conv_backward_data; sums[2*cin] = {sum g, sum g*x_raw},
- *       g = dx * act'(x_pw(x_raw)): the first two sums of bp_act_backward(dx, NULL, x_raw, x_pw, ...). */
+ *       g = dx * act'(x_pw(x_raw)): the first two sums of bp_act_backward(dx, NULL, x_raw, x_pw, ...).  With bf16
+ *       views (dx and x_raw bf16, packed_bwd the bf16 image) the bf16 kernels run: their two full-resolution
+ *       flattened-K data gradients have the epilogue (the layers behind the generator's 16-channel 512^2 slots), g
+ *       from the bf16-rounded dx as stored; workspace query with impl = BP_IMPL_BF16. */
 size_t bp_conv_stats_workspace(const bp_conv* cv, int dir, const bp_view* x, const bp_view* y, int impl);
 int bp_conv_forward_stats(const bp_conv* cv, const bp_view* x, const bp_pointwise* x_pw, const float* packed_fwd,
                           const bp_view* y, double* sums, void* workspace, size_t workspace_bytes, int impl,

@@ -141,6 +141,71 @@ def test_bf16_convolution_forward_dgrad_wgrad(case, io):
     assert G.rel_err(dw.cpu().numpy(), dw_ref) < 1e-4, "backward_weight"
 
 
+# (cin, cout, k, stride, pad, dy is bf16): Conv2d layers whose DATA GRADIENT runs on a flattened-K kernel that can take
+# the producer's batch-norm backward sums in its epilogue (conv_bf16_flat.hip STATS == 2)
+BWD_STATS_CASES = [(16, 8, 7, 1, 3, False), (16, 32, 4, 2, 1, True)]
+
+
+@pytest.mark.parametrize("shape", [(2, 22, 38), (3, 64, 130)], ids=["ragged", "tiles"])
+@pytest.mark.parametrize("case", BWD_STATS_CASES, ids=lambda c: "C%d_%d_k%ds%d" % c[:4])
+def test_bf16_data_gradient_with_activation_sums(case, shape):
+    """bp_conv_backward_data_stats on bf16 views: dx as bp_conv_backward_data writes it (bit for bit) and
+    {sum g, sum g*raw}, g = dx * act'(pw(raw)), equal to what bp_act_backward computes from the stored bf16 dx."""
+    lib = L.load()
+    ci, co, k, s, p, dy_bf = case
+    n, h, w = shape
+    rng = np.random.default_rng(ci + co + k)
+    wt = (rng.standard_normal((co, ci, k, k)) * 0.1).astype(np.float32)
+    ho, wo = (h + 2 * p - k) // s + 1, (w + 2 * p - k) // s + 1
+    dy = rng.standard_normal((n, co, ho, wo)).astype(np.float32)
+    raw = bf16_round(rng.standard_normal((n, ci, h, w)).astype(np.float32))
+    scale = rng.uniform(0.5, 1.5, ci).astype(np.float32)
+    shift = rng.uniform(-0.4, 0.4, ci).astype(np.float32)
+    slope = rng.uniform(0.0, 0.3, ci).astype(np.float32)
+    slope[::3] = 0.0
+    cv = L.Conv(0, ci, co, k, s, p, 0)
+    st = G.stream()
+    dyb, dyv = to_view(bf16_round(dy) if dy_bf else dy, dy_bf)
+    rb, rv = to_view(raw, True, cstride=ci + 8, coff=4)
+    keep, pw = G.pointwise(scale, shift, slope)
+    wd = G.dev(wt)
+    pb = torch.zeros(lib.bp_conv_bf16_packed_elems(C.byref(cv), L.PACK_BWD), device="cuda", dtype=torch.bfloat16)
+    L.check(lib.bp_conv_bf16_pack(C.byref(cv), L.PACK_BWD, L.ptr(wd), L.ptr(pb), st))
+    dxb, dxv = empty_view(n, h, w, ci, True)
+    L.check(lib.bp_conv_backward_data(C.byref(cv), C.byref(dyv), L.ptr(pb), L.ptr(wd), C.byref(dxv), L.IMPL_BF16, st))
+    nb = lib.bp_conv_stats_workspace(C.byref(cv), L.PACK_BWD, C.byref(dxv), C.byref(dyv), L.IMPL_BF16)
+    assert nb > 0
+    dx2b, dx2v = empty_view(n, h, w, ci, True)
+    sums = torch.full((2 * ci,), float("nan"), dtype=torch.float64, device="cuda")
+    ws = torch.full((nb // 8 + 8,), float("nan"), dtype=torch.float64, device="cuda")
+    L.check(lib.bp_conv_backward_data_stats(C.byref(cv), C.byref(dyv), L.ptr(pb), C.byref(dx2v), C.byref(rv), C.byref(pw),
+                                            L.ptr(sums), L.ptr(ws), nb, st), "backward_data + activation sums")
+    assert torch.equal(dx2b, dxb), "the epilogue must not change the data gradient"
+    dx = from_view(dxb, ci).astype(np.float64)
+    t = (raw.astype(np.float64) * scale[None, :, None, None] + shift[None, :, None, None]).astype(np.float32)
+    g = np.where(t > 0, dx, dx * slope[None, :, None, None].astype(np.float64))
+    got = sums.cpu().numpy()
+    r64 = raw.astype(np.float64)
+    assert (np.abs(got[:ci] - g.sum(axis=(0, 2, 3))) <= 2e-6 * np.abs(g).sum(axis=(0, 2, 3)) + 1e-12).all()
+    assert (np.abs(got[ci:] - (g * r64).sum(axis=(0, 2, 3))) <= 2e-6 * np.abs(g * r64).sum(axis=(0, 2, 3)) + 1e-12).all()
+    # ... and the separate pass over the stored gradient
+    ref = torch.zeros(3 * ci, dtype=torch.float64, device="cuda")
+    r2b, r2v = to_view(raw, True)               # (the streaming pass wants views of one geometry)
+    nb2 = lib.bp_act_backward_workspace(C.byref(r2v))
+    ws2 = torch.zeros(nb2 // 8 + 8, dtype=torch.float64, device="cuda")
+    L.check(lib.bp_act_backward(C.byref(dxv), None, C.byref(r2v), C.byref(pw), None, None, L.ptr(ref), L.ptr(ws2), nb2, st))
+    ref = ref.cpu().numpy()
+    assert (np.abs(got[:ci] - ref[:ci]) <= 2e-6 * np.abs(g).sum(axis=(0, 2, 3)) + 1e-12).all()
+    assert (np.abs(got[ci:] - ref[ci:2 * ci]) <= 2e-6 * np.abs(g * r64).sum(axis=(0, 2, 3)) + 1e-12).all()
+    assert lib.bp_conv_backward_data_stats(C.byref(cv), C.byref(dyv), L.ptr(pb), C.byref(dx2v), C.byref(rv), C.byref(pw),
+                                           L.ptr(sums), L.ptr(ws), nb - 8, st) == -4
+    # the generic bf16 kernels have no such epilogue
+    cv2 = L.Conv(0, 128, 128, 3, 1, 1, 0)
+    a_b, a_v = empty_view(1, 8, 8, 128, True)
+    b_b, b_v = empty_view(1, 8, 8, 128, True)
+    assert lib.bp_conv_stats_workspace(C.byref(cv2), L.PACK_BWD, C.byref(a_v), C.byref(b_v), L.IMPL_BF16) == 0
+
+
 def test_fp32_entry_points_refuse_bf16_views():
     lib = L.load()
     buf, v = empty_view(1, 4, 4, 8, True)
