@@ -38,6 +38,11 @@ class BnTrain(C.Structure):
                 ("save_mean", C.c_void_p), ("save_invstd", C.c_void_p)]
 
 
+class BnBackwardFin(C.Structure):
+    _fields_ = [("count", C.c_double), ("gamma", C.c_void_p), ("save_mean", C.c_void_p), ("save_invstd", C.c_void_p),
+                ("param_grad_scale", C.c_float), ("dgamma", C.c_void_p), ("dbeta", C.c_void_p), ("coef_abc", C.c_void_p)]
+
+
 class Latent(C.Structure):
     _fields_ = [("n", C.c_int32), ("L", C.c_int32), ("zc", C.c_int32), ("zh", C.c_int32),
                 ("zw", C.c_int32), ("min_z_var", C.c_float)]
@@ -86,6 +91,7 @@ SIGNATURES = {
     "bp_bn_eval_pointwise": (C.c_int, [C.c_int32, _P, _P, _P, _P, C.c_float, _P, _P, _P]),
     "bp_act_backward_workspace": (C.c_size_t, [_VP]),
     "bp_act_backward": (C.c_int, [_VP, _VP, _VP, _PWP, _VP, _VP, _P, _P, C.c_size_t, _P]),
+    "bp_act_backward_bn": (C.c_int, [_VP, _VP, _VP, _PWP, _VP, _VP, _P, C.POINTER(BnBackwardFin), _P, C.c_size_t, _P]),
     "bp_bn_backward_finalize": (C.c_int, [_P, C.c_double, C.c_int32, _P, _P, _P, C.c_float, _P, _P, _P, _P]),
     "bp_bn_backward_apply": (C.c_int, [_VP, _VP, _P, _VP, _P]),
     "bp_act_bn_backward_apply": (C.c_int, [_VP, _VP, _VP, _PWP, _VP, _P, _VP, _P]),

@@ -888,6 +888,47 @@ int bp_sum_partials_strided(const double* partial, int nblk, int stride, int n, 
   return BP_OK;
 }
 
+// bp_act_backward_bn: the last stage of the activation backward's three sums with the batch-norm backward finalize of
+// the same layer folded in.  One workgroup per channel, wave q sums column q*c + ch exactly as sum_partials_wave_kernel
+// does (bitwise the same sums), then one thread evaluates bn_backward_finalize_kernel's formulas for the channel.
+struct BnBwdFin {
+  double count;
+  const float* gamma; const double* smean; const double* sinv;
+  float pscale;
+  float* dgamma; float* dbeta; double* coef;
+};
+__global__ __launch_bounds__(192) void sum_partials_bnbwd_kernel(const double* partial, int nblk, int c, double* sums, BnBwdFin f) {
+  __shared__ double sh[3];
+  const int ch = blockIdx.x, q = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int i = q * c + ch;
+  double t = 0.0;
+  for (int b = lane; b < nblk; b += 64) t += partial[(int64_t)b * 3 * c + i];
+#pragma unroll
+  for (int s = 32; s > 0; s >>= 1) t += __shfl_down(t, s, 64);
+  if (lane == 0) { sums[i] = t; sh[q] = t; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double S0 = sh[0], S1 = sh[1];
+    const double mean = f.smean[ch], inv = f.sinv[ch], g = f.gamma ? (double)f.gamma[ch] : 1.0;
+    const double dg = inv * (S1 - mean * S0);
+    if (f.dgamma) f.dgamma[ch] = (float)(dg * f.pscale);
+    if (f.dbeta) f.dbeta[ch] = (float)(S0 * f.pscale);
+    f.coef[ch] = g * inv;
+    f.coef[c + ch] = S0 / f.count;
+    f.coef[2 * c + ch] = -g * inv * inv * dg / f.count;
+    f.coef[3 * c + ch] = mean;
+  }
+}
+static thread_local const BnBwdFin* t_bnbwd = nullptr;       // set by bp_act_backward_bn around bp_act_backward
+
+// the three sums of an activation backward, partial[nblk][3c] -> sums[3c] (+ the pending finalize)
+int bp_sum_partials3(const double* partial, int nblk, int c, double* sums, hipStream_t st) {
+  if (t_bnbwd) hipLaunchKernelGGL(sum_partials_bnbwd_kernel, dim3(c), dim3(192), 0, st, partial, nblk, c, sums, *t_bnbwd);
+  else hipLaunchKernelGGL(sum_partials_wave_kernel, dim3(3 * c), dim3(64), 0, st, partial, nblk, 3 * c, sums);
+  BP_CHECK_LAUNCH();
+  return BP_OK;
+}
+
 // out[i] = sum over blocks of partial[b][i], fixed order (shared with pointwise_bf16.hip)
 int bp_sum_partials(const double* partial, int nblk, int n, double* out, hipStream_t st) {
   hipLaunchKernelGGL(sum_partials_wave_kernel, dim3(n), dim3(64), 0, st, partial, nblk, n, out);
@@ -1024,9 +1065,7 @@ int bp_act_backward(const bp_view* dout, const bp_view* dout2, const bp_view* ra
     fa.partial = reinterpret_cast<double*>(workspace);
     hipLaunchKernelGGL(act_backward_fast_kernel, dim3(f.nblk), dim3(RB), 0, st, fa);
     BP_CHECK_LAUNCH();
-    hipLaunchKernelGGL(sum_partials_wave_kernel, dim3(3 * raw->c), dim3(64), 0, st, fa.partial, f.nblk, 3 * raw->c, sums);
-    BP_CHECK_LAUNCH();
-    return BP_OK;
+    return bp_sum_partials3(fa.partial, f.nblk, raw->c, sums, st);
   }
   ActBwdArgs a{};
   a.dout = vd(dout); a.dout2 = vd(dout2); a.raw = vd(raw); a.aout = vd(act_out); a.g = vd(g);
@@ -1036,9 +1075,19 @@ int bp_act_backward(const bp_view* dout, const bp_view* dout2, const bp_view* ra
     hipLaunchKernelGGL(act_backward_kernel, dim3(r.nblk), dim3(RB), 0, st, a);
     BP_CHECK_LAUNCH();
   }
-  hipLaunchKernelGGL(sum_partials_wave_kernel, dim3(3 * raw->c), dim3(64), 0, st, a.partial, r.nblk, 3 * raw->c, sums);
-  BP_CHECK_LAUNCH();
-  return BP_OK;
+  return bp_sum_partials3(a.partial, r.nblk, raw->c, sums, st);
+}
+
+int bp_act_backward_bn(const bp_view* dout, const bp_view* dout2, const bp_view* raw, const bp_pointwise* pw,
+                       const bp_view* act_out, const bp_view* g, double* sums, const bp_bn_backward_fin* fin,
+                       void* workspace, size_t workspace_bytes, void* stream) {
+  if (!fin || !raw || fin->count <= 0 || !fin->save_mean || !fin->save_invstd || !fin->coef_abc) return BP_EINVAL;
+  const BnBwdFin f{fin->count, fin->gamma, fin->save_mean, fin->save_invstd, fin->param_grad_scale, fin->dgamma,
+                   fin->dbeta, fin->coef_abc};
+  t_bnbwd = &f;
+  const int rc = bp_act_backward(dout, dout2, raw, pw, act_out, g, sums, workspace, workspace_bytes, stream);
+  t_bnbwd = nullptr;
+  return rc;
 }
 
 int bp_bn_backward_finalize(const double* sums, double count, int32_t c, const float* gamma,

@@ -266,6 +266,7 @@ static inline unsigned stream_blocks(int64_t total8) {
 
 // pointwise.hip
 int bp_sum_partials(const double* partial, int nblk, int n, double* out, hipStream_t st);
+int bp_sum_partials3(const double* partial, int nblk, int c, double* sums, hipStream_t st);
 
 bool bp_bf16_dense_ok(const bp_view* v) {
   return v && v->dtype == BP_BF16 && v->cstride == v->c && v->coff == 0 && v->c >= 8 && v->c <= 1024 &&
@@ -304,7 +305,7 @@ int bp_bf16_act_backward(const bp_view* dout, const bp_view* dout2, const bp_vie
     default: hipLaunchKernelGGL((act_backward_bf16_kernel<true, true, true>), grid, block, 0, st, a); break;
   }
   BP_CHECK_LAUNCH();
-  return bp_sum_partials(a.partial, f.nblk, 3 * raw->c, sums, st);
+  return bp_sum_partials3(a.partial, f.nblk, raw->c, sums, st);
 }
 
 int bp_bf16_bn_backward_apply(const bp_view* dout, const bp_view* dout2, const bp_view* raw, const PW& pw,

@@ -26,6 +26,7 @@ from .. import _lib as L
 _ES = os.environ.get("BP_EPILOGUE_STATS", "auto")
 EPILOGUE_STATS = _ES != "0"
 EPILOGUE_FWD, EPILOGUE_BWD = _ES in ("1", "fwd", "auto"), _ES in ("1", "bwd", "auto")
+FUSE_BN_BWD_FINALIZE = os.environ.get("BP_FUSE_BN_BWD_FINALIZE", "1") != "0"       # bp_act_backward_bn
 # "auto": the backward sums only from the flattened-K data-gradient kernels (conv_flat.hip: weights in registers, sums
 # per lane in LDS).  In the tiled igemm kernels the double-precision sums cost what the saved pass costs ("1": all).
 _BWD_KERNEL_IDS = (710000,) if _ES == "auto" else None
@@ -603,6 +604,7 @@ class ConvUnit:
         aout = None if act_out is None else C.byref(act_out)
         d2 = None if dout2 is None else C.byref(dout2)
         nstreams = 2 + (dout2 is not None) + (act_out is not None)       # tensors this pass and the apply pass read
+        finalized = False
         if self._sums_ready and g_out is None and dout2 is None and act_out is None:
             self._sums_ready = False         # the consumer's data gradient left {sum g, sum g*raw} in self.sums
         elif self._g_ready and bn is None and dout2 is None and act_out is None and g_out is dout:
@@ -613,9 +615,20 @@ class ConvUnit:
             if self._sums_ready:
                 raise RuntimeError(f"{self.name}: fused statistics do not match this activation backward")
             t0 = plan.prof_begin()
-            L.check(lib.bp_act_backward(C.byref(dout), d2, C.byref(self.out.view), pw, aout,
-                                        None if g_out is None else C.byref(g_out), L.ptr(self.sums),
-                                        L.ptr(self._ws()), plan.ws_bytes, st), f"{self.name} act backward")
+            if bn is not None and not (plan.sync is not None and plan.sync.sync_bn) and FUSE_BN_BWD_FINALIZE:
+                # single device: the batch-norm backward finalize rides on the launch that adds the partial sums
+                dp = lambda t: None if t is None else t.data_ptr()
+                fin = L.BnBackwardFin(self.count, dp(bn.weight), dp(self.save_mean), dp(self.save_invstd), 1.0,
+                                      dp(grads[id(bn.weight)]), dp(grads[id(bn.bias)]), dp(self.abc))
+                L.check(lib.bp_act_backward_bn(C.byref(dout), d2, C.byref(self.out.view), pw, aout,
+                                               None if g_out is None else C.byref(g_out), L.ptr(self.sums),
+                                               C.byref(fin), L.ptr(self._ws()), plan.ws_bytes, st),
+                        f"{self.name} act backward + bn backward finalize")
+                finalized = True
+            else:
+                L.check(lib.bp_act_backward(C.byref(dout), d2, C.byref(self.out.view), pw, aout,
+                                            None if g_out is None else C.byref(g_out), L.ptr(self.sums),
+                                            L.ptr(self._ws()), plan.ws_bytes, st), f"{self.name} act backward")
             plan.prof_end(t0, self, "act_backward", nstreams + (g_out is not None))
         if self.act == "prelu":
             L.check(lib.bp_prelu_slope_grad(L.ptr(self.sums), c, L.ptr(grads[id(self.act_holder.weight)]), st),
@@ -625,10 +638,11 @@ class ConvUnit:
             if plan.sync is not None and plan.sync.sync_bn:
                 yield self.sums[:2 * c]
                 pscale = 1.0 / plan.sync.world_size       # sums are global, losses are per-rank means
-            L.check(lib.bp_bn_backward_finalize(L.ptr(self.sums), self.count, c, L.ptr(bn.weight),
-                                                L.ptr(self.save_mean), L.ptr(self.save_invstd), pscale,
-                                                L.ptr(grads[id(bn.weight)]), L.ptr(grads[id(bn.bias)]),
-                                                L.ptr(self.abc), st), f"{self.name} bn backward")
+            if not finalized:
+                L.check(lib.bp_bn_backward_finalize(L.ptr(self.sums), self.count, c, L.ptr(bn.weight),
+                                                    L.ptr(self.save_mean), L.ptr(self.save_invstd), pscale,
+                                                    L.ptr(grads[id(bn.weight)]), L.ptr(grads[id(bn.bias)]),
+                                                    L.ptr(self.abc), st), f"{self.name} bn backward")
             t0 = plan.prof_begin()
             if g_out is None:
                 L.check(lib.bp_act_bn_backward_apply(C.byref(dout), d2, C.byref(self.out.view), pw, aout,

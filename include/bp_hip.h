@@ -237,6 +237,22 @@ int bp_act_backward(const bp_view* dout, const bp_view* dout2, const bp_view* ra
                     const bp_pointwise* pw, const bp_view* act_out, const bp_view* g,
                     double* sums, void* workspace, size_t workspace_bytes, void* stream);
 
+/* bp_act_backward followed by bp_bn_backward_finalize(sums, ...) of the same layer, the finalize folded into the
+ * launch that adds the partial sums (one tiny launch less per batch-norm layer on the backward chain, where every
+ * launch's latency is exposed; the same numbers bit for bit).  Single-device training only: under data parallelism
+ * the sums are all-reduced between the two.  The fields are bp_bn_backward_finalize's arguments. */
+typedef struct bp_bn_backward_fin {
+  double count;
+  const float* gamma;                    /* NULL: 1 */
+  const double* save_mean; const double* save_invstd;
+  float param_grad_scale;
+  float* dgamma; float* dbeta;           /* NULL: skipped */
+  double* coef_abc;                      /* [4*c] */
+} bp_bn_backward_fin;
+int bp_act_backward_bn(const bp_view* dout, const bp_view* dout2, const bp_view* raw,
+                       const bp_pointwise* pw, const bp_view* act_out, const bp_view* g, double* sums,
+                       const bp_bn_backward_fin* fin, void* workspace, size_t workspace_bytes, void* stream);
+
 /* From the (all-reduced) sums: dgamma, dbeta and the per-channel coefficients {A, mg, B, mean} of
  *   d_raw = A*(g - mg) + B*(raw - mean)   (batch-norm backward as an affine map of (g, raw)),
  * kept and evaluated in double like the reference's CPU batch_norm_backward (its accumulate type).
