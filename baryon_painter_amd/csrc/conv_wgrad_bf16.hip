@@ -15,6 +15,7 @@ using namespace bpbf16;
 // 32-byte rows = 256 contiguous bytes: conflict-free.
 namespace {
 
+
 struct WbArgs {
   const void* X; int xh, xw, xcs, xco, cx, x_bf16;
   const void* Y; int yh, yw, ycs, yco, cy, y_bf16;
@@ -231,6 +232,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(WbArgs a) {
       }
     };
     auto commit = [&]() {
+      // A unit's 24 activation parameters are re-read from LDS for every unit (the stores in between may alias them
+      // as far as the compiler knows, and keeping them in registers across the loop spills: the accumulators fill the
+      // file): as six 16-byte reads instead of 24 scalar ones, four channels at a time -- the commit was LDS-
+      // instruction bound: weight gradients of the layers whose X carries a pending activation 0.32 -> 0.22 ms
+      // (16 -> 32), 0.31 -> 0.21 (64 -> 128), 0.18 -> 0.15 (trunk); the Y side (transposed layers) measured no gain
+      // from the same change and keeps its scalar reads.
 #pragma unroll
       for (int i = 0; i < NXS; ++i) {
         const int e = tid + i * 256;
@@ -245,10 +252,21 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(WbArgs a) {
         float v[8], raw[8];
         unpack_unit<8, XB>(xr[i], raw);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          float u = raw[j];
-          if (xon) { u = fmaf(u, lpw[xcu * 8 + j], lpw[CXC + xcu * 8 + j]); u = u > 0.f ? u : u * lpw[2 * CXC + xcu * 8 + j]; }
-          v[j] = ((xin >> i) & 1u) ? u : 0.f;
+        for (int h = 0; h < 2; ++h) {            // (four channels at a time: twelve parameter registers live, not 24)
+          float c[4] = {1.f, 1.f, 1.f, 1.f}, f[4] = {0.f, 0.f, 0.f, 0.f}, l[4] = {1.f, 1.f, 1.f, 1.f};
+          if (xon) {
+            const float4 sc = *reinterpret_cast<const float4*>(lpw + xcu * 8 + 4 * h);
+            const float4 sf = *reinterpret_cast<const float4*>(lpw + CXC + xcu * 8 + 4 * h);
+            const float4 sl = *reinterpret_cast<const float4*>(lpw + 2 * CXC + xcu * 8 + 4 * h);
+            c[0] = sc.x; c[1] = sc.y; c[2] = sc.z; c[3] = sc.w; f[0] = sf.x; f[1] = sf.y; f[2] = sf.z; f[3] = sf.w;
+            l[0] = sl.x; l[1] = sl.y; l[2] = sl.z; l[3] = sl.w;
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            float u = raw[4 * h + j];
+            if (xon) { u = fmaf(u, c[j], f[j]); u = u > 0.f ? u : u * l[j]; }
+            v[4 * h + j] = ((xin >> i) & 1u) ? u : 0.f;
+          }
         }
         lds_store_unit<8>(dst, v);
       }
@@ -268,7 +286,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(WbArgs a) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           float u = raw[j];
-          if (yon) {
+          if (yon) {       // (scalar reads here: the 16-byte form of the X side made this side slower, 0.15 -> 0.23 ms)
             u = fmaf(u, lpw[3 * CXC + ycu * 8 + j], lpw[3 * CXC + CYC + ycu * 8 + j]);
             u = u > 0.f ? u : u * lpw[3 * CXC + 2 * CYC + ycu * 8 + j];
           }
