@@ -501,19 +501,29 @@ struct FsArgs {
   PW pw;
   int tiles_x, tiles_y, n;
   double* stat; int stat_c;
+  const u16* raw; int raw_cs, raw_co;             // STATS == 2 (see FbArgs)
+  PW spw;
 };
 
 constexpr int FS_TW = 32, FS_TH = 8, FS_LW = 2 * (FS_TW - 1) + 4, FS_LH = 2 * (FS_TH - 1) + 4, FS_C = 16;
 constexpr int FS_ROWE = FS_LW * FS_C;
-constexpr size_t FS_LDS = ((size_t)FS_LH * FS_ROWE + 32) * 2 + 3 * FS_C * sizeof(float) + 4 * 64 * sizeof(double);
+constexpr size_t FS_LDS = ((size_t)FS_LH * FS_ROWE + 32) * 2 + 3 * FS_C * sizeof(float) + 4 * 64 * sizeof(double) + 3 * 32 * sizeof(float);
 
-template <bool STATS>
+template <int STATS>
 __global__ __launch_bounds__(256, 3) void flatb_s2_kernel(FsArgs a) {
   constexpr int NU = FS_LH * FS_LW * 2, SLOTS = (NU + 255) / 256;       // 8-channel units
   extern __shared__ __attribute__((aligned(16))) u16 smem_fb[];
   u16* lds = smem_fb;
   float* lpw = reinterpret_cast<float*>(lds + FS_LH * FS_ROWE + 32);
   double* red = reinterpret_cast<double*>(lpw + 3 * FS_C);
+  float* lspw = reinterpret_cast<float*>(red + 4 * 64);      // STATS == 2: the produced slot's activation [3][32]
+  if constexpr (STATS == 2) {
+    if (threadIdx.x < 32) {
+      const bool son = a.spw.scale != nullptr;
+      lspw[threadIdx.x] = son ? a.spw.scale[threadIdx.x] : 1.f; lspw[32 + threadIdx.x] = son ? a.spw.shift[threadIdx.x] : 0.f;
+      lspw[64 + threadIdx.x] = son ? a.spw.slope[threadIdx.x] : 1.f;
+    }
+  }
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lj = lane & 15, kg = lane >> 4;
@@ -598,6 +608,14 @@ __global__ __launch_bounds__(256, 3) void flatb_s2_kernel(FsArgs a) {
 #pragma unroll
   for (int q = 0; q < 8; ++q) { s1[q] = 0.f; s2[q] = 0.f; }
   const int ox = tx0 + x0 + lj;
+  uint4 rw[STATS == 2 ? 4 : 1];
+  if constexpr (STATS == 2) {              // the slot's raw values under this lane's four outputs, loaded together
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int oy = min(ty0 + r0 + r, a.oh - 1), oxc = min(ox, a.ow - 1);
+      rw[r] = *reinterpret_cast<const uint4*>(a.raw + ((int64_t)(n * a.oh + oy) * a.ow + oxc) * a.raw_cs + a.raw_co + kg * 8);
+    }
+  }
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int oy = ty0 + r0 + r;
@@ -606,9 +624,20 @@ __global__ __launch_bounds__(256, 3) void flatb_s2_kernel(FsArgs a) {
     *reinterpret_cast<uint4*>(reinterpret_cast<u16*>(a.out) + o) =
         make_uint4(pack2(acc[r][0][0], acc[r][0][1]), pack2(acc[r][0][2], acc[r][0][3]),
                    pack2(acc[r][1][0], acc[r][1][1]), pack2(acc[r][1][2], acc[r][1][3]));
-    if constexpr (STATS) {
+    if constexpr (STATS == 1) {
 #pragma unroll
       for (int q = 0; q < 8; ++q) { const float v = bf2f(f2bf(acc[r][q >> 2][q & 3])); s1[q] += v; s2[q] = fmaf(v, v, s2[q]); }
+    }
+    if constexpr (STATS == 2) {
+      const unsigned w4[4] = {rw[r].x, rw[r].y, rw[r].z, rw[r].w};
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const float rv = bf2f((u16)((q & 1) ? (w4[q >> 1] >> 16) : (w4[q >> 1] & 0xffffu)));
+        const float d = bf2f(f2bf(acc[r][q >> 2][q & 3]));
+        const float tt = fmaf(rv, lspw[kg * 8 + q], lspw[32 + kg * 8 + q]);
+        const float g = tt > 0.f ? d : d * lspw[64 + kg * 8 + q];
+        s1[q] += g; s2[q] = fmaf(g, rv, s2[q]);
+      }
     }
   }
   if constexpr (STATS) {
@@ -798,15 +827,23 @@ __global__ __launch_bounds__(256) void flatb_s2w_pack_kernel(FtPackArgs a) {
 
 constexpr int GT_TW = 32, GT_TH = 8, GT_LW = GT_TW + 2, GT_LH = GT_TH + 2, GT_C = 64;
 constexpr int GT_ROWE = GT_LW * GT_C;
-constexpr size_t GT_LDS = ((size_t)GT_LH * GT_ROWE) * 2 + 3 * GT_C * sizeof(float) + 4 * 64 * sizeof(double);
+constexpr size_t GT_LDS = ((size_t)GT_LH * GT_ROWE) * 2 + 3 * GT_C * sizeof(float) + 4 * 64 * sizeof(double) + 3 * 32 * sizeof(float);
 
-template <bool STATS>
+template <int STATS>
 __global__ __launch_bounds__(256, 2) void flatb_t2w_kernel(FtArgs a) {
   constexpr int NU = GT_LH * GT_LW * 8, SLOTS = (NU + 255) / 256;
   extern __shared__ __attribute__((aligned(16))) u16 smem_fb[];
   u16* lds = smem_fb;
   float* lpw = reinterpret_cast<float*>(lds + GT_LH * GT_ROWE);
   double* red = reinterpret_cast<double*>(lpw + 3 * GT_C);
+  float* lspw = reinterpret_cast<float*>(red + 4 * 64);      // STATS == 2: the produced slot's activation [3][32]
+  if constexpr (STATS == 2) {
+    if (threadIdx.x < 32) {
+      const bool son = a.spw.scale != nullptr;
+      lspw[threadIdx.x] = son ? a.spw.scale[threadIdx.x] : 1.f; lspw[32 + threadIdx.x] = son ? a.spw.shift[threadIdx.x] : 0.f;
+      lspw[64 + threadIdx.x] = son ? a.spw.slope[threadIdx.x] : 1.f;
+    }
+  }
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lj = lane & 15, kg = lane >> 4;
@@ -908,7 +945,15 @@ __global__ __launch_bounds__(256, 2) void flatb_t2w_kernel(FtArgs a) {
       }
     }
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
+    for (int r = 0; r < 4; ++r) {
+      uint4 rw[STATS == 2 ? 2 : 1];
+      if constexpr (STATS == 2) {
+#pragma unroll
+        for (int px = 0; px < 2; ++px) {
+          const int oy = min(2 * (ty0 + r0 + r) + py, a.oh - 1), ox = min(oxb + px, a.ow - 1);
+          rw[px] = *reinterpret_cast<const uint4*>(a.raw + ((int64_t)(n * a.oh + oy) * a.ow + ox) * a.raw_cs + a.raw_co + kg * 8);
+        }
+      }
 #pragma unroll
       for (int px = 0; px < 2; ++px) {
         const int oy = 2 * (ty0 + r0 + r) + py, ox = oxb + px;
@@ -917,11 +962,23 @@ __global__ __launch_bounds__(256, 2) void flatb_t2w_kernel(FtArgs a) {
         *reinterpret_cast<uint4*>(reinterpret_cast<u16*>(a.out) + o) =
             make_uint4(pack2(acc[r][px][0][0], acc[r][px][0][1]), pack2(acc[r][px][0][2], acc[r][px][0][3]),
                        pack2(acc[r][px][1][0], acc[r][px][1][1]), pack2(acc[r][px][1][2], acc[r][px][1][3]));
-        if constexpr (STATS) {
+        if constexpr (STATS == 1) {
 #pragma unroll
           for (int q = 0; q < 8; ++q) { const float v = bf2f(f2bf(acc[r][px][q >> 2][q & 3])); s1[q] += v; s2[q] = fmaf(v, v, s2[q]); }
         }
+        if constexpr (STATS == 2) {
+          const unsigned w4[4] = {rw[px].x, rw[px].y, rw[px].z, rw[px].w};
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            const float rv = bf2f((u16)((q & 1) ? (w4[q >> 1] >> 16) : (w4[q >> 1] & 0xffffu)));
+            const float d = bf2f(f2bf(acc[r][px][q >> 2][q & 3]));
+            const float tt = fmaf(rv, lspw[kg * 8 + q], lspw[32 + kg * 8 + q]);
+            const float g = tt > 0.f ? d : d * lspw[64 + kg * 8 + q];
+            s1[q] += g; s2[q] = fmaf(g, rv, s2[q]);
+          }
+        }
       }
+    }
   }
   if constexpr (STATS) {
     double d1[8], d2[8];
@@ -1090,7 +1147,8 @@ static bool f2_ok(const FbKind& f, const bp_view* in, const bp_view* out) {
 bool bp_bf16_flat_ok(const ConvGeom& g, const bp_view* in, const bp_view* out, const float* bias, int stats) {
   const FbKind f = fb_kind(g);
   if (!f.kind || bias || !in || !out) return false;
-  if (f.kind >= 5) return f2_ok(f, in, out) && (stats != 2 || f.kind == 5);
+  static const bool m2wide = !(getenv("BP_BF16_M2_WIDE") && atoi(getenv("BP_BF16_M2_WIDE")) == 0);
+  if (f.kind >= 5) return f2_ok(f, in, out) && (stats != 2 || f.kind == 5 || (m2wide && f.kind != 8));
   if (stats == 1 && f.kind != 3) return false;
   if (stats == 2 && f.kind != 2) return false;
   if (in->c != g.cin_g || out->c != g.cout_g || in->h != out->h || in->w != out->w || in->n != out->n) return false;
@@ -1125,23 +1183,36 @@ int bp_bf16_flat_run(const ConvGeom& g, const bp_view* in, const PW& pw, const u
     double* stat = nullptr;
     if (sr) {
       const size_t need = bp_stats_rows_bytes(rows, g.cout_g);
-      if ((sr->mode != 1 && !(sr->mode == 2 && f.kind == 5)) || !need) return BP_EUNSUPPORTED;
+      if ((sr->mode != 1 && !(sr->mode == 2 && f.kind != 8)) || !need) return BP_EUNSUPPORTED;
       if (!sr->ws || sr->ws_bytes < need || !sr->sums) return BP_EWORKSPACE;
       stat = reinterpret_cast<double*>(sr->ws);
     }
     const dim3 grid((unsigned)rows), block(256);
-    if (sr && sr->mode == 2) {          // T form 32 -> 16 as a data gradient: the producer's activation sums
+    if (sr && sr->mode == 2) {          // as a data gradient: the producer's batch-norm backward sums (kinds 5, 6, 7)
       const bp_view* r = sr->raw;
+      const int rv = f.kind == 5 ? 4 : 8;                       // raw channels per vector load
       if (!r || r->dtype != BP_BF16 || r->n != out->n || r->h != out->h || r->w != out->w || r->c != out->c ||
-          r->cstride % 4 || r->coff % 4 || reinterpret_cast<uintptr_t>(r->ptr) % 8)
+          r->cstride % rv || r->coff % rv || reinterpret_cast<uintptr_t>(r->ptr) % (2 * rv))
         return BP_EUNSUPPORTED;
-      FtArgs t{reinterpret_cast<const u16*>(in->ptr), in->h, in->w, in->cstride, in->coff, out->ptr, out->h, out->w,
-               out->cstride, out->coff, packed_flat, pw, tx, ty, in->n, stat, g.cout_g,
-               reinterpret_cast<const u16*>(r->ptr), r->cstride, r->coff, sr->spw};
-      static const int once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(flatb_t2_kernel<2>),
-                                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)FT_LDS), 0);
-      (void)once;
-      hipLaunchKernelGGL(flatb_t2_kernel<2>, grid, block, FT_LDS, st, t);
+      const u16* rp = reinterpret_cast<const u16*>(r->ptr);
+#define BP_F2M2(KERNEL, ARGS, LDS_)                                                                                   \
+      do {                                                                                                            \
+        static const int once2 = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(KERNEL<2>),                 \
+                                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDS_)), 0); \
+        (void)once2;                                                                                                  \
+        hipLaunchKernelGGL(KERNEL<2>, grid, block, LDS_, st, ARGS);                                                   \
+      } while (0)
+      if (f.kind == 6) {
+        FsArgs t{reinterpret_cast<const u16*>(in->ptr), in->h, in->w, in->cstride, in->coff, out->ptr, out->h, out->w,
+                 out->cstride, out->coff, packed_flat, pw, tx, ty, in->n, stat, g.cout_g, rp, r->cstride, r->coff, sr->spw};
+        BP_F2M2(flatb_s2_kernel, t, FS_LDS);
+      } else {
+        FtArgs t{reinterpret_cast<const u16*>(in->ptr), in->h, in->w, in->cstride, in->coff, out->ptr, out->h, out->w,
+                 out->cstride, out->coff, packed_flat, pw, tx, ty, in->n, stat, g.cout_g, rp, r->cstride, r->coff, sr->spw};
+        if (f.kind == 5) BP_F2M2(flatb_t2_kernel, t, FT_LDS);
+        else BP_F2M2(flatb_t2w_kernel, t, GT_LDS);
+      }
+#undef BP_F2M2
       BP_CHECK_LAUNCH();
       return bp_stats_rows_finish(stat, rows, g.cout_g, sr, st);
     }
@@ -1162,7 +1233,7 @@ int bp_bf16_flat_run(const ConvGeom& g, const bp_view* in, const PW& pw, const u
       else BP_F2(flatb_t2w_kernel, t, GT_LDS);
     } else {
       FsArgs t{reinterpret_cast<const u16*>(in->ptr), in->h, in->w, in->cstride, in->coff, out->ptr, out->h, out->w,
-               out->cstride, out->coff, packed_flat, pw, tx, ty, in->n, stat, g.cout_g};
+               out->cstride, out->coff, packed_flat, pw, tx, ty, in->n, stat, g.cout_g, nullptr, 0, 0, PW{nullptr, nullptr, nullptr}};
       if (f.kind == 6) BP_F2(flatb_s2_kernel, t, FS_LDS);
       else BP_F2(flatb_s2w_kernel, t, GS_LDS);
     }

@@ -143,30 +143,32 @@ def test_bf16_convolution_forward_dgrad_wgrad(case, io):
 
 # (cin, cout, k, stride, pad, dy is bf16): Conv2d layers whose DATA GRADIENT runs on a flattened-K kernel that can take
 # the producer's batch-norm backward sums in its epilogue (conv_bf16_flat.hip STATS == 2)
-BWD_STATS_CASES = [(16, 8, 7, 1, 3, False), (16, 32, 4, 2, 1, True)]
+BWD_STATS_CASES = [(0, 16, 8, 7, 1, 3, False), (0, 16, 32, 4, 2, 1, True), (0, 32, 64, 4, 2, 1, True), (1, 32, 16, 4, 2, 1, True)]
 
 
 @pytest.mark.parametrize("shape", [(2, 22, 38), (3, 64, 130)], ids=["ragged", "tiles"])
-@pytest.mark.parametrize("case", BWD_STATS_CASES, ids=lambda c: "C%d_%d_k%ds%d" % c[:4])
+@pytest.mark.parametrize("case", BWD_STATS_CASES, ids=lambda c: "%s%d_%d_k%ds%d" % ("T" if c[0] else "C", *c[1:5]))
 def test_bf16_data_gradient_with_activation_sums(case, shape):
     """bp_conv_backward_data_stats on bf16 views: dx as bp_conv_backward_data writes it (bit for bit) and
     {sum g, sum g*raw}, g = dx * act'(pw(raw)), equal to what bp_act_backward computes from the stored bf16 dx."""
     lib = L.load()
-    ci, co, k, s, p, dy_bf = case
+    tr, ci, co, k, s, p, dy_bf = case
     n, h, w = shape
+    if tr:
+        h, w = h // 2, w // 2                      # (the transposed layer's input is the coarse grid)
     rng = np.random.default_rng(ci + co + k)
-    wt = (rng.standard_normal((co, ci, k, k)) * 0.1).astype(np.float32)
-    ho, wo = (h + 2 * p - k) // s + 1, (w + 2 * p - k) // s + 1
+    wt = (rng.standard_normal(((ci, co) if tr else (co, ci)) + (k, k)) * 0.1).astype(np.float32)
+    ho, wo = ((h - 1) * s - 2 * p + k, (w - 1) * s - 2 * p + k) if tr else ((h + 2 * p - k) // s + 1, (w + 2 * p - k) // s + 1)
     dy = rng.standard_normal((n, co, ho, wo)).astype(np.float32)
     raw = bf16_round(rng.standard_normal((n, ci, h, w)).astype(np.float32))
     scale = rng.uniform(0.5, 1.5, ci).astype(np.float32)
     shift = rng.uniform(-0.4, 0.4, ci).astype(np.float32)
     slope = rng.uniform(0.0, 0.3, ci).astype(np.float32)
     slope[::3] = 0.0
-    cv = L.Conv(0, ci, co, k, s, p, 0)
+    cv = L.Conv(tr, ci, co, k, s, p, 0)
     st = G.stream()
     dyb, dyv = to_view(bf16_round(dy) if dy_bf else dy, dy_bf)
-    rb, rv = to_view(raw, True, cstride=ci + 8, coff=4)
+    rb, rv = to_view(raw, True, cstride=ci + 8, coff=8 if ci >= 32 else 4)
     keep, pw = G.pointwise(scale, shift, slope)
     wd = G.dev(wt)
     pb = torch.zeros(lib.bp_conv_bf16_packed_elems(C.byref(cv), L.PACK_BWD), device="cuda", dtype=torch.bfloat16)
