@@ -167,7 +167,10 @@ class _Plan:
         if self.defer_reduce:
             for u in self._flat([u for us in self.q_units for u in us] + list(self.p_units)
                                 + [u for us in self.g_units for u in us] + list(self.mu_units) + list(self.var_units)):
-                if isinstance(u, ConvUnit) and getattr(u, "_wgrad_ws_bytes", 0) > 0 and not u.bf16:
+                # (BP_DEFER_MAX_MB: layers with larger partial sums reduce at once.  Measured: deferring ALL fp32 layers,
+                #  the trunk's 16 MB and the encoder layer's 25 MB of partial sums included, is best -- 41.3 vs 41.6 ms
+                #  with a 4 MB limit -- although the batched launch then ends the backward pass with 50 us of reads)
+                if isinstance(u, ConvUnit) and 0 < getattr(u, "_wgrad_ws_bytes", 0) <= DEFER_MAX_BYTES and not u.bf16:
                     u.ws_own = torch.empty(u._wgrad_ws_bytes // 8 + 32, device=dev, dtype=torch.float64)
         self.side = self._side_stream = None
         if with_grad and os.environ.get("BP_SIDE_WGRAD", "1") != "0":
@@ -575,6 +578,9 @@ class _Plan:
         with torch.cuda.stream(self.side):
             sync.all_reduce_mean(self.model._flat_grads[sl[0]:sl[1]])
         return sl
+
+
+DEFER_MAX_BYTES = int(os.environ.get("BP_DEFER_MAX_MB", "1048576")) << 20
 
 
 class _ELBOFunction(torch.autograd.Function):
