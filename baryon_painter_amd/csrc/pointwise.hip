@@ -454,6 +454,38 @@ __global__ __launch_bounds__(RB) void nchw_to_view_kernel(const float* src, int 
   out.p[p * out.cs + out.co + ch] = v;
 }
 
+// ... four consecutive pixels per thread (h*w a multiple of 4, source 16-byte aligned): one 16-byte load per channel,
+// 32-bit index arithmetic; CT = c + caux <= 4 known at compile time.  (The element-per-thread kernel above spends its
+// time in 64-bit divisions: 94 us for the 64 x 512^2 y + aux image.)
+template <int CT>
+__global__ __launch_bounds__(RB) void nchw_to_view4_kernel(const float* src, int c, const float* aux, ViewD out, int hw4,
+                                                           int64_t total4) {
+  const int64_t i = (int64_t)blockIdx.x * RB + threadIdx.x;
+  if (i >= total4) return;
+  const int nn = (int)(i / hw4), q = (int)(i - (int64_t)nn * hw4);
+  float v[CT][4];
+#pragma unroll
+  for (int ch = 0; ch < CT; ++ch) {
+    if (ch < c) {
+      const float4 t = *reinterpret_cast<const float4*>(src + ((int64_t)nn * c + ch) * hw4 * 4 + 4 * q);
+      v[ch][0] = t.x; v[ch][1] = t.y; v[ch][2] = t.z; v[ch][3] = t.w;
+    } else {
+      const float t = aux[nn * (CT - c) + (ch - c)];
+      v[ch][0] = t; v[ch][1] = t; v[ch][2] = t; v[ch][3] = t;
+    }
+  }
+  float* o = out.p + ((int64_t)nn * hw4 * 4 + 4 * q) * out.cs + out.co;
+  if (CT == 2 && out.cs == 2 && out.co == 0) {          // dense two-channel image: 32 contiguous bytes
+    reinterpret_cast<float4*>(o)[0] = make_float4(v[0][0], v[1][0], v[0][1], v[1][1]);
+    reinterpret_cast<float4*>(o)[1] = make_float4(v[0][2], v[1][2], v[0][3], v[1][3]);
+  } else {
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+      for (int ch = 0; ch < CT; ++ch) o[p * out.cs + ch] = v[ch][p];
+  }
+}
+
 __device__ __forceinline__ float softplus_f(float x) { return x > 20.f ? x : log1pf(expf(x)); }
 __device__ __forceinline__ float softplus_grad_f(float x) { return x > 20.f ? 1.f : 1.f / (1.f + expf(-x)); }
 
@@ -1208,6 +1240,23 @@ int bp_nchw_to_view(const float* src_nchw, int32_t c, const float* aux, int32_t 
   if (!src_nchw || c <= 0 || caux < 0 || (caux > 0 && !aux) || !out || !out->ptr) return BP_EINVAL;
   if (out->coff < 0 || out->coff + c + caux > out->cstride) return BP_EINVAL;
   const int64_t total = bp_view_pixels(out) * (c + caux);
+  const int64_t hw = (int64_t)out->h * out->w;
+  const int ct = c + caux;
+  if (hw % 4 == 0 && hw / 4 < 0x7fffffff && ct >= 1 && ct <= 4 && reinterpret_cast<uintptr_t>(src_nchw) % 16 == 0 &&
+      (!(ct == 2 && out->cstride == 2 && out->coff == 0) || reinterpret_cast<uintptr_t>(out->ptr) % 16 == 0)) {
+    const int hw4 = (int)(hw / 4);
+    const int64_t total4 = (int64_t)out->n * hw4;
+    const dim3 grid(nblocks(total4)), block(RB);
+    hipStream_t st = bp_stream(stream);
+    switch (ct) {
+      case 1: hipLaunchKernelGGL(nchw_to_view4_kernel<1>, grid, block, 0, st, src_nchw, c, aux, vd(out), hw4, total4); break;
+      case 2: hipLaunchKernelGGL(nchw_to_view4_kernel<2>, grid, block, 0, st, src_nchw, c, aux, vd(out), hw4, total4); break;
+      case 3: hipLaunchKernelGGL(nchw_to_view4_kernel<3>, grid, block, 0, st, src_nchw, c, aux, vd(out), hw4, total4); break;
+      default: hipLaunchKernelGGL(nchw_to_view4_kernel<4>, grid, block, 0, st, src_nchw, c, aux, vd(out), hw4, total4); break;
+    }
+    BP_CHECK_LAUNCH();
+    return BP_OK;
+  }
   hipLaunchKernelGGL(nchw_to_view_kernel, dim3(nblocks(total)), dim3(RB), 0, bp_stream(stream), src_nchw, c, aux,
                      caux, vd(out), out->n, total);
   BP_CHECK_LAUNCH();

@@ -542,6 +542,26 @@ def test_merge_aux_label_layout(golden_ops):
     assert np.array_equal(got, golden_ops["merge_aux/out/full"].reshape(got.shape))   # bit-exact copy
 
 
+@pytest.mark.parametrize("c,caux,cs,coff", [(1, 1, 2, 0), (1, 1, 4, 1), (1, 0, 1, 0), (2, 1, 4, 0), (3, 1, 6, 1), (1, 1, 3, 1)])
+@pytest.mark.parametrize("hw", [(8, 12), (5, 7)], ids=["quads", "ragged"])
+def test_nchw_to_view_all_forms(c, caux, cs, coff, hw):
+    """bp_nchw_to_view: the four-pixels-per-thread kernel (h*w a multiple of 4) and the element-per-thread one must
+    both be the bit-exact channel-last copy with the per-tile aux values broadcast over the pixels."""
+    lib = L.load()
+    n, (h, w) = 3, hw
+    rng = np.random.default_rng(c * 7 + caux + cs)
+    y = rng.standard_normal((n, c, h, w)).astype(np.float32)
+    aux = rng.standard_normal((n, max(caux, 1))).astype(np.float32)
+    ob, ov = G.empty_nhwc(n, h, w, c + caux, cstride=cs, coff=coff)
+    yd, ad = G.dev(y), G.dev(aux)
+    L.check(lib.bp_nchw_to_view(L.ptr(yd), c, L.ptr(ad) if caux else None, caux, C.byref(ov), G.stream()))
+    got = G.from_nhwc(ob, c + caux, coff=coff)
+    ref = np.concatenate([y] + ([np.broadcast_to(aux[:, :caux, None, None], (n, caux, h, w))] if caux else []), axis=1)
+    assert np.array_equal(got, ref)
+    rest = torch.ones(cs, dtype=torch.bool); rest[coff:coff + c + caux] = False
+    assert torch.isnan(ob[..., rest.cuda()]).all(), "stores outside the view"
+
+
 def test_adam_matches_torch():
     lib = L.load()
     rng = np.random.default_rng(0)
