@@ -180,6 +180,8 @@ class _Plan:
         # q_y_in and the prior run on their own streams, each with its own reduction workspace
         all_units = self._flat([u for us in self.q_units for u in us] + list(self.p_units)
                                + [u for us in self.g_units for u in us] + list(self.mu_units) + list(self.var_units))
+        for u in self._flat([u for us in self.g_units for u in us] + list(self.mu_units) + list(self.var_units)):
+            u.pack_late = True              # (graph.PackBatch: nothing in front of run_generator reads their weights)
         self.pack_batch = PackBatch(self, [u for u in all_units if isinstance(u, ConvUnit)])
         # Under data parallelism the recognition branches and the prior network advance level by level and share ONE
         # all-reduce of batch-norm sums per level (forward and backward): 14 fewer latency-bound collectives per step.
@@ -406,8 +408,8 @@ class _Plan:
             if i == 0 and getattr(self, "_gen_inputs", None) is not None:
                 torch.cuda.current_stream(self.device).wait_event(self._gen_inputs)    # load_inputs: y for the generator
                 self._gen_inputs = None
-            if i == 1 and getattr(self, "_own_packed", None) is not None:
-                torch.cuda.current_stream(self.device).wait_event(self._own_packed)    # graph.PackBatch: bf16 images
+            if i == 0 and getattr(self, "_own_packed", None) is not None:
+                torch.cuda.current_stream(self.device).wait_event(self._own_packed)    # graph.PackBatch: late packs
                 self._own_packed = None
             for u in us:
                 u.forward(training)

@@ -778,7 +778,7 @@ class PackBatch:
     def _build(self):
         lib, dev = self.plan.lib, self.plan.device
         nb = lib.bp_conv_pack_job_bytes()
-        recs, counts, self.rest = [], [], []
+        recs, counts, self.rest, self.rest_late = [], [], [], []     # (rest_late: units marked ``pack_late`` by the plan)
         self.own = [u for u in self.units if u.bf16]            # (bf16 images: the layer's own pack launches)
         for u in self.units:
             if u.bf16:
@@ -795,6 +795,8 @@ class PackBatch:
                 if rc == L.BP_OK:
                     recs.append(bytes(buf))
                     counts.append(n.value)
+                elif getattr(u, "pack_late", False):
+                    self.rest_late.append((cv, d, w, packed))
                 else:
                     self.rest.append((cv, d, w, packed))
         first = [0]
@@ -815,24 +817,29 @@ class PackBatch:
         # prior networks in front of it do not.
         side = getattr(plan, "side", None)
         plan._own_packed = None
-        if side is not None and self.own and not torch.cuda.is_current_stream_capturing():
-            side.wait_stream(torch.cuda.current_stream(plan.device))          # the optimizer's update
-            with torch.cuda.stream(side):
-                for u in self.own:
-                    u._packed_version = None
-                    u.maybe_pack()
-                plan._own_packed = torch.cuda.Event()
-                plan._own_packed.record(side)
-        else:
-            for u in self.own:
-                u._packed_version = None
-                u.maybe_pack()
-        for u in self.units:
+        for u in self.units:                 # (weight slices of restricted data gradients: before anything packs them)
             if u._sub is not None and not u.bf16:
                 c0, c1 = u.dgrad_slice
                 w = u.holder.weight
                 with torch.no_grad():
                     u._sub["w"].copy_(w[c0:c1] if u.cv.transposed else w[:, c0:c1])
+
+        def late(stream):
+            for u in self.own:
+                u._packed_version = None
+                u.maybe_pack()
+            # ... and the single-launch packs of fp32 layers the generator reads first (``pack_late`` units): the
+            # recognition / prior networks at the front of the step do not wait for them
+            for cv, d, w, packed in self.rest_late:
+                L.check(lib.bp_conv_pack(C.byref(cv), d, L.ptr(w), L.ptr(packed), stream), "pack")
+        if side is not None and (self.own or self.rest_late) and not torch.cuda.is_current_stream_capturing():
+            side.wait_stream(torch.cuda.current_stream(plan.device))          # the optimizer's update
+            with torch.cuda.stream(side):
+                late(_stream())
+                plan._own_packed = torch.cuda.Event()
+                plan._own_packed.record(side)
+        else:
+            late(st)
         L.check(lib.bp_conv_pack_jobs(L.ptr(self.jobs), L.ptr(self.first), self.njobs, self.total_blocks, st),
                 "batched pack")
         for cv, d, w, packed in self.rest:
