@@ -30,7 +30,6 @@ struct WsArgs {
   float* ws;
   int nsplit, tiles_x, tiles_y;
   int xvec, yvec;
-  int dbg;
 };
 
 template <int K, int S, int CXS, int CYS, int BH>
@@ -236,15 +235,14 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(WsArgs a) {
   //  and more than the overlap wins: 0.10 -> 0.15 ms; such shapes load and commit back to back)
   constexpr bool PIPE = GY * GX <= 16;
   int tile = split;
-  if (PIPE && tile < ntiles && !(a.dbg & 2)) issue(tile);
+  if (PIPE && tile < ntiles) issue(tile);
   for (; tile < ntiles; tile += a.nsplit) {
-    if (!PIPE && !(a.dbg & 2)) issue(tile);
+    if (!PIPE) issue(tile);
     __syncthreads();
-    if (!(a.dbg & 2)) commit();
+    commit();
     __syncthreads();
-    if (PIPE && tile + a.nsplit < ntiles && !(a.dbg & 2)) issue(tile + a.nsplit);
+    if (PIPE && tile + a.nsplit < ntiles) issue(tile + a.nsplit);
     // ---- k-steps: row r' (0..RS-1), pixel group g (0..7); this wave takes every 4th
-    if (!(a.dbg & 1))
     for (int s = wk; s < RS * 8; s += 4) {
       const int r = s >> 3, g = s & 7;
       const float bf = ys[((PADR + r) * YWS + 4 * g) * CYS + b_lane];
@@ -295,9 +293,7 @@ int launch(const bp_view* X, const PW& pwx, const bp_view* Y, const PW& pwy, int
   a.tiles_x = bp_ceil_div(Y->w, 32);
   a.tiles_y = bp_ceil_div(Y->h, BH);
   int64_t ntiles = (int64_t)Y->n * a.tiles_x * a.tiles_y;
-  static const int dbg = getenv("BP_WS_DEBUG") ? atoi(getenv("BP_WS_DEBUG")) : 0;
   static const int cap = getenv("BP_WS_NSPLIT") ? atoi(getenv("BP_WS_NSPLIT")) : 1024;
-  a.dbg = dbg;
   int64_t ns = ntiles < cap ? ntiles : cap;          // ~4 workgroups per CU
   a.nsplit = (int)ns;
   *need = (size_t)a.nsplit * K * K * CYS * CXS * sizeof(float);
