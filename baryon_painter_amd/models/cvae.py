@@ -190,19 +190,28 @@ class _Plan:
                 and os.environ.get("BP_LEVEL_SYNC", "1") != "0":
             self.levels = self._build_levels()
         self.branch = self._branch_streams = None
-        # (single device only: under data parallelism every batch-norm layer all-reduces its statistics, and
-        #  collectives of one communicator must not be in flight on several streams at once)
-        if os.environ.get("BP_BRANCH_STREAMS", "1") != "0" and self.q_units and self.p_units and model.sync is None:
+        # (not with global batch-norm statistics: every batch-norm layer then all-reduces its sums, and collectives of
+        #  one communicator must not be in flight on several streams at once; with local statistics -- throughput mode --
+        #  the only collective is the gradient all-reduce after the joins)
+        if os.environ.get("BP_BRANCH_STREAMS", "1") != "0" and self.q_units and self.p_units \
+                and (model.sync is None or not model.sync.sync_bn):
             self.branch = self._branch_streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
             self.ws_b, self.ws_c = torch.zeros_like(self.ws), torch.zeros_like(self.ws)
             for u in self._flat(self.q_units[1]):
                 u.ws_name = "ws_b"
             for u in self._flat(self.p_units):
                 u.ws_name = "ws_c"
-            # ... and their weight gradients get streams of their own too: nine small launches that would otherwise
-            # queue behind each other on the one weight-gradient stream after the main stream has finished
-            if self.side is not None and os.environ.get("BP_BRANCH_SIDE", "1") != "0":
-                self.side_branch = {k: (torch.cuda.Stream(device=dev), torch.zeros_like(self.ws)) for k in ("ws_b", "ws_c")}
+
+        # The weight gradients of the q_y_in / prior branches get streams of their own: nine small launches that would
+        # otherwise queue behind each other on the one weight-gradient stream after the main stream has finished.  Also
+        # under data parallelism (weight gradients issue no collectives), where the branches themselves share the
+        # main stream.
+        if self.side is not None and self.q_units and self.p_units and os.environ.get("BP_BRANCH_SIDE", "1") != "0":
+            self.side_branch = {k: (torch.cuda.Stream(device=dev), torch.zeros_like(self.ws)) for k in ("b", "c")}
+            for u in self._flat(self.q_units[1]):
+                u.side_name = "b"
+            for u in self._flat(self.p_units):
+                u.side_name = "c"
 
     # ---- bf16 policy (dtype="bf16", BASELINE.json configs[3]).  The generator trunk p_y_z_in and the first layer of
     # each head run on the bf16 matrix-core kernels and every p_y_z_in activation / gradient is stored as bf16: that
@@ -233,8 +242,8 @@ class _Plan:
         """(stream, workspace) for a unit's weight gradient, or (None, None): serial schedule."""
         if self.side is None:
             return None, None
-        if self.side_branch is not None and self.branch is not None and unit.ws_name in self.side_branch:
-            return self.side_branch[unit.ws_name]
+        if self.side_branch is not None and getattr(unit, "side_name", None) in self.side_branch:
+            return self.side_branch[unit.side_name]
         return self.side, self.ws2
 
     def impl_of(self, kind, unit=None):
