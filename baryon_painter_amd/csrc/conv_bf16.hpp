@@ -392,6 +392,9 @@ __global__ __launch_bounds__(64 * NW, 2) void igemm_bf16_kernel(BArgs a) {
       sf[j] = on ? lpw[cpad + ch + j] : 0.f;
       sl[j] = on ? lpw[2 * cpad + ch + j] : 1.f;
     }
+    bool relu = on && ch + U <= a.cin;
+#pragma unroll
+    for (int j = 0; j < U; ++j) relu = relu && sl[j] == 0.f;
 #pragma unroll
     for (int i = 0; i < SLOTS; ++i) {
       if (s_g[i] == -2) continue;
@@ -406,14 +409,19 @@ __global__ __launch_bounds__(64 * NW, 2) void igemm_bf16_kernel(BArgs a) {
       }
       float v[U], raw[U];
       unpack_unit<U, IN_BF16>(stage[i], raw);
+      if (relu) {        // batch-norm + ReLU (slopes 0, whole unit inside the tensor's channels): fma + max per element
 #pragma unroll
-      for (int j = 0; j < U; ++j) {
-        float t = 0.f;
-        if (s_g[i] >= 0 && ch + j < a.cin) {
-          t = raw[j];
-          if (on) { t = fmaf(t, sc[j], sf[j]); t = t > 0.f ? t : t * sl[j]; }
+        for (int j = 0; j < U; ++j) v[j] = s_g[i] >= 0 ? fmaxf(fmaf(raw[j], sc[j], sf[j]), 0.f) : 0.f;
+      } else {
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+          float t = 0.f;
+          if (s_g[i] >= 0 && ch + j < a.cin) {
+            t = raw[j];
+            if (on) { t = fmaf(t, sc[j], sf[j]); t = t > 0.f ? t : t * sl[j]; }
+          }
+          v[j] = t;
         }
-        v[j] = t;
       }
       const int e = tid + i * NTH;
       if constexpr (CC == 32) lds_store_unit<U>(lds_in + ((e % UPP) * a.npixp + e / UPP) * 8, v);

@@ -271,11 +271,18 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(WbArgs a) {
             c[0] = sc.x; c[1] = sc.y; c[2] = sc.z; c[3] = sc.w; f[0] = sf.x; f[1] = sf.y; f[2] = sf.z; f[3] = sf.w;
             l[0] = sl.x; l[1] = sl.y; l[2] = sl.z; l[3] = sl.w;
           }
+          // (batch-norm + ReLU -- every trunk layer: slope 0 -- is fma + max instead of fma + compare + multiply + select)
+          const bool relu = l[0] == 0.f && l[1] == 0.f && l[2] == 0.f && l[3] == 0.f;
+          if (relu) {
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            float u = raw[4 * h + j];
-            if (xon) { u = fmaf(u, c[j], f[j]); u = u > 0.f ? u : u * l[j]; }
-            v[4 * h + j] = ((xin >> i) & 1u) ? u : 0.f;
+            for (int j = 0; j < 4; ++j) v[4 * h + j] = ((xin >> i) & 1u) ? fmaxf(fmaf(raw[4 * h + j], c[j], f[j]), 0.f) : 0.f;
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              float u = raw[4 * h + j];
+              if (xon) { u = fmaf(u, c[j], f[j]); u = u > 0.f ? u : u * l[j]; }
+              v[4 * h + j] = ((xin >> i) & 1u) ? u : 0.f;
+            }
           }
         }
         lds_store_unit<8>(dst, v);

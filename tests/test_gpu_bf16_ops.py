@@ -60,10 +60,11 @@ CASES = [
 ]
 
 
+@pytest.mark.parametrize("relu", [False, True], ids=["leaky", "relu"])
 @pytest.mark.parametrize("io", [(True, True), (False, True), (True, False), (False, False)],
                          ids=["bf16-bf16", "f32-bf16", "bf16-f32", "f32-f32"])
 @pytest.mark.parametrize("case", CASES, ids=lambda c: "%s%d_%d_k%ds%d_%dx%d" % ("T" if c[0] else "C", *c[1:5], *c[6][1:]))
-def test_bf16_convolution_forward_dgrad_wgrad(case, io):
+def test_bf16_convolution_forward_dgrad_wgrad(case, io, relu):
     lib = L.load()
     tr, ci, co, k, s, p, (n, h, w), in_cs = case
     in_bf, out_bf = io
@@ -73,6 +74,8 @@ def test_bf16_convolution_forward_dgrad_wgrad(case, io):
     scale = rng.uniform(0.5, 1.5, ci).astype(np.float32)
     shift = rng.uniform(0.2, 0.6, ci).astype(np.float32)          # act(0) != 0: padding must stay 0
     slope = rng.uniform(0.0, 0.3, ci).astype(np.float32)
+    if relu:
+        slope[:] = 0.0                 # batch-norm + ReLU: the staging code's fma + max path (every trunk layer)
     xin = bf16_round(x) if in_bf else x
     # the kernel evaluates fmaf(x, scale, shift) in fp32: product exact in float64, one rounding
     t = (xin.astype(np.float64) * scale[None, :, None, None].astype(np.float64)
