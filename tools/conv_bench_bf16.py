@@ -1,7 +1,7 @@
 """Micro-benchmark of one bf16 convolution layer through the C ABI (forward, data gradient, weight gradient).
 usage: conv_bench_bf16.py transposed cin cout k stride pad n h w [reps]
 YF32=1: the produced tensor and its gradient are fp32 (the heads' first layer: bf16 trunk in, fp32 out); PWIN=1: a
-pending batch-norm + ReLU on the input (as in the network)."""
+pending batch-norm + ReLU on the input (as in the network); STATS=1: also the forward with the statistics epilogue."""
 import ctypes as C, os, sys, time
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -44,6 +44,11 @@ def run(name, fn):
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / reps
     print(f"{name:8s} {dt*1e6:9.1f} us  {flop/dt/1e12:8.1f} TF/s  {(x.numel()*x.element_size()+y.numel()*y.element_size())/dt/1e9:8.1f} GB/s", flush=True)
 which = os.environ.get("WHICH", "fdw")
+if os.environ.get("STATS") == "1":      # forward with the batch-norm sums from the epilogue (bp_conv_forward_stats)
+    nb = lib.bp_conv_stats_workspace(C.byref(cv), 0, C.byref(xv), C.byref(yv), L.IMPL_BF16)
+    sums = torch.zeros(2 * co, dtype=torch.float64, device="cuda")
+    wss = torch.zeros(nb // 8 + 8, dtype=torch.float64, device="cuda")
+    run("fwd+stat", lambda: L.check(lib.bp_conv_forward_stats(C.byref(cv), C.byref(xv), pw, L.ptr(pf), C.byref(yv), L.ptr(sums), L.ptr(wss), nb, L.IMPL_BF16, st)))
 if "f" in which: run("forward", lambda: L.check(lib.bp_conv_forward(C.byref(cv), C.byref(xv), pw, L.ptr(pf), L.ptr(wt), None, C.byref(yv), L.IMPL_BF16, st)))
 if "d" in which: run("dgrad", lambda: L.check(lib.bp_conv_backward_data(C.byref(cv), C.byref(dyv), L.ptr(pb), L.ptr(wt), C.byref(dxv), L.IMPL_BF16, st)))
 if "w" in which: run("wgrad", lambda: L.check(lib.bp_conv_backward_weight(C.byref(cv), C.byref(xv), pw, C.byref(dyv), L.ptr(dw), None, L.ptr(ws), ws.numel() * 8, L.IMPL_BF16, st)))
