@@ -283,3 +283,20 @@ def test_vectorised_redshift_interpolation_equals_the_scalar_one():
         assert np.array_equal(np.array([T.interpolate_z(st, float(z))[key] for z in zs]), T.interpolate_z_many(st, zs, key))
     one = {0.3: {"mean": 1.0, "var": 2.0}}
     assert np.array_equal(T.interpolate_z_many(one, zs), np.full(len(zs), 2.0))
+
+
+def test_dense_gradient_buffer_of_a_channel_slice():
+    """graph.Slot: a channel slice normally keeps its gradient inside the wide slot's gradient buffer (same stride);
+    with ``dense_grad`` (the latent channel of the generator's 4-channel input, cvae._Plan) it owns a dense buffer --
+    host bookkeeping only, no kernel."""
+    import torch
+    from baryon_painter_amd.models.graph import Slot
+    wide = Slot.new(2, 4, 6, 3, "cpu", cstride=4)
+    z = wide.sub(0, 1, dense_grad=True)
+    ya = wide.sub(1, 3)
+    gz, gy = z.ensure_grad(), ya.ensure_grad()
+    assert (gz.c, gz.cstride, gz.coff) == (1, 1, 0) and tuple(z.grad_buf.shape) == (2, 4, 6, 1)
+    assert (gy.c, gy.cstride, gy.coff) == (2, 4, 1) and ya.grad_buf is wide.grad_buf
+    assert z.grad_buf.data_ptr() != wide.grad_buf.data_ptr()
+    assert z.ensure_grad() is gz                           # allocated once
+    assert torch.count_nonzero(z.grad_buf) == 0
