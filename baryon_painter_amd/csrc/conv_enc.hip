@@ -334,6 +334,156 @@ __global__ void enc_dgrad_pack_kernel(const float* w, int64_t sa, int64_t sb, fl
   wp[idx] = w[co * sa + ci * sb + ky * 8 + kx];
 }
 
+// ------------------------------------------------------------------------------------------------ k4 s2 {1,2} -> 8
+// The first layer of the recognition / prior networks (512^2 -> 256^2, utils.py:96 conv_down(c, 8, scale=2)), forward.
+// The per-pixel vector-ALU kernel (conv_small.hip) is bound by its 128 / 256 weights, which do not fit the scalar
+// registers and arrive in sixteen waited-for batches: 0.15 ms for the 2-channel layer against 0.05 of HBM time.  As a
+// GEMM it is K = 16 taps x CI = 4 or 8 k-steps of the 16x16x4 MFMA with the weights in 4 or 8 registers: the (tx, ci)
+// floats of a tap row are consecutive in the NHWC input row starting at pixel 2x - 1, so lane (pixel, kq) reads float
+// 4j + kq of its run -- 64 consecutive-ish addresses per wave, no conflicts.  Rows 8..15 of the tile are padding (8
+// produced channels): the matrix work is 27 us either way.  A wave owns two output rows of the 8 x 32 tile; outputs
+// go straight from the accumulators to memory; batch-norm sums per lane over its tiles, one row per workgroup.
+constexpr int E0_R = 8, E0_W = 32;                   // output tile
+constexpr int E0_IR = 2 * E0_R + 2, E0_IC = 2 * E0_W + 2;
+
+template <int CI>
+__global__ __launch_bounds__(256) void enc0_fwd_kernel(EncArgs a) {
+  constexpr int KS = 4 * CI;                         // k-steps: 4 tap rows x CI
+  constexpr int RP = E0_IC * CI;                     // LDS row pitch in floats
+  constexpr int NU = E0_IR * E0_IC, UX = (NU + 255) / 256;      // staging units: one input pixel each
+  __shared__ __attribute__((aligned(16))) float xs[E0_IR * RP + 4];
+  __shared__ double red[4][16];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wk = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, kq = lane >> 4;
+
+  float wr[KS];
+#pragma unroll
+  for (int j = 0; j < KS; ++j) wr[j] = a.wp[j * 64 + lane];
+  float bias4[4] = {0.f, 0.f, 0.f, 0.f};
+  if (a.bias && kq < 2) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bias4[r] = a.bias[4 * kq + r];
+  }
+  const bool on = a.pw.scale != nullptr;
+  float psc[CI], psf[CI], psl[CI];
+#pragma unroll
+  for (int c = 0; c < CI; ++c) { psc[c] = on ? a.pw.scale[c] : 1.f; psf[c] = on ? a.pw.shift[c] : 0.f; psl[c] = on ? a.pw.slope[c] : 1.f; }
+
+  const int tiles_per_img = a.tiles_x * a.tiles_y;
+  float xv[UX][CI];
+  unsigned okm = 0;
+  auto issue = [&](int tile) {
+    const int n = tile / tiles_per_img;
+    const int trem = tile - n * tiles_per_img;
+    const int ty_ = trem / a.tiles_x, tx_ = trem - ty_ * a.tiles_x;
+    const int iy0 = 2 * E0_R * ty_ - 1, ix0 = 2 * E0_W * tx_ - 1;
+    const float* base = a.in + (int64_t)n * a.ih * a.iw * a.ics + a.ico;
+    okm = 0;
+#pragma unroll
+    for (int j = 0; j < UX; ++j) {
+      const int e = min(tid + j * 256, NU - 1);
+      const int r = e / E0_IC, c = e - r * E0_IC;
+      const int iy = iy0 + r, ix = ix0 + c;
+      if (iy >= 0 && iy < a.ih && ix >= 0 && ix < a.iw) okm |= 1u << j;
+      const float* q = base + ((int64_t)min(max(iy, 0), a.ih - 1) * a.iw + min(max(ix, 0), a.iw - 1)) * a.ics;
+      if (CI == 2 && a.in_vec) {                    // (in_vec here: 8-byte aligned channel pairs)
+        const float2 t = *reinterpret_cast<const float2*>(q);
+        xv[j][0] = t.x; xv[j][CI - 1] = t.y;
+      } else {
+#pragma unroll
+        for (int c2 = 0; c2 < CI; ++c2) xv[j][c2] = q[c2];
+      }
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int j = 0; j < UX; ++j) {
+      const int e = tid + j * 256;
+      if (e < NU) {
+#pragma unroll
+        for (int c2 = 0; c2 < CI; ++c2) {
+          float v = xv[j][c2];
+          if (on) { v = fmaf(v, psc[c2], psf[c2]); v = v > 0.f ? v : v * psl[c2]; }
+          xs[e * CI + c2] = ((okm >> j) & 1) ? v : 0.f;
+        }
+      }
+    }
+  };
+
+  float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
+  int tile = blockIdx.x;
+  if (tile < a.ntiles) issue(tile);
+  for (; tile < a.ntiles; tile += gridDim.x) {
+    __syncthreads();
+    commit();
+    __syncthreads();
+    const int next = tile + gridDim.x;
+    if (next < a.ntiles) issue(next);
+    const int n = tile / tiles_per_img;
+    const int trem = tile - n * tiles_per_img;
+    const int ty_ = trem / a.tiles_x, tx_ = trem - ty_ * a.tiles_x;
+    v4f acc[2][2];                               // [output row of this wave][16-pixel half]
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int hx = 0; hx < 2; ++hx) acc[u][hx] = v4f{bias4[0], bias4[1], bias4[2], bias4[3]};
+#pragma unroll
+    for (int j = 0; j < KS; ++j) {
+      const int ty = j / CI, jj = j % CI;        // tap row, 4-float step inside its run of 4 CI floats
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int hx = 0; hx < 2; ++hx) {
+          const float bf = xs[(2 * (2 * wk + u) + ty) * RP + (2 * (16 * hx + li)) * CI + 4 * jj + kq];
+          acc[u][hx] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[j], bf, acc[u][hx], 0, 0, 0);
+        }
+    }
+    if (kq < 2) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int hx = 0; hx < 2; ++hx) {
+          const int oy = E0_R * ty_ + 2 * wk + u, ox = E0_W * tx_ + 16 * hx + li;
+          if (oy < a.oh && ox < a.ow) {
+            float* o = a.out + (((int64_t)n * a.oh + oy) * a.ow + ox) * a.ocs + a.oco + 4 * kq;
+            const v4f v = acc[u][hx];
+            if (a.out_vec) *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+            else { o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3]; }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { ssum[r] += v[r]; ssq[r] = fmaf(v[r], v[r], ssq[r]); }
+          }
+        }
+    }
+  }
+  if (a.stat) {
+    double v[8];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { v[r] = (double)ssum[r]; v[4 + r] = (double)ssq[r]; }
+#pragma unroll
+    for (int sh = 1; sh < 16; sh <<= 1)
+#pragma unroll
+      for (int r = 0; r < 8; ++r) v[r] += __shfl_xor(v[r], sh, 64);
+    if (li == 0 && kq < 2) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { red[wk][4 * kq + r] = v[r]; red[wk][8 + 4 * kq + r] = v[4 + r]; }
+    }
+    __syncthreads();
+    if (tid < 16) a.stat[(int64_t)blockIdx.x * 16 + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+  }
+}
+
+// wp[j][kq][co]: k-step j = (ty, jj): float f = 4 jj + kq of tap row ty's run -> (tx, ci) = (f / CI, f % CI); rows 8..15: 0
+__global__ void enc0_fwd_pack_kernel(const float* w, int64_t sa, int64_t sb, int ci_n, float* wp) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= 4 * ci_n * 64) return;
+  const int co = idx & 15, kq = (idx >> 4) & 3, j = idx >> 6;
+  const int ty = j / ci_n, jj = j % ci_n;
+  const int f = 4 * jj + kq;
+  const int tx = f / ci_n, ci = f % ci_n;
+  wp[idx] = co < 8 ? w[ci * sa + co * sb + ty * 4 + tx] : 0.f;
+}
+
 // ------------------------------------------------------------------------------------------------ weight gradient
 //   dW[co][ci][ky][kx] = sum_{n,oy,ox} act(X)[n, 4 oy - 2 + ky, 4 ox - 2 + kx, ci] * dY[n, oy, ox, co]
 // GEMM K = output pixels.  MFMA rows = the 16 channels of dY, columns = 16 consecutive floats (kx, ci) of X's tap row
@@ -466,11 +616,18 @@ bool bp_enc_fwd_ok(const ConvGeom& g) {
 bool bp_enc_dgrad_ok(const ConvGeom& g) {
   return !enc_off() && g.gather_transposed && g.k == 8 && g.stride == 4 && g.pad == 2 && g.cin_g == 16 && g.cout_g == 8;
 }
-bool bp_enc_ok(const ConvGeom& g) { return bp_enc_fwd_ok(g) || bp_enc_dgrad_ok(g); }
-int64_t bp_enc_packed_floats() { return 8192; }
+bool bp_enc0_fwd_ok(const ConvGeom& g) {
+  static const bool off0 = getenv("BP_NOENC0") != nullptr;
+  return !enc_off() && !off0 && !g.gather_transposed && g.k == 4 && g.stride == 2 && g.pad == 1 &&
+         (g.cin_g == 1 || g.cin_g == 2) && g.cout_g == 8;
+}
+bool bp_enc_ok(const ConvGeom& g) { return bp_enc_fwd_ok(g) || bp_enc_dgrad_ok(g) || bp_enc0_fwd_ok(g); }
+int bp_enc_kernel_id(const ConvGeom& g) { return bp_enc0_fwd_ok(g) ? 780000 + g.cin_g : (g.gather_transposed ? 770000 : 760000); }
+int64_t bp_enc_packed_floats(const ConvGeom& g) { return bp_enc0_fwd_ok(g) ? 4 * g.cin_g * 64 : 8192; }
 
 int bp_enc_pack(const ConvGeom& g, const WeightMap& wm, const float* w_torch, float* packed, hipStream_t st) {
-  if (bp_enc_fwd_ok(g)) hipLaunchKernelGGL(enc_fwd_pack_kernel, dim3(32), dim3(256), 0, st, w_torch, wm.sa, wm.sb, packed);
+  if (bp_enc0_fwd_ok(g)) hipLaunchKernelGGL(enc0_fwd_pack_kernel, dim3(2), dim3(256), 0, st, w_torch, wm.sa, wm.sb, g.cin_g, packed);
+  else if (bp_enc_fwd_ok(g)) hipLaunchKernelGGL(enc_fwd_pack_kernel, dim3(32), dim3(256), 0, st, w_torch, wm.sa, wm.sb, packed);
   else hipLaunchKernelGGL(enc_dgrad_pack_kernel, dim3(32), dim3(256), 0, st, w_torch, wm.sa, wm.sb, packed);
   BP_CHECK_LAUNCH();
   return BP_OK;
@@ -489,8 +646,23 @@ static int enc_fwd_grid(const bp_view* in, const bp_view* out, int* tiles_x, int
   return *ntiles < 256 * per_cu ? *ntiles : 256 * per_cu;
 }
 
+static int enc0_fwd_grid(const bp_view* in, const bp_view* out, int* tiles_x, int* tiles_y, int* ntiles) {
+  static const int cap = getenv("BP_ENC0_WGS") ? atoi(getenv("BP_ENC0_WGS")) : 2048;
+  *tiles_x = bp_ceil_div(out->w, E0_W);
+  *tiles_y = bp_ceil_div(out->h, E0_R);
+  const int64_t nt = (int64_t)in->n * *tiles_x * *tiles_y;
+  if (nt > 0x7fffffff) return -1;
+  *ntiles = (int)nt;
+  return *ntiles < cap ? *ntiles : cap;
+}
+
 // forward only: {sum y, sum y^2} per produced channel (mode 1), one row per workgroup
 size_t bp_enc_stats_workspace(const ConvGeom& g, const bp_view* in, const bp_view* out, int mode) {
+  if (bp_enc0_fwd_ok(g) && mode == 1) {
+    int tx, ty, nt;
+    const int grid = enc0_fwd_grid(in, out, &tx, &ty, &nt);
+    return grid > 0 ? bp_stats_rows_bytes(grid, 8) : 0;
+  }
   if (!bp_enc_fwd_ok(g) || mode != 1) return 0;
   int tx, ty, nt;
   const int grid = enc_fwd_grid(in, out, &tx, &ty, &nt);
@@ -506,6 +678,21 @@ int bp_enc_run(const ConvGeom& g, const bp_view* in, const PW& pw, const float* 
   a.wp = packed; a.pw = pw; a.n = in->n;
   a.in_vec = bp_view_vec4(in) ? 1 : 0;
   a.out_vec = bp_view_vec4(out) ? 1 : 0;
+  if (bp_enc0_fwd_ok(g)) {
+    const int grid = enc0_fwd_grid(in, out, &a.tiles_x, &a.tiles_y, &a.ntiles);
+    if (grid <= 0) return BP_EUNSUPPORTED;
+    if (sr) {
+      if (bias || sr->mode != 1) return BP_EUNSUPPORTED;
+      if (!sr->ws || sr->ws_bytes < bp_stats_rows_bytes(grid, 8) || !sr->sums) return BP_EWORKSPACE;
+      a.stat = reinterpret_cast<double*>(sr->ws);
+    }
+    // (in_vec for this kernel: channel pairs on 8-byte boundaries)
+    a.in_vec = (g.cin_g == 2 && in->cstride % 2 == 0 && in->coff % 2 == 0 && reinterpret_cast<uintptr_t>(in->ptr) % 8 == 0) ? 1 : 0;
+    if (g.cin_g == 1) hipLaunchKernelGGL(enc0_fwd_kernel<1>, dim3(grid), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(enc0_fwd_kernel<2>, dim3(grid), dim3(256), 0, st, a);
+    BP_CHECK_LAUNCH();
+    return sr ? bp_stats_rows_finish(a.stat, grid, 8, sr, st) : BP_OK;
+  }
   if (bp_enc_fwd_ok(g)) {
     const int grid = enc_fwd_grid(in, out, &a.tiles_x, &a.tiles_y, &a.ntiles);
     if (grid <= 0) return BP_EUNSUPPORTED;

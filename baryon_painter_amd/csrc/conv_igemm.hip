@@ -1491,14 +1491,15 @@ int bp_flat_h7_run(const bp_view* in, const PW& pw, const float* packed, const f
 
 // ... and the k8 stride-4 layer 8 -> 16 of the recognition / prior networks, forward and data gradient (conv_enc.hip)
 bool bp_enc_ok(const ConvGeom& g);
-int64_t bp_enc_packed_floats();
+int bp_enc_kernel_id(const ConvGeom& g);
+int64_t bp_enc_packed_floats(const ConvGeom& g);
 int bp_enc_pack(const ConvGeom& g, const WeightMap& wm, const float* w_torch, float* packed, hipStream_t st);
 size_t bp_enc_stats_workspace(const ConvGeom& g, const bp_view* in, const bp_view* out, int mode);
 int bp_enc_run(const ConvGeom& g, const bp_view* in, const PW& pw, const float* packed, const float* bias,
                const bp_view* out, hipStream_t st, const IgemmStatsReq* sr);
 
 int bp_igemm_kernel_id(const ConvGeom& g) {
-  if (bp_enc_ok(g)) return g.gather_transposed ? 770000 : 760000;
+  if (bp_enc_ok(g)) return bp_enc_kernel_id(g);
   if (bp_stem_ok(g)) return 700000;
   if (bp_flat_ok(g)) return 710000;
   if (bp_flat_t4_ok(g) && !bp_flat_t64_ok(g)) return 720000;
@@ -1512,7 +1513,7 @@ int bp_igemm_kernel_id(const ConvGeom& g) {
 }
 
 int64_t bp_igemm_packed_floats(const ConvGeom& g) {
-  if (bp_enc_ok(g)) return bp_enc_packed_floats();
+  if (bp_enc_ok(g)) return bp_enc_packed_floats(g);
   if (bp_stem_ok(g)) return bp_stem_packed_floats();
   if (bp_flat_ok(g)) return bp_flat_packed_floats();
   if (bp_flat_t4_ok(g) && !bp_flat_t64_ok(g)) return bp_flat_t4_packed_floats();

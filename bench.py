@@ -83,6 +83,8 @@ def kernel_name(kind, unit, lib):
     if kind == "backward_data" and getattr(unit, "_sub", None) is not None:
         cv = unit._sub["cv"]           # data gradient restricted to a channel slice
     kid = lib.bp_conv_kernel_id(C.byref(cv), L.PACK_FWD if kind == "forward" else L.PACK_BWD)
+    if kid in (780001, 780002):
+        return "enc0_fwd_kernel<%d>" % (kid - 780000)
     if kid == 760000:
         return "enc_fwd_kernel"
     if kid == 770000:

@@ -34,8 +34,10 @@ DRAWS = 3
 CASES = [("fid128_n2", 128, 2), ("fid256_n4", 256, 4), ("fid512_n2", 512, 2)]
 
 
-def gradient(arch, n, size, delta, draw, seed_w=7, seed_d=1234, seed_eps=99):
+def gradient(arch, n, size, delta, draw, seed_w=7, seed_d=1234, seed_eps=99, alpha=None):
     m = CVAEOracle(arch, dtype=np.float64)
+    if alpha is not None:
+        m.alpha_var = alpha               # (two-head cases of tests/test_gpu_model.py: the variance head's weight)
     P = syn.fill_params(m.param_shapes(), seed_w)
     if delta > 0:
         rng = np.random.default_rng(1000 + draw)

@@ -43,6 +43,9 @@ CASES = [
     (0, 3, 16, 5, 1, 2, (40, 130, 200)),      # ... with more tiles than workgroups (grid-stride walk)
     (0, 8, 16, 8, 4, 2, (3, 37, 70)),         # conv_enc.hip: sums kept per thread over its tiles, one row per workgroup
     (0, 8, 16, 8, 4, 2, (100, 64, 128)),      # ... more tiles than workgroups
+    (0, 1, 8, 4, 2, 1, (3, 37, 70)),          # conv_enc.hip enc0_fwd_kernel: the {1,2} -> 8 stems of the encoders
+    (0, 2, 8, 4, 2, 1, (3, 37, 70)),
+    (0, 2, 8, 4, 2, 1, (40, 128, 256)),       # ... more tiles than workgroups
 ]
 
 

@@ -131,12 +131,14 @@ def test_model_matches_reference_goldens(tag, size, n, two, alpha, impl, golden_
         # two-tile) gradients by up to 1e-2; which side a float32 evaluation lands on is chance.
         floor = {k: reference_noise_floor(tag, k, golden_model) if f"{tag}/grad64/{k}/shape" in golden_model else 0.0
                  for k in g}
-        if alpha is None:
-            from golden import make_goldens_cond as mc
-            for draw in range(mc.DRAWS):
-                gd = mc.gradient(arch, n, size, mc.DELTA, draw)
-                for k in g:
-                    floor[k] = max(floor[k], G.rel_err(gd[k], g[k]))
+        # (... for the two-head cases too: their fixtures hold no conditioning draws, and a kernel that merely adds in a
+        #  different order -- the MFMA form of the recognition / prior stems -- moved p_z_in.7.bias by 1.5 of the old
+        #  limit at 64^2 through one such unit)
+        from golden import make_goldens_cond as mc
+        for draw in range(mc.DRAWS):
+            gd = mc.gradient(arch, n, size, mc.DELTA, draw, alpha=alpha)
+            for k in g:
+                floor[k] = max(floor[k], G.rel_err(gd[k], g[k]))
         errs = sorted(((G.rel_err(p.grad.cpu().numpy(), g[k]) / max(4 * floor[k], 2e-3), k)
                        for k, p in m.named_parameters()), reverse=True)
         print("worst gradient errors vs float64 oracle, in units of max(4 x noise floor, 2e-3):", errs[:5])
