@@ -16,6 +16,8 @@
 #include <cstdlib>
 
 // conv_igemm.hip: fold of per-workgroup rows of n doubles into sr->sums
+size_t bp_stats_rows_bytes(int64_t rows, int C);
+int bp_stats_rows_finish(double* ws, int64_t rows, int C, const IgemmStatsReq* sr, hipStream_t st);
 int bp_stats_row_stride(int n);
 size_t bp_stats_rows_bytes_n(int64_t rows, int n);
 int bp_stats_rows_finish_n(double* ws, int64_t rows, int n, const IgemmStatsReq* sr, hipStream_t st);
@@ -252,6 +254,7 @@ struct TinyArgs {
   int pad;
   int64_t total;   // produced pixels per image
   int n;
+  double* stat;    // transposed form, one produced channel: rows {sum y, sum y^2} per workgroup (nullptr: none)
 };
 
 // gather form: out[y, x, :] = sum_{ty,tx,ci} act(in[S*y - pad + ty, S*x - pad + tx, ci]) * wp[ty][tx][ci][:]
@@ -319,8 +322,10 @@ __global__ __launch_bounds__(256) void tiny_gather_kernel(TinyArgs a) {
 // r = (Y+pad) % S: K/S taps per dimension.
 template <int K, int S, int CI, int CO>
 __global__ __launch_bounds__(256) void tiny_transposed_kernel(TinyArgs a) {
-  const unsigned i = blockIdx.x * 256u + threadIdx.x;
-  if (i >= (unsigned)a.total) return;
+  const unsigned i0 = blockIdx.x * 256u + threadIdx.x;
+  const bool live = i0 < (unsigned)a.total;
+  if (!live && !a.stat) return;
+  const unsigned i = live ? i0 : 0u;             // (idle lanes of the last workgroup: compute pixel 0, store nothing)
   constexpr int T = K / S;
   const int X = i % (unsigned)a.out_w;
   const int Y = i / (unsigned)a.out_w;
@@ -352,8 +357,25 @@ __global__ __launch_bounds__(256) void tiny_transposed_kernel(TinyArgs a) {
     }
   }
   float* o = a.out + (((int64_t)n * a.out_h + Y) * a.out_w + X) * a.out_cs + a.out_co;
+  if (live) {
 #pragma unroll
-  for (int co = 0; co < CO; ++co) o[co] = acc[co];
+    for (int co = 0; co < CO; ++co) o[co] = acc[co];
+  }
+  if constexpr (CO == 1) {
+    if (a.stat) {          // batch-norm sums of what was stored (the latent up-sampler's strided one-channel output:
+      //                      the separate pass reads a 4-channel slot for one channel, 0.08 ms at 512^2)
+      __shared__ double red[4][2];
+      double d1 = live ? (double)acc[0] : 0.0, d2 = d1 * d1;
+#pragma unroll
+      for (int sh = 32; sh > 0; sh >>= 1) { d1 += __shfl_down(d1, sh, 64); d2 += __shfl_down(d2, sh, 64); }
+      if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][0] = d1; red[threadIdx.x >> 6][1] = d2; }
+      __syncthreads();
+      if (threadIdx.x < 2) {
+        const int64_t row = (int64_t)blockIdx.y * gridDim.x + blockIdx.x;
+        a.stat[row * 2 + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+      }
+    }
+  }
 }
 
 template <int K, int S, int CI, int CO>
@@ -374,15 +396,28 @@ bool tiny_ok(const ConvGeom& g) {
   return (g.cin_g == 1 && g.cout_g == 1) || (g.k == 4 && g.cin_g <= 2 && g.cout_g == 8);
 }
 
+bool tiny_stats_geom(const ConvGeom& g) { return tiny_ok(g) && g.gather_transposed && g.cin_g == 1 && g.cout_g == 1; }
+int64_t tiny_rows(const bp_view* out) { return (((int64_t)out->h * out->w + 255) / 256) * out->n; }
+
 int tiny_run(const ConvGeom& g, const bp_view* in, const PW& pw, const float* packed, const float* bias,
-             const bp_view* out, hipStream_t st) {
+             const bp_view* out, hipStream_t st, const IgemmStatsReq* sr = nullptr) {
   TinyArgs a{};
+  if (sr) {
+    const int64_t rows = tiny_rows(out);
+    if (sr->mode != 1 || !tiny_stats_geom(g) || bias) return BP_EUNSUPPORTED;
+    if (!sr->ws || sr->ws_bytes < bp_stats_rows_bytes(rows, 1) || !sr->sums) return BP_EWORKSPACE;
+    a.stat = reinterpret_cast<double*>(sr->ws);
+  }
   a.in = in->ptr; a.in_h = in->h; a.in_w = in->w; a.in_cs = in->cstride; a.in_co = in->coff;
   a.out = out->ptr; a.out_h = out->h; a.out_w = out->w; a.out_cs = out->cstride; a.out_co = out->coff;
   a.wp = packed; a.bias = bias; a.pw = pw; a.pad = g.pad;
   a.total = (int64_t)out->h * out->w; a.n = out->n;
   if (a.total > 0x7fffff00LL || out->n > 65535) return BP_EUNSUPPORTED;
   const bool tr = g.gather_transposed != 0;
+  if (sr) {
+    const int rc = g.k == 4 ? launch_tiny<4, 2, 1, 1>(a, tr, st) : launch_tiny<8, 4, 1, 1>(a, tr, st);
+    return rc != BP_OK ? rc : bp_stats_rows_finish(a.stat, tiny_rows(out), 1, sr, st);
+  }
   if (g.k == 4 && g.cin_g == 1 && g.cout_g == 1) return launch_tiny<4, 2, 1, 1>(a, tr, st);
   if (g.k == 8 && g.cin_g == 1 && g.cout_g == 1) return launch_tiny<8, 4, 1, 1>(a, tr, st);
   if (g.k == 4 && g.cin_g == 1 && g.cout_g == 8 && !tr) return launch_tiny<4, 2, 1, 8>(a, tr, st);
@@ -458,14 +493,15 @@ int bp_small_pack(const ConvGeom& g, const WeightMap& wm, const float* w_torch, 
 
 // mode 3 (IgemmStatsReq): activation backward of the produced slot in the epilogue; 0 = this layer has none
 size_t bp_small_stats_workspace(const ConvGeom& g, const bp_view* in, const bp_view* out, int mode) {
+  if (mode == 1 && tiny_stats_geom(g)) return bp_stats_rows_bytes(tiny_rows(out), 1);
   if (mode != 3 || tiny_ok(g) || !act_geom(g)) return 0;
   return bp_stats_rows_bytes_n(act_rows(out), 3 * g.cout_g);
 }
 
 int bp_small_run(const ConvGeom& g, const bp_view* in, const PW& pw, const float* packed, const float* bias,
                  const bp_view* out, hipStream_t st, const IgemmStatsReq* sr) {
-  if (sr && (sr->mode != 3 || tiny_ok(g) || !act_geom(g) || bias)) return BP_EUNSUPPORTED;
-  if (tiny_ok(g)) return tiny_run(g, in, pw, packed, bias, out, st);
+  if (tiny_ok(g)) return tiny_run(g, in, pw, packed, bias, out, st, sr);
+  if (sr && (sr->mode != 3 || !act_geom(g) || bias)) return BP_EUNSUPPORTED;
   SmallArgs a{};
   a.in = in->ptr; a.in_h = in->h; a.in_w = in->w; a.in_cs = in->cstride; a.in_co = in->coff;
   a.out = out->ptr; a.out_h = out->h; a.out_w = out->w; a.out_cs = out->cstride; a.out_co = out->coff;

@@ -46,6 +46,9 @@ CASES = [
     (0, 1, 8, 4, 2, 1, (3, 37, 70)),          # conv_enc.hip enc0_fwd_kernel: the {1,2} -> 8 stems of the encoders
     (0, 2, 8, 4, 2, 1, (3, 37, 70)),
     (0, 2, 8, 4, 2, 1, (40, 128, 256)),       # ... more tiles than workgroups
+    (1, 1, 1, 8, 4, 2, (3, 9, 11)),           # conv_small.hip per-pixel transposed kernel (the latent up-sampler)
+    (1, 1, 1, 4, 2, 1, (3, 9, 11)),
+    (1, 1, 1, 8, 4, 2, (5, 32, 32)),          # ... more than 2048 workgroup rows: the fold runs
 ]
 
 
