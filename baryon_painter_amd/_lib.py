@@ -62,6 +62,7 @@ _CP = C.POINTER(Conv)
 # name -> (restype, argtypes); one entry per declaration in include/bp_hip.h
 SIGNATURES = {
     "bp_version": (C.c_int, []),
+    "bp_set_option": (C.c_int, [C.c_char_p, C.c_int]),
     "bp_strerror": (C.c_char_p, [C.c_int]),
     "bp_conv_packed_floats": (C.c_int64, [_CP, C.c_int]),
     "bp_conv_kernel_id": (C.c_int, [_CP, C.c_int]),

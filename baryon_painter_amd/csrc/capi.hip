@@ -1,6 +1,7 @@
 // C ABI of the convolution entry points (include/bp_hip.h): shape validation on the host, then
 // dispatch to the MFMA kernels (conv_igemm.hip / conv_wgrad.hip) or the direct ones.
 #include "common.hpp"
+#include <cstring>
 
 int64_t bp_igemm_packed_floats(const ConvGeom& g);
 int bp_igemm_kernel_id(const ConvGeom& g);
@@ -32,6 +33,8 @@ size_t bp_wgrad_bf16_workspace(const bp_conv* cv, const bp_view* X, const bp_vie
 int bp_wgrad_bf16_run(const bp_conv* cv, const bp_view* X, const PW& pwx, const bp_view* Y, const PW& pwy, float* dst,
                       void* workspace, size_t workspace_bytes, hipStream_t st);
 
+void bp_bf16_ws_set(int v);       // conv_bf16_ws.hip
+
 namespace {
 
 bool conv_ok(const bp_conv* cv) {
@@ -62,6 +65,12 @@ int bp_wgrad_defer_flush_impl(hipStream_t st, int end);
 extern "C" {
 
 int bp_version(void) { return 100; }
+
+int bp_set_option(const char* name, int value) {
+  if (!name) return BP_EINVAL;
+  if (!strcmp(name, "bf16_ws")) { bp_bf16_ws_set(value); return BP_OK; }
+  return BP_EUNSUPPORTED;
+}
 
 const char* bp_strerror(int code) {
   switch (code) {

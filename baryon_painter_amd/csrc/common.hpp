@@ -76,6 +76,9 @@ __device__ __forceinline__ float pw_apply(const PW& pw, int ch, float x) {
   return t > 0.f ? t : t * pw.slope[ch];
 }
 
+// ReLU that keeps a NaN a NaN, as torch.relu does (fmaxf(NaN, 0) is 0: a diverged run would paint finite tiles)
+__device__ __forceinline__ float bp_relu_nan(float t) { return t < 0.f ? 0.f : t; }
+
 // The pending activation of 4 consecutive channels held in registers (staging loops: a thread
 // always handles the same channel quad, so the parameters are loaded once, not per element).
 struct PW4 {

@@ -17,6 +17,15 @@ size_t bp_bf16_flat_stats_workspace(const ConvGeom& g, const bp_view* in, const 
 int bp_bf16_flat_run(const ConvGeom& g, const bp_view* in, const PW& pw, const u16* packed_flat, const bp_view* out,
                      hipStream_t st, const IgemmStatsReq* sr);
 
+// conv_bf16_ws.hip: weights-stationary kernel of the 128 -> 128 k3 trunk; its weight image follows the other two
+bool bp_bf16_ws_geom_ok(const ConvGeom& g);
+int64_t bp_bf16_ws_packed_elems(const ConvGeom& g);
+int bp_bf16_ws_pack(const ConvGeom& g, const WeightMap& wm, const float* w_torch, u16* dst, hipStream_t st);
+bool bp_bf16_ws_ok(const ConvGeom& g, const bp_view* in, const bp_view* out, const float* bias, int mode);
+size_t bp_bf16_ws_stats_workspace(const ConvGeom& g, const bp_view* in, const bp_view* out);
+int bp_bf16_ws_run(const ConvGeom& g, const bp_view* in, const PW& pw, const u16* packed_ws, const bp_view* out,
+                   hipStream_t st, const IgemmStatsReq* sr);
+
 namespace {
 
 struct BPackArgs {
@@ -85,11 +94,12 @@ static int64_t generic_packed_elems(const ConvGeom& g, const BConfig& c) {
   return (int64_t)g.nphase * g.nphase * g.taps * c.nrun * c.nchunk * c.cout_padP * 32;
 }
 
-// [generic image | flattened-K image (conv_bf16_flat.hip) where that kernel applies]
+// [generic image | flattened-K image (conv_bf16_flat.hip) | weights-stationary image (conv_bf16_ws.hip)], the last
+// two where those kernels apply
 int64_t bp_bf16_packed_elems(const ConvGeom& g) {
   const BConfig c = b_config(g);
   if (!c.ok) return -1;
-  return generic_packed_elems(g, c) + bp_bf16_flat_packed_elems(g);
+  return generic_packed_elems(g, c) + bp_bf16_flat_packed_elems(g) + bp_bf16_ws_packed_elems(g);
 }
 
 int bp_bf16_pack(const ConvGeom& g, const WeightMap& wm, const float* w_torch, void* packed, hipStream_t st) {
@@ -104,7 +114,11 @@ int bp_bf16_pack(const ConvGeom& g, const WeightMap& wm, const float* w_torch, v
   a.total = generic_packed_elems(g, c);
   hipLaunchKernelGGL(pack_bf16_kernel, dim3((unsigned)((a.total + 255) / 256)), dim3(256), 0, st, a);
   BP_CHECK_LAUNCH();
-  if (bp_bf16_flat_packed_elems(g) > 0) return bp_bf16_flat_pack(g, wm, w_torch, a.dst + a.total, st);
+  if (bp_bf16_flat_packed_elems(g) > 0) {
+    const int rc = bp_bf16_flat_pack(g, wm, w_torch, a.dst + a.total, st);
+    if (rc != BP_OK) return rc;
+  }
+  if (bp_bf16_ws_packed_elems(g) > 0) return bp_bf16_ws_pack(g, wm, w_torch, a.dst + a.total + bp_bf16_flat_packed_elems(g), st);
   return BP_OK;
 }
 
@@ -123,7 +137,12 @@ size_t bp_bf16_stats_workspace(const ConvGeom& g, const bp_view* in, const bp_vi
   if (!c.ok || !bp_bf16_igemm_ok(g, in, out)) return 0;
   if (bp_bf16_flat_ok(g, in, out, nullptr, mode)) return bp_bf16_flat_stats_workspace(g, in, out, mode);
   if (mode != 1) return 0;                                    // (mode 2: the two flattened-K kernels only)
-  return bp_stats_rows_bytes(bf16_stat_rows(g, c, in, out), g.cout_g);
+  const size_t generic = bp_stats_rows_bytes(bf16_stat_rows(g, c, in, out), g.cout_g);
+  if (bp_bf16_ws_ok(g, in, out, nullptr, mode)) {        // (the larger of the two: bp_set_option may switch kernels later)
+    const size_t ws = bp_bf16_ws_stats_workspace(g, in, out);
+    return ws > generic ? ws : generic;
+  }
+  return generic;
 }
 
 int bp_bf16_igemm_run(const ConvGeom& g, const bp_view* in, const PW& pw, const void* packed, const float* bias,
@@ -132,6 +151,9 @@ int bp_bf16_igemm_run(const ConvGeom& g, const bp_view* in, const PW& pw, const 
   if (!c.ok || !bp_bf16_igemm_ok(g, in, out)) return BP_EUNSUPPORTED;
   if (bp_bf16_flat_ok(g, in, out, bias, sr ? sr->mode : 0))
     return bp_bf16_flat_run(g, in, pw, reinterpret_cast<const u16*>(packed) + generic_packed_elems(g, c), out, st, sr);
+  if (bp_bf16_ws_ok(g, in, out, bias, sr ? sr->mode : 0))
+    return bp_bf16_ws_run(g, in, pw, reinterpret_cast<const u16*>(packed) + generic_packed_elems(g, c) +
+                          bp_bf16_flat_packed_elems(g), out, st, sr);
   BArgs a{};
   a.in = in->ptr; a.in_h = in->h; a.in_w = in->w; a.in_cs = in->cstride; a.in_co = in->coff; a.cin = g.cin_g;
   a.out = out->ptr; a.out_h = out->h; a.out_w = out->w; a.out_cs = out->cstride; a.out_co = out->coff;

@@ -409,9 +409,10 @@ __global__ __launch_bounds__(64 * NW, 2) void igemm_bf16_kernel(BArgs a) {
       }
       float v[U], raw[U];
       unpack_unit<U, IN_BF16>(stage[i], raw);
-      if (relu) {        // batch-norm + ReLU (slopes 0, whole unit inside the tensor's channels): fma + max per element
+      if (relu) {        // batch-norm + ReLU (slopes 0, whole unit inside the tensor's channels): fma + compare + select per element,
+                         // NaN-propagating
 #pragma unroll
-        for (int j = 0; j < U; ++j) v[j] = s_g[i] >= 0 ? fmaxf(fmaf(raw[j], sc[j], sf[j]), 0.f) : 0.f;
+        for (int j = 0; j < U; ++j) v[j] = s_g[i] >= 0 ? bp_relu_nan(fmaf(raw[j], sc[j], sf[j])) : 0.f;
       } else {
 #pragma unroll
         for (int j = 0; j < U; ++j) {

@@ -1,0 +1,343 @@
+// Weights-stationary bf16 convolution of the generator's residual trunk: Conv2d k3 s1 p1, 128 -> 128 channels
+// (/root/reference/baryon_painter/models/utils.py:22-38 ResidualBlock, 8 layers = 47 % of the step's FLOPs), forward
+// and data gradient (the same correlation with the taps mirrored and the channel roles swapped: a different weight
+// image, the same kernel).
+//
+// Why a kernel of its own: the tiled igemm_bf16_kernel streams the layer's 295 KB of weights through LDS once per
+// 256-pixel tile -- five times the bytes of the tile's input -- and reads every MFMA operand out of LDS; it runs at
+// 0.29 of the bf16 matrix peak (profiles/r03_mfma_util_bf16.txt), bound by LDS fragment reads and slab barriers.
+// Here the weights never move after the prologue:
+//   * one workgroup of four waves (one per SIMD, up to 512 registers each) per CU; wave w owns produced channels
+//     [32 w, 32 w + 32) and keeps ITS weights for all 9 taps x 128 gathered channels in registers: 72 MFMA A-fragments
+//     = 288 VGPR/AGPRs per lane (a CU's register file is 512 KB; the layer's weights are 295 KB);
+//   * the workgroup walks a band of image rows top to bottom with a ring of four input rows in LDS (one new row per
+//     produced row: every input byte is fetched once per band, + 2 halo rows per band);
+//   * per K-step (tap, 32 channels) a wave reads one 16-byte B-fragment per 16 pixels and uses it for two MFMAs
+//     (v_mfma_f32_16x16x32_bf16, its two 16-channel blocks): 128 B/clk of LDS reads per CU = half the LDS peak, no
+//     weight reads at all, one barrier per ROW (9216 MFMAs per CU between barriers at W = 64);
+//   * LDS image: 16 planes (one per 8-channel octet) of [ring row][pixel + 2 zero columns] 16-byte slots, plane stride
+//     a multiple of 16 slots: the 16 lanes of every ds_read_b128 lane group hit 16 distinct bank quads whatever the
+//     tap offset; staging writes 8 consecutive pixels of one plane per 8 lanes (conflict-free ds_write_b128);
+//   * the producer's pending batch-norm + (leaky) ReLU is applied on the way into LDS, once per element (the 4 waves
+//     all read the same image), NaN-propagating like torch.relu;
+//   * epilogue per row from the accumulators: 16-byte bf16 stores (a lane holds 8 consecutive channels of a pixel: the
+//     A-fragment rows are ordered so), training-mode batch-norm sums {sum y, sum y^2} of the values AS STORED per lane
+//     in fp32 over the band (<= 256 terms), folded in double through LDS once per workgroup: one row per workgroup.
+#include "conv_bf16.hpp"
+
+size_t bp_stats_rows_bytes(int64_t rows, int C);
+int bp_stats_rows_finish(double* ws, int64_t rows, int C, const IgemmStatsReq* sr, hipStream_t st);
+
+namespace {
+using namespace bpbf16;
+
+constexpr int WS_C = 128;            // channels on both sides
+constexpr int WS_R = 4;              // ring rows
+constexpr int WS_FV = 32;            // ... of which in VGPRs (the rest in AGPRs)
+constexpr int WS_NF = 72;            // A-fragments per wave: 9 taps x 4 chunks of 32 channels x 2 blocks of 16 channels
+
+struct WsArgs {
+  const u16* in; int in_cs, in_co;
+  u16* out; int out_cs, out_co;
+  int n, h;
+  const u16* wp;                     // [wave 4][fragment 72][lane 64][8]
+  PW pw;
+  int BR, bands;
+  double* stat;                      // rows [workgroup][2][128]
+};
+
+template <int G> struct WsGeom {
+  static constexpr int W = 16 * G, RP = W + 2;
+  static constexpr int PS = (WS_R * RP + 15) / 16 * 16;         // 16-byte slots per plane
+  static constexpr size_t img_bytes = (size_t)16 * PS * 16;
+  static constexpr size_t lds_bytes = img_bytes + 3 * WS_C * sizeof(float);
+};
+
+// weight image: fragment f = ((ty*3 + tx)*4 + chunk)*2 + block of wave w; lane (lm, kq) holds A[row lm][k = 8 kq + j]:
+// produced channel 32 w + 8 (lm >> 2) + 4 block + (lm & 3), gathered channel 32 chunk + 8 kq + j
+struct WsPackArgs {
+  const float* w; u16* dst;
+  int64_t sa, sb;
+  int transposed;
+};
+__global__ __launch_bounds__(256) void ws_pack_kernel(WsPackArgs a) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= 4 * WS_NF * 64 * 8) return;
+  const int j = i & 7, lane = (i >> 3) & 63, f = (i >> 9) % WS_NF, w = i / (512 * WS_NF);
+  const int lm = lane & 15, kq = lane >> 4;
+  const int blk = f & 1, chunk = (f >> 1) & 3, tap = f >> 3;
+  const int ty = tap / 3, tx = tap % 3;
+  const int co = 32 * w + 8 * (lm >> 2) + 4 * blk + (lm & 3);
+  const int ci = 32 * chunk + 8 * kq + j;
+  // the gather-transposed form (data gradient of a Conv2d) visits the taps mirrored: bp_t_ky(0, 1, 1, 3, t) = 2 - t
+  const int ky = a.transposed ? 2 - ty : ty, kx = a.transposed ? 2 - tx : tx;
+  a.dst[i] = f2bf(a.w[ci * a.sa + co * a.sb + ky * 3 + kx]);
+}
+
+template <int G, bool ACT, bool STATS>
+__global__ __launch_bounds__(256) void ws3_bf16_kernel(WsArgs a) {
+  using GM = WsGeom<G>;
+  constexpr int W = GM::W, RP = GM::RP, PS = GM::PS;
+  extern __shared__ __attribute__((aligned(16))) u16 smem[];
+  uint4* img = reinterpret_cast<uint4*>(smem);
+  float* lpw = reinterpret_cast<float*>(smem + GM::img_bytes / 2);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lm = lane & 15, kq = lane >> 4;
+  const int n = blockIdx.x / a.bands, band = blockIdx.x % a.bands;
+  const int y0 = band * a.BR;
+  const int y1 = min(y0 + a.BR, a.h);
+
+  // staging units of this thread: unit i = 8 pixels x 8 octets per wave instruction
+  //   octet = (lane >> 3) + 8 * (ub & 1), pixel = (lane & 7) + 8 * (ub >> 1), ub = wave + 4 i
+  int s_px[G], s_oc[G];
+#pragma unroll
+  for (int i = 0; i < G; ++i) {
+    const int ub = wave + 4 * i;
+    s_oc[i] = (lane >> 3) + 8 * (ub & 1);
+    s_px[i] = (lane & 7) + 8 * (ub >> 1);
+  }
+  const u16* in_img = a.in + (int64_t)n * a.h * W * a.in_cs + a.in_co;
+  auto load_row = [&](int r, uint4 (&raw)[G]) {        // (r inside the image: uniform)
+#pragma unroll
+    for (int i = 0; i < G; ++i)
+      raw[i] = *reinterpret_cast<const uint4*>(in_img + ((int64_t)r * W + s_px[i]) * a.in_cs + s_oc[i] * 8);
+  };
+  auto commit_row = [&](int r, bool inside, const uint4 (&raw)[G]) {
+    const int rr = (r + 1) & (WS_R - 1);
+#pragma unroll
+    for (int i = 0; i < G; ++i) {
+      uint4 v = make_uint4(0u, 0u, 0u, 0u);
+      if (inside) {
+        v = raw[i];
+        if constexpr (ACT) {
+          const float4 sc0 = *reinterpret_cast<const float4*>(lpw + s_oc[i] * 8), sc1 = *reinterpret_cast<const float4*>(lpw + s_oc[i] * 8 + 4);
+          const float4 sf0 = *reinterpret_cast<const float4*>(lpw + WS_C + s_oc[i] * 8), sf1 = *reinterpret_cast<const float4*>(lpw + WS_C + s_oc[i] * 8 + 4);
+          const float4 sl0 = *reinterpret_cast<const float4*>(lpw + 2 * WS_C + s_oc[i] * 8), sl1 = *reinterpret_cast<const float4*>(lpw + 2 * WS_C + s_oc[i] * 8 + 4);
+          const float sc[8] = {sc0.x, sc0.y, sc0.z, sc0.w, sc1.x, sc1.y, sc1.z, sc1.w};
+          const float sf[8] = {sf0.x, sf0.y, sf0.z, sf0.w, sf1.x, sf1.y, sf1.z, sf1.w};
+          const float sl[8] = {sl0.x, sl0.y, sl0.z, sl0.w, sl1.x, sl1.y, sl1.z, sl1.w};
+          const unsigned wd[4] = {v.x, v.y, v.z, v.w};
+          float t[8];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            t[2 * j] = fmaf(bf2f((u16)(wd[j] & 0xffffu)), sc[2 * j], sf[2 * j]);
+            t[2 * j + 1] = fmaf(bf2f((u16)(wd[j] >> 16)), sc[2 * j + 1], sf[2 * j + 1]);
+          }
+#pragma unroll
+          for (int j = 0; j < 8; ++j) t[j] = t[j] > 0.f ? t[j] : t[j] * sl[j];      // (a NaN stays a NaN, as torch.relu)
+          v = make_uint4(pack2(t[0], t[1]), pack2(t[2], t[3]), pack2(t[4], t[5]), pack2(t[6], t[7]));
+        }
+      }
+      img[s_oc[i] * PS + rr * RP + 1 + s_px[i]] = v;
+    }
+  };
+
+  // ---- prologue: first three input rows requested, then the weights; zero columns; activation parameters
+  uint4 raw0[G], raw1[G], raw2[G];
+  const bool in0 = y0 - 1 >= 0, in2 = y0 + 1 < a.h;
+  if (in0) load_row(y0 - 1, raw0);
+  load_row(y0, raw1);
+  if (in2) load_row(y0 + 1, raw2);
+  bf8 wf[WS_NF];
+  {
+    const uint4* wsrc = reinterpret_cast<const uint4*>(a.wp) + (size_t)wave * WS_NF * 64 + lane;
+#pragma unroll
+    for (int f = 0; f < WS_NF; ++f) wf[f] = __builtin_bit_cast(bf8, wsrc[f * 64]);
+    // Register classes by hand: the first WS_FV fragments live in VGPRs, the others in AGPRs (an MFMA takes either as its
+    // A operand).  Left to itself the allocator fills the 256 VGPRs, spills the rest to AGPRs and copies them back in
+    // front of every use (181 v_accvgpr moves per 288 MFMAs, clustered at the head of each K-step).
+#pragma unroll
+    for (int f = 0; f < WS_NF; ++f) {
+      if (f < WS_FV) asm volatile("" : "+v"(wf[f]));
+      else asm volatile("" : "+a"(wf[f]));
+    }
+  }
+  if (tid < 128) {
+    const int plane = tid >> 3, rr = (tid >> 1) & 3, side = tid & 1;
+    img[plane * PS + rr * RP + (side ? RP - 1 : 0)] = make_uint4(0u, 0u, 0u, 0u);
+  }
+  if constexpr (ACT) {
+    for (int i = tid; i < WS_C; i += 256) { lpw[i] = a.pw.scale[i]; lpw[WS_C + i] = a.pw.shift[i]; lpw[2 * WS_C + i] = a.pw.slope[i]; }
+    __syncthreads();
+  }
+  commit_row(y0 - 1, in0, raw0);
+  commit_row(y0, true, raw1);
+  commit_row(y0 + 1, in2, raw2);
+  __syncthreads();
+
+  float s1[8], s2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+  const int lbase = kq * PS + lm;                       // slot of (plane kq, pixel lm) in ring row 0
+  u16* out_img = a.out + (int64_t)n * a.h * W * a.out_cs + a.out_co + 32 * wave + 8 * kq;
+
+  for (int y = y0; y < y1; ++y) {
+    const bool more = y + 1 < y1;                       // another produced row: input row y + 2 is wanted
+    const bool in_next = y + 2 < a.h;
+    if (more && in_next) load_row(y + 2, raw0);
+
+    int rbase[3];
+#pragma unroll
+    for (int ty = 0; ty < 3; ++ty) rbase[ty] = lbase + ((y + ty) & (WS_R - 1)) * RP;      // input row y - 1 + ty
+    v4f acc[G][2];
+#pragma unroll
+    for (int g = 0; g < G; ++g) { acc[g][0] = v4f{0.f, 0.f, 0.f, 0.f}; acc[g][1] = v4f{0.f, 0.f, 0.f, 0.f}; }
+    // 36 K-steps (tap row, channel chunk, tap column); the fragments of step s + 1 are requested before the MFMAs of
+    // step s (left alone the compiler reads each fragment right in front of its two MFMAs: an LDS round trip per pair)
+    bf8 xf[2][G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) xf[0][g] = __builtin_bit_cast(bf8, img[rbase[0] + 16 * g]);
+#pragma unroll
+    for (int s = 0; s < 36; ++s) {
+      const int ty = s / 12, c = (s / 3) & 3, tx = s % 3;
+      if (s + 1 < 36) {
+        const int ty1 = (s + 1) / 12, c1 = ((s + 1) / 3) & 3, tx1 = (s + 1) % 3;
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+          xf[(s + 1) & 1][g] = __builtin_bit_cast(bf8, img[rbase[ty1] + 4 * c1 * PS + 16 * g + tx1]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      const int f = ((ty * 3 + tx) * 4 + c) * 2;
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        acc[g][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[f], xf[s & 1][g], acc[g][0], 0, 0, 0);
+        acc[g][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[f + 1], xf[s & 1][g], acc[g][1], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // ---- epilogue of row y: lane (lm, kq) holds channels 32 wave + 8 kq + [0, 8) of pixel 16 g + lm
+    u16* orow = out_img + (int64_t)y * W * a.out_cs;
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      const uint4 v = make_uint4(pack2(acc[g][0][0], acc[g][0][1]), pack2(acc[g][0][2], acc[g][0][3]),
+                                 pack2(acc[g][1][0], acc[g][1][1]), pack2(acc[g][1][2], acc[g][1][3]));
+      *reinterpret_cast<uint4*>(orow + (int64_t)(16 * g + lm) * a.out_cs) = v;
+      if constexpr (STATS) {
+        const unsigned wd[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float lo = bf2f((u16)(wd[j] & 0xffffu)), hi = bf2f((u16)(wd[j] >> 16));
+          s1[2 * j] += lo; s2[2 * j] = fmaf(lo, lo, s2[2 * j]);
+          s1[2 * j + 1] += hi; s2[2 * j + 1] = fmaf(hi, hi, s2[2 * j + 1]);
+        }
+      }
+    }
+    if (more) commit_row(y + 2, in_next, raw0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  }
+
+  if constexpr (STATS) {
+    // per-lane fp32 partials -> LDS [stat][channel][lm] -> one double row per workgroup (fixed order)
+    float* red = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int ch = 32 * wave + 8 * kq + j;
+      red[ch * 16 + lm] = s1[j];
+      red[(WS_C + ch) * 16 + lm] = s2[j];
+    }
+    __syncthreads();
+    double t = 0.0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) t += (double)red[tid * 16 + i];
+    a.stat[(int64_t)blockIdx.x * 2 * WS_C + tid] = t;
+  }
+}
+
+bool ws_enabled() {
+  static const bool off = getenv("BP_BF16_WS") && atoi(getenv("BP_BF16_WS")) == 0;
+  return !off;
+}
+int g_ws_override = -1;       // bp_set_option("bf16_ws", v)
+
+int ws_G(const bp_view* v) { return v->w == 64 ? 4 : v->w == 32 ? 2 : v->w == 16 ? 1 : 0; }
+
+// rows per band: whole image per workgroup when there are many images, else bands of >= 4 rows so that ~256 workgroups exist
+void ws_bands(const bp_view* in, int* BR, int* bands) {
+  int br = in->h;
+  while (br > 4 && (int64_t)in->n * bp_ceil_div(in->h, br) < 256) br = bp_ceil_div(br, 2);
+  *BR = br;
+  *bands = bp_ceil_div(in->h, br);
+}
+
+template <int G, bool ACT, bool STATS>
+int ws_launch(const WsArgs& a, unsigned grid, hipStream_t st) {
+  static const hipError_t optin = hipFuncSetAttribute(reinterpret_cast<const void*>(&ws3_bf16_kernel<G, ACT, STATS>),
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)WsGeom<G>::lds_bytes);
+  if (optin != hipSuccess) return BP_ELAUNCH;
+  hipLaunchKernelGGL((ws3_bf16_kernel<G, ACT, STATS>), dim3(grid), dim3(256), WsGeom<G>::lds_bytes, st, a);
+  BP_CHECK_LAUNCH();
+  return BP_OK;
+}
+template <int G>
+int ws_launch_g(const WsArgs& a, bool act, bool stats, unsigned grid, hipStream_t st) {
+  if (act) return stats ? ws_launch<G, true, true>(a, grid, st) : ws_launch<G, true, false>(a, grid, st);
+  return stats ? ws_launch<G, false, true>(a, grid, st) : ws_launch<G, false, false>(a, grid, st);
+}
+
+}  // namespace
+
+void bp_bf16_ws_set(int v) { g_ws_override = v; }
+
+bool bp_bf16_ws_geom_ok(const ConvGeom& g) {
+  return g.k == 3 && g.stride == 1 && g.pad == 1 && g.cin_g == WS_C && g.cout_g == WS_C && g.nphase == 1 && g.taps == 3 &&
+         g.IS == 1 && g.OS == 1;
+}
+
+int64_t bp_bf16_ws_packed_elems(const ConvGeom& g) { return bp_bf16_ws_geom_ok(g) ? (int64_t)4 * WS_NF * 64 * 8 : 0; }
+
+int bp_bf16_ws_pack(const ConvGeom& g, const WeightMap& wm, const float* w_torch, u16* dst, hipStream_t st) {
+  if (!bp_bf16_ws_geom_ok(g)) return BP_EUNSUPPORTED;
+  const WsPackArgs a{w_torch, dst, wm.sa, wm.sb, g.gather_transposed};
+  hipLaunchKernelGGL(ws_pack_kernel, dim3(4 * WS_NF * 64 * 8 / 256), dim3(256), 0, st, a);
+  BP_CHECK_LAUNCH();
+  return BP_OK;
+}
+
+// mode: 0 none, 1 batch-norm sums of the produced tensor
+bool bp_bf16_ws_ok(const ConvGeom& g, const bp_view* in, const bp_view* out, const float* bias, int mode) {
+  if (!(g_ws_override < 0 ? ws_enabled() : g_ws_override != 0)) return false;
+  if (!bp_bf16_ws_geom_ok(g) || !in || !out || bias || (mode != 0 && mode != 1)) return false;
+  if (in->dtype != BP_BF16 || out->dtype != BP_BF16 || in->c != WS_C || out->c != WS_C) return false;
+  if (in->w != out->w || in->h != out->h || in->n != out->n || !ws_G(in)) return false;
+  if (in->cstride % 8 || in->coff % 8 || reinterpret_cast<uintptr_t>(in->ptr) % 16) return false;
+  if (out->cstride % 8 || out->coff % 8 || reinterpret_cast<uintptr_t>(out->ptr) % 16) return false;
+  int BR, bands;
+  ws_bands(in, &BR, &bands);
+  if (mode == 1 && BR * ws_G(in) > 256) return false;          // a lane's fp32 partial sums: <= 256 terms
+  return (int64_t)in->n * bands <= 0x7fffffff;
+}
+
+size_t bp_bf16_ws_stats_workspace(const ConvGeom& g, const bp_view* in, const bp_view* out) {
+  int BR, bands;
+  ws_bands(in, &BR, &bands);
+  return bp_stats_rows_bytes((int64_t)in->n * bands, g.cout_g);
+}
+
+int bp_bf16_ws_run(const ConvGeom& g, const bp_view* in, const PW& pw, const u16* packed_ws, const bp_view* out,
+                   hipStream_t st, const IgemmStatsReq* sr) {
+  WsArgs a{};
+  a.in = reinterpret_cast<const u16*>(in->ptr); a.in_cs = in->cstride; a.in_co = in->coff;
+  a.out = reinterpret_cast<u16*>(out->ptr); a.out_cs = out->cstride; a.out_co = out->coff;
+  a.n = in->n; a.h = in->h; a.wp = packed_ws; a.pw = pw;
+  ws_bands(in, &a.BR, &a.bands);
+  const int64_t rows = (int64_t)in->n * a.bands;
+  if (sr) {
+    const size_t need = bp_stats_rows_bytes(rows, g.cout_g);
+    if (sr->mode != 1 || !need) return BP_EUNSUPPORTED;
+    if (!sr->ws || sr->ws_bytes < need || !sr->sums) return BP_EWORKSPACE;
+    a.stat = reinterpret_cast<double*>(sr->ws);
+  }
+  const bool act = pw.scale != nullptr;
+  int rc;
+  switch (ws_G(in)) {
+    case 4: rc = ws_launch_g<4>(a, act, sr != nullptr, (unsigned)rows, st); break;
+    case 2: rc = ws_launch_g<2>(a, act, sr != nullptr, (unsigned)rows, st); break;
+    default: rc = ws_launch_g<1>(a, act, sr != nullptr, (unsigned)rows, st); break;
+  }
+  if (rc != BP_OK || !sr) return rc;
+  return bp_stats_rows_finish(a.stat, rows, g.cout_g, sr, st);
+}

@@ -275,7 +275,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(WbArgs a) {
           const bool relu = l[0] == 0.f && l[1] == 0.f && l[2] == 0.f && l[3] == 0.f;
           if (relu) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[4 * h + j] = ((xin >> i) & 1u) ? fmaxf(fmaf(raw[4 * h + j], c[j], f[j]), 0.f) : 0.f;
+            for (int j = 0; j < 4; ++j) v[4 * h + j] = ((xin >> i) & 1u) ? bp_relu_nan(fmaf(raw[4 * h + j], c[j], f[j])) : 0.f;
           } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {

@@ -78,6 +78,12 @@ enum { BP_PACK_FWD = 0, BP_PACK_BWD = 1 };
 
 /* ---- library ------------------------------------------------------------------------------ */
 int bp_version(void);
+/* Kernel-selection switches for A/B measurements and tests inside ONE process (the environment variables of the same
+ * names are read once, at the first call).  "bf16_ws": 1 / 0 = use / do not use the weights-stationary kernel for the
+ * 128 -> 128 k3 bf16 trunk layers (csrc/conv_bf16_ws.hip), -1 = back to the environment's choice (BP_BF16_WS).
+ * Not thread-safe against concurrent launches; results of either kernel meet the same tolerances.
+ * Returns BP_EUNSUPPORTED for an unknown name. */
+int bp_set_option(const char* name, int value);
 const char* bp_strerror(int code);
 
 /* ---- convolution (replaces nn.Conv2d / nn.ConvTranspose2d forward + their autograd backward,

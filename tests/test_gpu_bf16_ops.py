@@ -51,6 +51,9 @@ CASES = [
     (0, 32, 64, 4, 2, 1, (2, 14, 22), None),
     (0, 64, 128, 4, 2, 1, (2, 10, 38), None),
     (0, 128, 128, 3, 1, 1, (2, 13, 35), None),      # residual trunk
+    (0, 128, 128, 3, 1, 1, (2, 9, 16), None),       # ... at widths the weights-stationary kernel takes (conv_bf16_ws.hip:
+    (0, 128, 128, 3, 1, 1, (3, 7, 32), None),       #     bf16 on both sides; the other element types stay on the tiled one)
+    (0, 128, 128, 3, 1, 1, (2, 21, 64), None),
     (1, 128, 64, 4, 2, 1, (2, 7, 18), None),        # decoder
     (1, 64, 32, 4, 2, 1, (3, 5, 9), None),
     (1, 32, 16, 4, 2, 1, (2, 9, 21), None),
@@ -221,3 +224,121 @@ def test_fp32_entry_points_refuse_bf16_views():
     pf = torch.zeros(lib.bp_conv_packed_floats(C.byref(cv), L.PACK_FWD), device="cuda")
     assert lib.bp_conv_forward(C.byref(cv), C.byref(v), None, L.ptr(pf), None, None, C.byref(ov), L.IMPL_MFMA,
                                G.stream()) == -1            # BP_EINVAL: the fp32 kernels take fp32 views only
+
+
+# ---- the weights-stationary kernel of the 128 -> 128 k3 trunk (csrc/conv_bf16_ws.hip) against the tiled kernel it replaces
+@pytest.mark.parametrize("act", ["none", "relu", "leaky"])
+@pytest.mark.parametrize("shape", [(2, 9, 16), (3, 20, 32), (2, 64, 64), (5, 16, 64), (70, 8, 16)],
+                         ids=lambda s: "%dx%dx%d" % s)
+def test_weights_stationary_trunk_kernel(shape, act):
+    """Forward (with and without the batch-norm sums) and data gradient: each kernel within 2^-8 of the float64
+    convolution of the same bf16 operands, the two kernels' sums equal to 1e-6 of the sum of magnitudes; views that are
+    channel slices of wider buffers; bands that end inside the image (n * h chosen so that several band sizes occur)."""
+    lib = L.load()
+    n, h, w = shape
+    ci = co = 128
+    rng = np.random.default_rng(n * 1000 + h * 10 + w)
+    x = bf16_round(rng.standard_normal((n, ci, h, w)).astype(np.float32))
+    wt = (rng.standard_normal((co, ci, 3, 3)) * 0.05).astype(np.float32)
+    scale = rng.uniform(0.5, 1.5, ci).astype(np.float32)
+    shift = rng.uniform(0.2, 0.6, ci).astype(np.float32)
+    slope = rng.uniform(0.0, 0.3, ci).astype(np.float32)
+    if act == "relu":
+        slope[:] = 0.0
+    if act == "none":
+        xa = x.astype(np.float64)
+    else:
+        t = (x.astype(np.float64) * scale[None, :, None, None].astype(np.float64)
+             + shift[None, :, None, None].astype(np.float64)).astype(np.float32)
+        xa = bf16_round(np.where(t > 0, t, t * slope[None, :, None, None]).astype(np.float32)).astype(np.float64)
+    w64 = bf16_round(wt).astype(np.float64)
+    y_ref = ops.conv2d_fwd(xa, w64, 1, 1)
+    cv = L.Conv(0, ci, co, 3, 1, 1, 0)
+    st = G.stream()
+    xb, xv = to_view(x, True, cstride=ci + 16, coff=8)
+    keep, pw = G.pointwise(scale, shift, slope)
+    pwp = None if act == "none" else C.byref(pw)
+    wd = G.dev(wt)
+    pf = torch.zeros(lib.bp_conv_bf16_packed_elems(C.byref(cv), L.PACK_FWD), device="cuda", dtype=torch.bfloat16)
+    pb = torch.zeros(lib.bp_conv_bf16_packed_elems(C.byref(cv), L.PACK_BWD), device="cuda", dtype=torch.bfloat16)
+    L.check(lib.bp_conv_bf16_pack(C.byref(cv), L.PACK_FWD, L.ptr(wd), L.ptr(pf), st))
+    L.check(lib.bp_conv_bf16_pack(C.byref(cv), L.PACK_BWD, L.ptr(wd), L.ptr(pb), st))
+    dy = bf16_round(rng.standard_normal(y_ref.shape).astype(np.float32))
+    dyb, dyv = to_view(dy, True)
+    dx_ref = ops.conv2d_bwd_data(dy.astype(np.float64), w64, 1, 1, h, w)
+    res = {}
+    try:
+        for ws_on in (1, 0):
+            assert lib.bp_set_option(b"bf16_ws", ws_on) == 0
+            yb, yv = empty_view(n, h, w, co, True, cstride=co + 8, coff=8)
+            L.check(lib.bp_conv_forward(C.byref(cv), C.byref(xv), pwp, L.ptr(pf), L.ptr(wd), None, C.byref(yv),
+                                        L.IMPL_BF16, st), "forward")
+            got = from_view(yb, co, coff=8)
+            assert G.rel_err(got, y_ref) < 4e-3, f"forward ws={ws_on}"
+            assert torch.isnan(yb.to(torch.float32)[..., :8]).all(), "stores outside the view"
+            nb = lib.bp_conv_stats_workspace(C.byref(cv), L.PACK_FWD, C.byref(xv), C.byref(yv), L.IMPL_BF16)
+            assert nb > 0
+            yb2, yv2 = empty_view(n, h, w, co, True, cstride=co + 8, coff=8)
+            sums = torch.full((2 * co,), float("nan"), dtype=torch.float64, device="cuda")
+            wss = torch.full((nb // 8 + 8,), float("nan"), dtype=torch.float64, device="cuda")
+            L.check(lib.bp_conv_forward_stats(C.byref(cv), C.byref(xv), pwp, L.ptr(pf), C.byref(yv2), L.ptr(sums),
+                                              L.ptr(wss), nb, L.IMPL_BF16, st), "forward + statistics")
+            assert np.array_equal(from_view(yb2, co, coff=8), got), "the statistics epilogue must not change the output"
+            g64 = got.astype(np.float64)
+            sm = sums.cpu().numpy()
+            assert (np.abs(sm[:co] - g64.sum(axis=(0, 2, 3))) <= 1e-6 * np.abs(g64).sum(axis=(0, 2, 3)) + 1e-12).all()
+            assert np.allclose(sm[co:], (g64 ** 2).sum(axis=(0, 2, 3)), rtol=1e-6, atol=1e-12)
+            dxb, dxv = empty_view(n, h, w, ci, True, cstride=ci + 8, coff=0)
+            L.check(lib.bp_conv_backward_data(C.byref(cv), C.byref(dyv), L.ptr(pb), L.ptr(wd), C.byref(dxv), L.IMPL_BF16, st),
+                    "backward_data")
+            dx = from_view(dxb, ci)
+            assert G.rel_err(dx, dx_ref) < 4e-3, f"backward_data ws={ws_on}"
+            assert torch.isnan(dxb.to(torch.float32)[..., ci:]).all(), "stores outside the view"
+            res[ws_on] = (got, dx)
+    finally:
+        lib.bp_set_option(b"bf16_ws", -1)
+    # the two kernels differ by accumulation order only: a bf16 ulp (2^-8 of the value, at most 2^-7 of the maximum) here and there
+    assert G.rel_err(res[1][0], res[0][0]) < 8e-3 and G.rel_err(res[1][1], res[0][1]) < 8e-3
+    assert np.mean(res[1][0] != res[0][0]) < 0.05
+
+
+@pytest.mark.parametrize("ws_on", [1, 0], ids=["stationary", "tiled"])
+def test_bf16_relu_staging_propagates_nan(ws_on):
+    """torch.relu(NaN) is NaN (the reference's ReLU, utils.py:140): a NaN activation must reach every output its
+    3 x 3 footprint covers, through the batch-norm + ReLU staging of the forward kernels and of the weight gradient --
+    fmaxf(NaN, 0) would turn it into 0 and a diverged run would keep painting finite tiles."""
+    lib = L.load()
+    n, h, w, ci, co = 2, 8, 16, 128, 128
+    rng = np.random.default_rng(5)
+    x = bf16_round(rng.standard_normal((n, ci, h, w)).astype(np.float32))
+    x[1, 37, 4, 9] = np.nan
+    wt = (rng.standard_normal((co, ci, 3, 3)) * 0.05).astype(np.float32)
+    scale = rng.uniform(0.5, 1.5, ci).astype(np.float32)
+    shift = rng.uniform(0.2, 0.6, ci).astype(np.float32)
+    slope = np.zeros(ci, np.float32)
+    cv = L.Conv(0, ci, co, 3, 1, 1, 0)
+    st = G.stream()
+    xb, xv = to_view(x, True)
+    keep, pw = G.pointwise(scale, shift, slope)
+    wd = G.dev(wt)
+    pf = torch.zeros(lib.bp_conv_bf16_packed_elems(C.byref(cv), L.PACK_FWD), device="cuda", dtype=torch.bfloat16)
+    L.check(lib.bp_conv_bf16_pack(C.byref(cv), L.PACK_FWD, L.ptr(wd), L.ptr(pf), st))
+    try:
+        assert lib.bp_set_option(b"bf16_ws", ws_on) == 0
+        yb, yv = empty_view(n, h, w, co, True)
+        L.check(lib.bp_conv_forward(C.byref(cv), C.byref(xv), C.byref(pw), L.ptr(pf), L.ptr(wd), None, C.byref(yv),
+                                    L.IMPL_BF16, st), "forward")
+    finally:
+        lib.bp_set_option(b"bf16_ws", -1)
+    y = from_view(yb, co)
+    bad = np.isnan(y)
+    assert bad[1, :, 3:6, 8:11].all() and bad.sum() == co * 9
+    dy = bf16_round(rng.standard_normal(y.shape).astype(np.float32))
+    dyb, dyv = to_view(dy, True)
+    ws_bytes = lib.bp_conv_backward_weight_workspace(C.byref(cv), C.byref(xv), C.byref(dyv))
+    ws = torch.zeros(ws_bytes // 8 + 8, dtype=torch.float64, device="cuda")
+    dw = torch.zeros(wt.shape, device="cuda")
+    L.check(lib.bp_conv_backward_weight(C.byref(cv), C.byref(xv), C.byref(pw), C.byref(dyv), L.ptr(dw), None,
+                                        L.ptr(ws), ws.numel() * 8, L.IMPL_BF16, st), "backward_weight")
+    dwn = torch.isnan(dw).cpu().numpy()
+    assert dwn[:, 37].all() and not np.delete(dwn, 37, axis=1).any()

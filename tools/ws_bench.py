@@ -1,0 +1,61 @@
+"""A/B of the weights-stationary trunk kernel (csrc/conv_bf16_ws.hip) against the tiled igemm_bf16_kernel, in ONE process,
+interleaved rounds, random data (cdna_hip_programming.md rule 24 / 25).  usage: ws_bench.py [n h w [rounds]]"""
+import ctypes as C, os, sys
+import numpy as np
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from baryon_painter_amd import _lib as L
+
+n, h, w = (int(v) for v in sys.argv[1:4]) if len(sys.argv) > 3 else (64, 64, 64)
+rounds = int(sys.argv[4]) if len(sys.argv) > 4 else 15
+lib = L.load()
+ci = co = 128
+cv = L.Conv(0, ci, co, 3, 1, 1, 0)
+x = torch.randn((n, h, w, ci), device="cuda").to(torch.bfloat16)
+y = torch.empty((n, h, w, co), device="cuda", dtype=torch.bfloat16)
+dy = torch.randn((n, h, w, co), device="cuda").to(torch.bfloat16)
+dx = torch.empty_like(x)
+wt = torch.randn((co, ci, 3, 3), device="cuda") * 0.05
+xv = L.View(x.data_ptr(), n, h, w, ci, ci, 0, L.BF16)
+yv = L.View(y.data_ptr(), n, h, w, co, co, 0, L.BF16)
+dyv = L.View(dy.data_ptr(), n, h, w, co, co, 0, L.BF16)
+dxv = L.View(dx.data_ptr(), n, h, w, ci, ci, 0, L.BF16)
+pwk = [torch.rand(ci, device="cuda") + 0.5, torch.rand(ci, device="cuda") - 0.5, torch.zeros(ci, device="cuda")]
+pw = L.Pointwise(*[t.data_ptr() for t in pwk])
+st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+pf = torch.zeros(lib.bp_conv_bf16_packed_elems(C.byref(cv), 0), device="cuda", dtype=torch.bfloat16)
+pb = torch.zeros(lib.bp_conv_bf16_packed_elems(C.byref(cv), 1), device="cuda", dtype=torch.bfloat16)
+L.check(lib.bp_conv_bf16_pack(C.byref(cv), 0, L.ptr(wt), L.ptr(pf), st))
+L.check(lib.bp_conv_bf16_pack(C.byref(cv), 1, L.ptr(wt), L.ptr(pb), st))
+nb = max(lib.bp_conv_stats_workspace(C.byref(cv), 0, C.byref(xv), C.byref(yv), L.IMPL_BF16), 8)
+sums = torch.zeros(2 * co, dtype=torch.float64, device="cuda")
+wss = torch.zeros(nb // 8 + 8, dtype=torch.float64, device="cuda")
+flop = 2.0 * n * h * w * 9 * ci * co
+
+legs = {
+    "fwd": lambda: lib.bp_conv_forward(C.byref(cv), C.byref(xv), None, L.ptr(pf), L.ptr(wt), None, C.byref(yv), L.IMPL_BF16, st),
+    "fwd+act": lambda: lib.bp_conv_forward(C.byref(cv), C.byref(xv), C.byref(pw), L.ptr(pf), L.ptr(wt), None, C.byref(yv), L.IMPL_BF16, st),
+    "fwd+act+stats": lambda: lib.bp_conv_forward_stats(C.byref(cv), C.byref(xv), C.byref(pw), L.ptr(pf), C.byref(yv), L.ptr(sums), L.ptr(wss), nb, L.IMPL_BF16, st),
+    "dgrad": lambda: lib.bp_conv_backward_data(C.byref(cv), C.byref(dyv), L.ptr(pb), L.ptr(wt), C.byref(dxv), L.IMPL_BF16, st),
+}
+times = {(k, o): [] for k in legs for o in (1, 0)}
+REP = 10
+for r in range(rounds + 2):
+    for o in (1, 0):
+        lib.bp_set_option(b"bf16_ws", o)
+        for k, fn in legs.items():
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(REP):
+                L.check(fn())
+            e1.record()
+            torch.cuda.synchronize()
+            if r >= 2:
+                times[(k, o)].append(e0.elapsed_time(e1) * 1e3 / REP)
+lib.bp_set_option(b"bf16_ws", -1)
+print(f"128->128 k3 bf16, batch {n} of {h}x{w}: us per launch incl. its reductions (median / min over {rounds} rounds of {REP})")
+for k in legs:
+    a, b = np.array(times[(k, 1)]), np.array(times[(k, 0)])
+    print(f"  {k:14s} stationary {np.median(a):7.1f} / {a.min():7.1f} us = {flop/np.median(a)/1e6:7.1f} TF/s ({flop/np.median(a)/1e6/2500:.3f} of 2.5 PF)"
+          f"   tiled {np.median(b):7.1f} / {b.min():7.1f} us = {flop/np.median(b)/1e6:7.1f} TF/s", flush=True)
