@@ -37,7 +37,14 @@ typedef unsigned short u16;
 
 __device__ __forceinline__ float bf2f(u16 v) { return __builtin_bit_cast(float, (unsigned)v << 16); }
 __device__ __forceinline__ u16 f2bf(float f) { return __builtin_bit_cast(u16, (__bf16)f); }   // RNE, NaN stays NaN
-__device__ __forceinline__ unsigned pack2(float a, float b) { return (unsigned)f2bf(a) | ((unsigned)f2bf(b) << 16); }
+// two floats -> two bf16 in one word (a in the low half): ONE v_cvt_pk_bf16_f32 (RNE, a NaN stays a NaN).  Written as
+// two scalar casts + shift + or, the compiler pairs the casts of DIFFERENT words and shuffles halves afterwards.
+typedef float pk_f2 __attribute__((ext_vector_type(2)));
+typedef __bf16 pk_b2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack2(float a, float b) {
+  const pk_f2 v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, pk_b2));
+}
 
 // ---------------------------------------------------------------------------------------------- forward / dgrad
 struct BArgs {

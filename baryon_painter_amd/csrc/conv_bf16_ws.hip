@@ -24,6 +24,7 @@
 //     A-fragment rows are ordered so), training-mode batch-norm sums {sum y, sum y^2} of the values AS STORED per lane
 //     in fp32 over the band (<= 256 terms), folded in double through LDS once per workgroup: one row per workgroup.
 #include "conv_bf16.hpp"
+#include <type_traits>
 
 size_t bp_stats_rows_bytes(int64_t rows, int C);
 int bp_stats_rows_finish(double* ws, int64_t rows, int C, const IgemmStatsReq* sr, hipStream_t st);
@@ -33,7 +34,7 @@ using namespace bpbf16;
 
 constexpr int WS_C = 128;            // channels on both sides
 constexpr int WS_R = 4;              // ring rows
-constexpr int WS_FV = 32;            // ... of which in VGPRs (the rest in AGPRs)
+constexpr int WS_FV = 32; // ... of which in VGPRs (the rest in AGPRs)
 constexpr int WS_NF = 72;            // A-fragments per wave: 9 taps x 4 chunks of 32 channels x 2 blocks of 16 channels
 
 struct WsArgs {
@@ -74,6 +75,10 @@ __global__ __launch_bounds__(256) void ws_pack_kernel(WsPackArgs a) {
   a.dst[i] = f2bf(a.w[ci * a.sa + co * a.sb + ky * 3 + kx]);
 }
 
+// scheduling masks of __builtin_amdgcn_sched_group_barrier
+#define WS_SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
+constexpr int SG_VALU = 0x2, SG_MFMA = 0x8, SG_DSR = 0x100;
+
 template <int G, bool ACT, bool STATS>
 __global__ __launch_bounds__(256) void ws3_bf16_kernel(WsArgs a) {
   using GM = WsGeom<G>;
@@ -91,55 +96,64 @@ __global__ __launch_bounds__(256) void ws3_bf16_kernel(WsArgs a) {
 
   // staging units of this thread: unit i = 8 pixels x 8 octets per wave instruction
   //   octet = (lane >> 3) + 8 * (ub & 1), pixel = (lane & 7) + 8 * (ub >> 1), ub = wave + 4 i
-  int s_px[G], s_oc[G];
+  // addresses: a wave-uniform image base + a 32-bit byte offset per lane (bp_bf16_ws_ok bounds the tensor)
+  int s_slot[G], s_oc[G];
+  unsigned s_off[G];
 #pragma unroll
   for (int i = 0; i < G; ++i) {
     const int ub = wave + 4 * i;
     s_oc[i] = (lane >> 3) + 8 * (ub & 1);
-    s_px[i] = (lane & 7) + 8 * (ub >> 1);
+    const int px = (lane & 7) + 8 * (ub >> 1);
+    s_slot[i] = s_oc[i] * PS + 1 + px;
+    s_off[i] = (unsigned)(px * a.in_cs + s_oc[i] * 8) * 2u;
   }
-  const u16* in_img = a.in + (int64_t)n * a.h * W * a.in_cs + a.in_co;
-  auto load_row = [&](int r, uint4 (&raw)[G]) {        // (r inside the image: uniform)
+  const char* in_img = reinterpret_cast<const char*>(a.in + (int64_t)n * a.h * W * a.in_cs + a.in_co);
+  const unsigned in_row = (unsigned)(W * a.in_cs) * 2u;
+  auto load_row = [&](int r, uint4 (&raw)[G]) {        // (r inside the image)
+    const char* rowp = in_img + (size_t)((unsigned)r * in_row);           // wave-uniform: a scalar base + a lane offset
 #pragma unroll
-    for (int i = 0; i < G; ++i)
-      raw[i] = *reinterpret_cast<const uint4*>(in_img + ((int64_t)r * W + s_px[i]) * a.in_cs + s_oc[i] * 8);
+    for (int i = 0; i < G; ++i) raw[i] = *reinterpret_cast<const uint4*>(rowp + s_off[i]);
+  };
+  // one half (4 channels: words 2h, 2h + 1) of a unit through the pending activation, in two phases that the row loop
+  // places in different K-steps: (A) parameters + unpack + affine, (B) leaky ReLU + rounding
+  auto act_a = [&](int oc, int h, unsigned w0, unsigned w1, float (&t)[4], float (&sl)[4]) {
+    const float4 sc = *reinterpret_cast<const float4*>(lpw + oc * 8 + 4 * h);
+    const float4 sf = *reinterpret_cast<const float4*>(lpw + WS_C + oc * 8 + 4 * h);
+    const float4 sv = *reinterpret_cast<const float4*>(lpw + 2 * WS_C + oc * 8 + 4 * h);
+    t[0] = fmaf(bf2f((u16)(w0 & 0xffffu)), sc.x, sf.x); t[1] = fmaf(bf2f((u16)(w0 >> 16)), sc.y, sf.y);
+    t[2] = fmaf(bf2f((u16)(w1 & 0xffffu)), sc.z, sf.z); t[3] = fmaf(bf2f((u16)(w1 >> 16)), sc.w, sf.w);
+    sl[0] = sv.x; sl[1] = sv.y; sl[2] = sv.z; sl[3] = sv.w;
+  };
+  auto act_b = [&](const float (&t)[4], const float (&sl)[4], unsigned& o0, unsigned& o1) {
+    const float u0 = t[0] > 0.f ? t[0] : t[0] * sl[0], u1 = t[1] > 0.f ? t[1] : t[1] * sl[1];      // (a NaN stays a NaN, as torch.relu)
+    const float u2 = t[2] > 0.f ? t[2] : t[2] * sl[2], u3 = t[3] > 0.f ? t[3] : t[3] * sl[3];
+    o0 = pack2(u0, u1); o1 = pack2(u2, u3);
+  };
+  auto act_half = [&](int oc, int h, unsigned w0, unsigned w1, unsigned& o0, unsigned& o1) {
+    float t[4], sl[4];
+    act_a(oc, h, w0, w1, t, sl);
+    act_b(t, sl, o0, o1);
+  };
+  auto commit_unit = [&](int i, int rr, bool inside, uint4 v) {
+    if constexpr (ACT) {
+      act_half(s_oc[i], 0, v.x, v.y, v.x, v.y);
+      act_half(s_oc[i], 1, v.z, v.w, v.z, v.w);
+    }
+    if (!inside) v = make_uint4(0u, 0u, 0u, 0u);
+    img[s_slot[i] + rr * RP] = v;
   };
   auto commit_row = [&](int r, bool inside, const uint4 (&raw)[G]) {
     const int rr = (r + 1) & (WS_R - 1);
 #pragma unroll
-    for (int i = 0; i < G; ++i) {
-      uint4 v = make_uint4(0u, 0u, 0u, 0u);
-      if (inside) {
-        v = raw[i];
-        if constexpr (ACT) {
-          const float4 sc0 = *reinterpret_cast<const float4*>(lpw + s_oc[i] * 8), sc1 = *reinterpret_cast<const float4*>(lpw + s_oc[i] * 8 + 4);
-          const float4 sf0 = *reinterpret_cast<const float4*>(lpw + WS_C + s_oc[i] * 8), sf1 = *reinterpret_cast<const float4*>(lpw + WS_C + s_oc[i] * 8 + 4);
-          const float4 sl0 = *reinterpret_cast<const float4*>(lpw + 2 * WS_C + s_oc[i] * 8), sl1 = *reinterpret_cast<const float4*>(lpw + 2 * WS_C + s_oc[i] * 8 + 4);
-          const float sc[8] = {sc0.x, sc0.y, sc0.z, sc0.w, sc1.x, sc1.y, sc1.z, sc1.w};
-          const float sf[8] = {sf0.x, sf0.y, sf0.z, sf0.w, sf1.x, sf1.y, sf1.z, sf1.w};
-          const float sl[8] = {sl0.x, sl0.y, sl0.z, sl0.w, sl1.x, sl1.y, sl1.z, sl1.w};
-          const unsigned wd[4] = {v.x, v.y, v.z, v.w};
-          float t[8];
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            t[2 * j] = fmaf(bf2f((u16)(wd[j] & 0xffffu)), sc[2 * j], sf[2 * j]);
-            t[2 * j + 1] = fmaf(bf2f((u16)(wd[j] >> 16)), sc[2 * j + 1], sf[2 * j + 1]);
-          }
-#pragma unroll
-          for (int j = 0; j < 8; ++j) t[j] = t[j] > 0.f ? t[j] : t[j] * sl[j];      // (a NaN stays a NaN, as torch.relu)
-          v = make_uint4(pack2(t[0], t[1]), pack2(t[2], t[3]), pack2(t[4], t[5]), pack2(t[6], t[7]));
-        }
-      }
-      img[s_oc[i] * PS + rr * RP + 1 + s_px[i]] = v;
-    }
+    for (int i = 0; i < G; ++i) commit_unit(i, rr, inside, raw[i]);
   };
 
   // ---- prologue: first three input rows requested, then the weights; zero columns; activation parameters
   uint4 raw0[G], raw1[G], raw2[G];
   const bool in0 = y0 - 1 >= 0, in2 = y0 + 1 < a.h;
-  if (in0) load_row(y0 - 1, raw0);
+  load_row(in0 ? y0 - 1 : y0, raw0);
   load_row(y0, raw1);
-  if (in2) load_row(y0 + 1, raw2);
+  load_row(in2 ? y0 + 1 : y0, raw2);
   bf8 wf[WS_NF];
   {
     const uint4* wsrc = reinterpret_cast<const uint4*>(a.wp) + (size_t)wave * WS_NF * 64 + lane;
@@ -171,63 +185,130 @@ __global__ __launch_bounds__(256) void ws3_bf16_kernel(WsArgs a) {
 #pragma unroll
   for (int j = 0; j < 8; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
   const int lbase = kq * PS + lm;                       // slot of (plane kq, pixel lm) in ring row 0
-  u16* out_img = a.out + (int64_t)n * a.h * W * a.out_cs + a.out_co + 32 * wave + 8 * kq;
+  char* out_img = reinterpret_cast<char*>(a.out + (int64_t)n * a.h * W * a.out_cs + a.out_co);
+  const unsigned out_row = (unsigned)(W * a.out_cs) * 2u;
+  const unsigned o_off = (unsigned)(lm * a.out_cs + 32 * wave + 8 * kq) * 2u, o_g = (unsigned)(16 * a.out_cs) * 2u;
 
-  for (int y = y0; y < y1; ++y) {
-    const bool more = y + 1 < y1;                       // another produced row: input row y + 2 is wanted
+  // Software pipeline over rows: while row y is multiplied into acc[P], the accumulators of row y - 1 (acc[P ^ 1]) are
+  // rounded, stored and summed, and input row y + 2 -- requested at the top of the row -- goes through its activation
+  // into the ring slot nobody reads this row; both in slices of a few vector instructions placed between the MFMAs of a
+  // K-step by sched_group_barrier patterns (one wave per SIMD: nobody else would fill the gaps).  The B fragments of
+  // step s + 1 (the next row's step 0 included: its input row is resident) are requested before the MFMAs of step s.
+  v4f acc[2][G][2];
+  bf8 xf[2][G];
+  uint4 pk[G];
+  auto epi_pack = [&](auto P_, int g, int yp) {         // row yp from acc[P]: a lane's 8 consecutive channels of a pixel
+    constexpr int P = decltype(P_)::value;
+    pk[g] = make_uint4(pack2(acc[P][g][0][0], acc[P][g][0][1]), pack2(acc[P][g][0][2], acc[P][g][0][3]),
+                       pack2(acc[P][g][1][0], acc[P][g][1][1]), pack2(acc[P][g][1][2], acc[P][g][1][3]));
+    char* rowp = out_img + (size_t)((unsigned)yp * out_row);
+    *reinterpret_cast<uint4*>(rowp + (o_off + (unsigned)g * o_g)) = pk[g];
+  };
+  auto epi_stats = [&](int g, int h) {                  // channels 4h .. 4h + 3 of the values AS STORED
+    const unsigned w0 = h ? pk[g].z : pk[g].x, w1 = h ? pk[g].w : pk[g].y;
+    const float v0 = bf2f((u16)(w0 & 0xffffu)), v1 = bf2f((u16)(w0 >> 16)), v2 = bf2f((u16)(w1 & 0xffffu)), v3 = bf2f((u16)(w1 >> 16));
+    s1[4 * h] += v0; s2[4 * h] = fmaf(v0, v0, s2[4 * h]);
+    s1[4 * h + 1] += v1; s2[4 * h + 1] = fmaf(v1, v1, s2[4 * h + 1]);
+    s1[4 * h + 2] += v2; s2[4 * h + 2] = fmaf(v2, v2, s2[4 * h + 2]);
+    s1[4 * h + 3] += v3; s2[4 * h + 3] = fmaf(v3, v3, s2[4 * h + 3]);
+  };
+  auto epi_all = [&](auto P_, int yp) {
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      epi_pack(P_, g, yp);
+      if constexpr (STATS) { epi_stats(g, 0); epi_stats(g, 1); }
+    }
+  };
+
+  auto row = [&](auto P_, auto PREV_, int y) {
+    constexpr int P = decltype(P_)::value;
+    constexpr bool PREV = decltype(PREV_)::value;
     const bool in_next = y + 2 < a.h;
-    if (more && in_next) load_row(y + 2, raw0);
-
+    load_row(in_next ? y + 2 : a.h - 1, raw0);          // (always: beyond the band's last row it lands in a free slot)
+    const int rr_next = (y + 3) & (WS_R - 1);
+    const unsigned keep = in_next ? 0xffffffffu : 0u;   // rows below the image are zero
     int rbase[3];
 #pragma unroll
     for (int ty = 0; ty < 3; ++ty) rbase[ty] = lbase + ((y + ty) & (WS_R - 1)) * RP;      // input row y - 1 + ty
-    v4f acc[G][2];
-#pragma unroll
-    for (int g = 0; g < G; ++g) { acc[g][0] = v4f{0.f, 0.f, 0.f, 0.f}; acc[g][1] = v4f{0.f, 0.f, 0.f, 0.f}; }
-    // 36 K-steps (tap row, channel chunk, tap column); the fragments of step s + 1 are requested before the MFMAs of
-    // step s (left alone the compiler reads each fragment right in front of its two MFMAs: an LDS round trip per pair)
-    bf8 xf[2][G];
-#pragma unroll
-    for (int g = 0; g < G; ++g) xf[0][g] = __builtin_bit_cast(bf8, img[rbase[0] + 16 * g]);
+    uint4 cv = make_uint4(0u, 0u, 0u, 0u);
+    float ct[4] = {0.f, 0.f, 0.f, 0.f}, csl[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int s = 0; s < 36; ++s) {
       const int ty = s / 12, c = (s / 3) & 3, tx = s % 3;
-      if (s + 1 < 36) {
-        const int ty1 = (s + 1) / 12, c1 = ((s + 1) / 3) & 3, tx1 = (s + 1) % 3;
+      // -- fragment reads of the next step (s == 35: step 0 of row y + 1, whose tap row 0 is input row y)
+      {
+        const int s1_ = (s + 1) % 36;
+        const int ty1 = s1_ / 12, c1 = (s1_ / 3) & 3, tx1 = s1_ % 3;
+        const int base1 = s == 35 ? rbase[1] : rbase[ty1];
 #pragma unroll
-        for (int g = 0; g < G; ++g)
-          xf[(s + 1) & 1][g] = __builtin_bit_cast(bf8, img[rbase[ty1] + 4 * c1 * PS + 16 * g + tx1]);
+        for (int g = 0; g < G; ++g) xf[(s + 1) & 1][g] = __builtin_bit_cast(bf8, img[base1 + 4 * c1 * PS + 16 * g + tx1]);
       }
-      __builtin_amdgcn_sched_barrier(0);
+      // -- side work of this step: one slice of <= 16 vector instructions (two per MFMA are free: an MFMA holds the
+      //    SIMD's issue port for 8 of its 16 cycles, a vector instruction for 4)
+      //    steps 1 .. 3G: previous row, group g: round + store | sums of channels 0-3 | of channels 4-7
+      //    steps 13 .. 13 + 4G: input row y + 2, unit i: half 0 affine | half 0 ReLU | half 1 affine | half 1 ReLU + write
+      if constexpr (PREV) {
+        if (s >= 1 && s < 1 + 3 * G) {
+          const int g = (s - 1) / 3, part = (s - 1) % 3;
+          if (part == 0) epi_pack(std::integral_constant<int, P ^ 1>{}, g, y - 1);
+          else if constexpr (STATS) epi_stats(g, part - 1);
+        }
+      }
+      if (s >= 13 && s < 13 + 4 * G) {
+        const int i = (s - 13) / 4, ph = (s - 13) % 4;
+        if constexpr (ACT) {
+          if (ph == 0) { cv = raw0[i]; act_a(s_oc[i], 0, cv.x, cv.y, ct, csl); }
+          else if (ph == 1) act_b(ct, csl, cv.x, cv.y);
+          else if (ph == 2) act_a(s_oc[i], 1, cv.z, cv.w, ct, csl);
+          else act_b(ct, csl, cv.z, cv.w);
+        } else {
+          if (ph == 0) cv = raw0[i];
+        }
+        if (ph == 3) {          // (a mask, not a branch: a branch would cut the K-step's scheduling region in two)
+          img[s_slot[i] + rr_next * RP] = make_uint4(cv.x & keep, cv.y & keep, cv.z & keep, cv.w & keep);
+        }
+      }
+      // -- the step's MFMAs
       const int f = ((ty * 3 + tx) * 4 + c) * 2;
 #pragma unroll
       for (int g = 0; g < G; ++g) {
-        acc[g][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[f], xf[s & 1][g], acc[g][0], 0, 0, 0);
-        acc[g][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[f + 1], xf[s & 1][g], acc[g][1], 0, 0, 0);
+        const v4f z = {0.f, 0.f, 0.f, 0.f};
+        acc[P][g][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[f], xf[s & 1][g], s == 0 ? z : acc[P][g][0], 0, 0, 0);
+        acc[P][g][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[f + 1], xf[s & 1][g], s == 0 ? z : acc[P][g][1], 0, 0, 0);
+      }
+      // -- issue order: a fragment read, then its share of the MFMAs with the side work's vector instructions between
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        WS_SGB(SG_DSR, 1);
+        WS_SGB(SG_MFMA, 1); WS_SGB(SG_VALU, 2);
+        WS_SGB(SG_MFMA, 1); WS_SGB(SG_VALU, 2);
       }
       __builtin_amdgcn_sched_barrier(0);
     }
-    // ---- epilogue of row y: lane (lm, kq) holds channels 32 wave + 8 kq + [0, 8) of pixel 16 g + lm
-    u16* orow = out_img + (int64_t)y * W * a.out_cs;
-#pragma unroll
-    for (int g = 0; g < G; ++g) {
-      const uint4 v = make_uint4(pack2(acc[g][0][0], acc[g][0][1]), pack2(acc[g][0][2], acc[g][0][3]),
-                                 pack2(acc[g][1][0], acc[g][1][1]), pack2(acc[g][1][2], acc[g][1][3]));
-      *reinterpret_cast<uint4*>(orow + (int64_t)(16 * g + lm) * a.out_cs) = v;
-      if constexpr (STATS) {
-        const unsigned wd[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float lo = bf2f((u16)(wd[j] & 0xffffu)), hi = bf2f((u16)(wd[j] >> 16));
-          s1[2 * j] += lo; s2[2 * j] = fmaf(lo, lo, s2[2 * j]);
-          s1[2 * j + 1] += hi; s2[2 * j + 1] = fmaf(hi, hi, s2[2 * j + 1]);
-        }
-      }
-    }
-    if (more) commit_row(y + 2, in_next, raw0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+  };
+
+  {
+    // step 0 of the first row
+    const int rb0 = lbase + (y0 & (WS_R - 1)) * RP;
+#pragma unroll
+    for (int g = 0; g < G; ++g) xf[0][g] = __builtin_bit_cast(bf8, img[rb0 + 16 * g]);
+  }
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  row(I0{}, std::false_type{}, y0);
+  int y = y0 + 1;
+  for (; y + 1 < y1; y += 2) {
+    row(I1{}, std::true_type{}, y);
+    row(I0{}, std::true_type{}, y + 1);
+  }
+  if (y < y1) {
+    row(I1{}, std::true_type{}, y);
+    epi_all(I1{}, y);
+  } else {
+    epi_all(I0{}, y - 1);
   }
 
   if constexpr (STATS) {

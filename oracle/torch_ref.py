@@ -14,23 +14,56 @@ import torch
 import torch.nn.functional as F
 
 
-def _seq(architecture, x, P, prefix, training, tap=None):
+class _StoreBf16(torch.autograd.Function):
+    """A tensor that the bf16 mode keeps in HBM as bf16: rounded (to nearest even) on the way forward, and its gradient
+    rounded on the way back -- whatever the arithmetic type of the graph around it (float64 in the tests)."""
+
+    @staticmethod
+    def forward(ctx, x, both):
+        ctx.both = both
+        return x.to(torch.bfloat16).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return (g.to(torch.bfloat16).to(g.dtype) if ctx.both else g), None
+
+
+def _bf16_layer(bf16, p):
+    """The bf16 policy of baryon_painter_amd.models.cvae._Plan.bf16_unit / bf16_out for the layer with state_dict
+    prefix ``p``: (runs on bf16 matrix cores, output stored as bf16)."""
+    if not bf16:
+        return False, False
+    name = p[:-1]
+    return name.startswith("p_y_z_in.") or name in ("p_mu_out.0", "p_var_out.0"), name.startswith("p_y_z_in.")
+
+
+def _seq(architecture, x, P, prefix, training, tap=None, bf16=False):
     """``tap`` (debug aid, tools/chain_bisect.py): dict that receives every convolution's raw output under the
-    layer's state_dict prefix, with ``retain_grad()`` so that d(loss)/d(raw) can be read after backward."""
+    layer's state_dict prefix, with ``retain_grad()`` so that d(loss)/d(raw) can be read after backward.
+    ``bf16``: a ROUNDING TWIN of the throughput mode (BASELINE.json configs[3]) -- the graph stays in its own dtype, but
+    every tensor the HIP path stores or stages as bf16 is rounded where that path rounds it: the operands of the trunk's
+    matrix-core layers (staged activation, packed weight), their stored raw outputs and residual sums, and the gradients
+    stored in those slots.  Not bit-equal to the kernels (accumulation order, fp32 vs this graph's dtype), but the same
+    rounding noise at the same places: what a correct bf16 execution's distance from the float64 truth looks like, per
+    tensor, conditioning included."""
     for i, layer in enumerate(architecture or []):
         name = layer[0].lower()
         cfg = layer[1] if len(layer) == 2 else None
         p = f"{prefix}{i}."
-        if name == "conv":
-            x = F.conv2d(x, P[p + "weight"], P.get(p + "bias"), stride=cfg.get("stride", 1),
-                         padding=cfg.get("padding", 0))
-            if tap is not None:
-                tap[p] = x
-                if x.requires_grad:
-                    x.retain_grad()
-        elif name == "transp conv":
-            x = F.conv_transpose2d(x, P[p + "weight"], P.get(p + "bias"), stride=cfg.get("stride", 1),
-                                   padding=cfg.get("padding", 0), output_padding=cfg.get("output_padding", 0))
+        if name in ("conv", "transp conv"):
+            w = P[p + "weight"]
+            mm, stored = _bf16_layer(bf16, p)
+            if mm:
+                # the stem's input is an fp32 slot whose gradient stays fp32 (dense one-channel buffer)
+                x = _StoreBf16.apply(x, not p.startswith("p_y_z_in.0."))
+                w = _StoreBf16.apply(w, False)
+            if name == "conv":
+                x = F.conv2d(x, w, P.get(p + "bias"), stride=cfg.get("stride", 1), padding=cfg.get("padding", 0))
+            else:
+                x = F.conv_transpose2d(x, w, P.get(p + "bias"), stride=cfg.get("stride", 1),
+                                       padding=cfg.get("padding", 0), output_padding=cfg.get("output_padding", 0))
+            if stored:
+                x = _StoreBf16.apply(x, True)
             if tap is not None:
                 tap[p] = x
                 if x.requires_grad:
@@ -57,7 +90,7 @@ def _seq(architecture, x, P, prefix, training, tap=None):
         elif name == "flatten":
             x = x.view(x.size(0), -1)
         elif name == "residual block":
-            h = _seq(cfg[0], x, P, p + "res_block.", training, tap) + x
+            h = _seq(cfg[0], x, P, p + "res_block.", training, tap, bf16) + x
             tail = cfg[1][0]
             if tail is None:
                 x = h
@@ -67,17 +100,20 @@ def _seq(architecture, x, P, prefix, training, tap=None):
                 x = F.leaky_relu(h, cfg[1][1])
             else:
                 raise NotImplementedError(tail)
+            if _bf16_layer(bf16, p)[1]:
+                x = _StoreBf16.apply(x, True)
         else:
             raise NotImplementedError(name)
     return x
 
 
 class TorchRefCVAE:
-    def __init__(self, architecture, params, buffers=None, dtype=torch.float32, tap=None):
+    def __init__(self, architecture, params, buffers=None, dtype=torch.float32, tap=None, bf16=False):
         """params: name -> array/tensor (learnables).  Buffers default to torch's initial values.
-        ``dtype`` float64 gives the "true value" of every tensor; ``tap``: see ``_seq``."""
+        ``dtype`` float64 gives the "true value" of every tensor; ``tap``, ``bf16`` (rounding twin of the throughput
+        mode): see ``_seq``."""
         self.a = architecture
-        self.dtype, self.tap = dtype, tap
+        self.dtype, self.tap, self.bf16 = dtype, tap, bf16
         self.P = {}
         for k, v in params.items():
             t = torch.as_tensor(v, dtype=dtype).clone()
@@ -163,9 +199,10 @@ class TorchRefCVAE:
         a, P, tr, tap = self.a, self.P, self.training, self.tap
         h_y = _seq(a["p_y_in"], y2, P, "p_y_in.", tr, tap)
         h_z = _seq(a["p_z_in"], z, P, "p_z_in.", tr, tap)
-        h = _seq(a["p_y_z_in"], torch.cat([h_z, h_y.repeat(self.L, 1, 1, 1)], 1), P, "p_y_z_in.", tr, tap)
-        x_mu = _seq(a["p_y_z_out"][0], h, P, "p_mu_out.", tr, tap)
-        x_lv = _seq(a["p_y_z_out"][1], h, P, "p_var_out.", tr, tap) if self.predict_var else None
+        b = self.bf16
+        h = _seq(a["p_y_z_in"], torch.cat([h_z, h_y.repeat(self.L, 1, 1, 1)], 1), P, "p_y_z_in.", tr, tap, b)
+        x_mu = _seq(a["p_y_z_out"][0], h, P, "p_mu_out.", tr, tap, b)
+        x_lv = _seq(a["p_y_z_out"][1], h, P, "p_var_out.", tr, tap, b) if self.predict_var else None
         return x_mu, x_lv
 
     def sample_P(self, y, aux, eps=None, z=None):
