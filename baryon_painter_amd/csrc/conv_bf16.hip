@@ -18,7 +18,6 @@ int bp_bf16_flat_run(const ConvGeom& g, const bp_view* in, const PW& pw, const u
                      hipStream_t st, const IgemmStatsReq* sr);
 
 // conv_bf16_ws.hip: weights-stationary kernel of the 128 -> 128 k3 trunk; its weight image follows the other two
-bool bp_bf16_ws_geom_ok(const ConvGeom& g);
 int64_t bp_bf16_ws_packed_elems(const ConvGeom& g);
 int bp_bf16_ws_pack(const ConvGeom& g, const WeightMap& wm, const float* w_torch, u16* dst, hipStream_t st);
 bool bp_bf16_ws_ok(const ConvGeom& g, const bp_view* in, const bp_view* out, const float* bias, int mode);

@@ -328,52 +328,337 @@ __global__ __launch_bounds__(256) void ws3_bf16_kernel(WsArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// The same scheme for the strided gather form  k4 s2 p1, 64 -> 128 channels  (forward of p_y_z_in.9, data gradient of the
+// transposed layer p_y_z_in.16: /root/reference/trained_models/CVAE/fiducial/architecture_built.txt:51,94): 262 KB of
+// weights = 64 A-fragments per wave; one produced row gathers four input rows (two new ones per produced row: a ring of
+// six), the fine-grid pixels split by column parity into two sets of eight octet planes so that the 16 pixels of a
+// B-fragment (stride 2 on the fine grid) are consecutive slots of one plane.
+constexpr int W4_CI = 64, W4_R = 6, W4_NF = 64, W4_FV = 16;
+template <int G> struct W4Geom {
+  static constexpr int W = 16 * G, RP = W + 2;
+  static constexpr int PS = (W4_R * RP + 15) / 16 * 16;
+  static constexpr size_t img_bytes = (size_t)16 * PS * 16;
+  static constexpr size_t lds_bytes = img_bytes + 3 * W4_CI * sizeof(float);
+};
+
+// fragment f = ((ky*4 + kx)*2 + chunk)*2 + block; lane (lm, kq): produced channel 32 w + 8 (lm >> 2) + 4 block + (lm & 3),
+// gathered channel 32 chunk + 8 kq + j
+__global__ __launch_bounds__(256) void ws4_pack_kernel(WsPackArgs a) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= 4 * W4_NF * 64 * 8) return;
+  const int j = i & 7, lane = (i >> 3) & 63, f = (i >> 9) % W4_NF, w = i / (512 * W4_NF);
+  const int lm = lane & 15, kq = lane >> 4;
+  const int blk = f & 1, chunk = (f >> 1) & 1, tap = f >> 2;
+  const int ky = tap >> 2, kx = tap & 3;
+  const int co = 32 * w + 8 * (lm >> 2) + 4 * blk + (lm & 3);
+  const int ci = 32 * chunk + 8 * kq + j;
+  a.dst[i] = f2bf(a.w[ci * a.sa + co * a.sb + ky * 4 + kx]);
+}
+
+__device__ __forceinline__ void ws_act_a(const float* lpw, int C, int oc, int h, unsigned w0, unsigned w1, float (&t)[4], float (&sl)[4]) {
+  const float4 sc = *reinterpret_cast<const float4*>(lpw + oc * 8 + 4 * h);
+  const float4 sf = *reinterpret_cast<const float4*>(lpw + C + oc * 8 + 4 * h);
+  const float4 sv = *reinterpret_cast<const float4*>(lpw + 2 * C + oc * 8 + 4 * h);
+  t[0] = fmaf(bf2f((u16)(w0 & 0xffffu)), sc.x, sf.x); t[1] = fmaf(bf2f((u16)(w0 >> 16)), sc.y, sf.y);
+  t[2] = fmaf(bf2f((u16)(w1 & 0xffffu)), sc.z, sf.z); t[3] = fmaf(bf2f((u16)(w1 >> 16)), sc.w, sf.w);
+  sl[0] = sv.x; sl[1] = sv.y; sl[2] = sv.z; sl[3] = sv.w;
+}
+__device__ __forceinline__ void ws_act_b(const float (&t)[4], const float (&sl)[4], unsigned& o0, unsigned& o1) {
+  const float u0 = t[0] > 0.f ? t[0] : t[0] * sl[0], u1 = t[1] > 0.f ? t[1] : t[1] * sl[1];      // (a NaN stays a NaN)
+  const float u2 = t[2] > 0.f ? t[2] : t[2] * sl[2], u3 = t[3] > 0.f ? t[3] : t[3] * sl[3];
+  o0 = pack2(u0, u1); o1 = pack2(u2, u3);
+}
+
+template <int G, bool ACT, bool STATS>
+__global__ __launch_bounds__(256) void ws4_bf16_kernel(WsArgs a) {
+  using GM = W4Geom<G>;
+  constexpr int W = GM::W, RP = GM::RP, PS = GM::PS;
+  constexpr int NS = 32;                                // K-steps per produced row: 16 taps x 2 chunks of 32 channels
+  extern __shared__ __attribute__((aligned(16))) u16 smem[];
+  uint4* img = reinterpret_cast<uint4*>(smem);          // [parity 2][octet 8][ring row 6][RP]
+  float* lpw = reinterpret_cast<float*>(smem + GM::img_bytes / 2);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lm = lane & 15, kq = lane >> 4;
+  const int n = blockIdx.x / a.bands, band = blockIdx.x % a.bands;
+  const int y0 = band * a.BR;
+  const int y1 = min(y0 + a.BR, a.h);                   // produced rows [y0, y1); a.h produced rows, 2 a.h gathered rows
+  const int hin = 2 * a.h;
+
+  // staging units of this thread, per gathered row: unit j = 8 fine pixels x 8 octets per wave instruction,
+  // fine pixel (lane & 7) + 8 (wave + 4 j), octet lane >> 3; the pixel's parity (lane & 1) picks the plane set
+  const int s_oc = lane >> 3;
+  const int s_slot0 = ((lane & 1) * 8 + s_oc) * PS + 1 + ((lane & 7) >> 1) + 4 * wave;          // + 16 j + ring * RP
+  const unsigned s_off0 = (unsigned)(((lane & 7) + 8 * wave) * a.in_cs + s_oc * 8) * 2u;       // + j * s_offj
+  const unsigned s_offj = (unsigned)(32 * a.in_cs) * 2u;
+  const char* in_img = reinterpret_cast<const char*>(a.in + (int64_t)n * hin * (2 * W) * a.in_cs + a.in_co);
+  const unsigned in_row = (unsigned)(2 * W * a.in_cs) * 2u;
+  auto load_row = [&](int r, uint4 (&raw)[G]) {         // (r inside the image)
+    const char* rowp = in_img + (size_t)((unsigned)r * in_row);
+#pragma unroll
+    for (int j = 0; j < G; ++j) raw[j] = *reinterpret_cast<const uint4*>(rowp + (s_off0 + (unsigned)j * s_offj));
+  };
+  auto commit_row = [&](int ring, bool inside, const uint4 (&raw)[G]) {
+#pragma unroll
+    for (int j = 0; j < G; ++j) {
+      uint4 v = raw[j];
+      if constexpr (ACT) {
+        float t[4], sl[4];
+        ws_act_a(lpw, W4_CI, s_oc, 0, v.x, v.y, t, sl); ws_act_b(t, sl, v.x, v.y);
+        ws_act_a(lpw, W4_CI, s_oc, 1, v.z, v.w, t, sl); ws_act_b(t, sl, v.z, v.w);
+      }
+      if (!inside) v = make_uint4(0u, 0u, 0u, 0u);
+      img[s_slot0 + 16 * j + ring * RP] = v;
+    }
+  };
+  // ring slot of gathered row r (>= -1): (r + 1) % 6
+  auto ring_of = [](int r) { return (r + 1) % W4_R; };
+
+  // ---- prologue: gathered rows 2 y0 - 1 .. 2 y0 + 2, the weights, zero columns, activation parameters
+  uint4 rawa[G], rawb[G];
+  const int r0 = 2 * y0 - 1;
+  load_row(r0 >= 0 ? r0 : 0, rawa);
+  load_row(r0 + 1, rawb);
+  bf8 wf[W4_NF];
+  {
+    const uint4* wsrc = reinterpret_cast<const uint4*>(a.wp) + (size_t)wave * W4_NF * 64 + lane;
+#pragma unroll
+    for (int f = 0; f < W4_NF; ++f) wf[f] = __builtin_bit_cast(bf8, wsrc[f * 64]);
+#pragma unroll
+    for (int f = 0; f < W4_NF; ++f) {
+      if (f < W4_FV) asm volatile("" : "+v"(wf[f]));
+      else asm volatile("" : "+a"(wf[f]));
+    }
+  }
+  if (tid < 192) {
+    const int plane = tid / 12, rr = (tid / 2) % 6, side = tid & 1;
+    img[plane * PS + rr * RP + (side ? RP - 1 : 0)] = make_uint4(0u, 0u, 0u, 0u);
+  }
+  if constexpr (ACT) {
+    for (int i = tid; i < W4_CI; i += 256) { lpw[i] = a.pw.scale[i]; lpw[W4_CI + i] = a.pw.shift[i]; lpw[2 * W4_CI + i] = a.pw.slope[i]; }
+    __syncthreads();
+  }
+  commit_row(ring_of(r0), r0 >= 0, rawa);
+  commit_row(ring_of(r0 + 1), true, rawb);
+  load_row(r0 + 2, rawa);
+  load_row(r0 + 3 < hin ? r0 + 3 : hin - 1, rawb);
+  commit_row(ring_of(r0 + 2), true, rawa);
+  commit_row(ring_of(r0 + 3), r0 + 3 < hin, rawb);
+  __syncthreads();
+
+  float s1[8], s2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+  const int lbase = kq * PS + lm;
+  char* out_img = reinterpret_cast<char*>(a.out + (int64_t)n * a.h * W * a.out_cs + a.out_co);
+  const unsigned out_row = (unsigned)(W * a.out_cs) * 2u;
+  const unsigned o_off = (unsigned)(lm * a.out_cs + 32 * wave + 8 * kq) * 2u, o_g = (unsigned)(16 * a.out_cs) * 2u;
+
+  v4f acc[2][G][2];
+  bf8 xf[2][G];
+  uint4 pk[G];
+  auto epi_pack = [&](auto P_, int g, int yp) {
+    constexpr int P = decltype(P_)::value;
+    pk[g] = make_uint4(pack2(acc[P][g][0][0], acc[P][g][0][1]), pack2(acc[P][g][0][2], acc[P][g][0][3]),
+                       pack2(acc[P][g][1][0], acc[P][g][1][1]), pack2(acc[P][g][1][2], acc[P][g][1][3]));
+    char* rowp = out_img + (size_t)((unsigned)yp * out_row);
+    *reinterpret_cast<uint4*>(rowp + (o_off + (unsigned)g * o_g)) = pk[g];
+  };
+  auto epi_stats = [&](int g, int h) {
+    const unsigned w0 = h ? pk[g].z : pk[g].x, w1 = h ? pk[g].w : pk[g].y;
+    const float v0 = bf2f((u16)(w0 & 0xffffu)), v1 = bf2f((u16)(w0 >> 16)), v2 = bf2f((u16)(w1 & 0xffffu)), v3 = bf2f((u16)(w1 >> 16));
+    s1[4 * h] += v0; s2[4 * h] = fmaf(v0, v0, s2[4 * h]);
+    s1[4 * h + 1] += v1; s2[4 * h + 1] = fmaf(v1, v1, s2[4 * h + 1]);
+    s1[4 * h + 2] += v2; s2[4 * h + 2] = fmaf(v2, v2, s2[4 * h + 2]);
+    s1[4 * h + 3] += v3; s2[4 * h + 3] = fmaf(v3, v3, s2[4 * h + 3]);
+  };
+  auto epi_all = [&](auto P_, int yp) {
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      epi_pack(P_, g, yp);
+      if constexpr (STATS) { epi_stats(g, 0); epi_stats(g, 1); }
+    }
+  };
+
+  // row y: gathered rows 2y - 1 + t, t = 0..3, live in ring slots (rb + t) % 6, rb = (2 y) % 6; rows t = 4, 5 are requested at
+  // the top and committed in the second half of the K-steps
+  auto row = [&](auto P_, auto PREV_, int y, int rb) {
+    constexpr int P = decltype(P_)::value;
+    constexpr bool PREV = decltype(PREV_)::value;
+    const int ra = 2 * y + 3, rbw = 2 * y + 4;
+    const bool in_a = ra < hin, in_b = rbw < hin;
+    load_row(in_a ? ra : hin - 1, rawa);
+    load_row(in_b ? rbw : hin - 1, rawb);
+    const unsigned keep_a = in_a ? 0xffffffffu : 0u, keep_b = in_b ? 0xffffffffu : 0u;
+    int ring[6];
+#pragma unroll
+    for (int t = 0; t < 6; ++t) ring[t] = rb + t < W4_R ? rb + t : rb + t - W4_R;
+    int vb[2][4];                                       // per-lane slot of (parity, tap row)
+#pragma unroll
+    for (int ky = 0; ky < 4; ++ky) { vb[0][ky] = lbase + ring[ky] * RP; vb[1][ky] = vb[0][ky] + 8 * PS; }
+    uint4 cv = make_uint4(0u, 0u, 0u, 0u);
+    float ct[4] = {0.f, 0.f, 0.f, 0.f}, csl[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const int ky = s >> 3, c = (s >> 2) & 1, kx = s & 3;
+      {   // fragments of the next step (s == NS - 1: step 0 of row y + 1, whose tap row 0 is this row's tap row 2)
+        const int sn = (s + 1) % NS;
+        const int kyn = sn >> 3, cn = (sn >> 2) & 1, kxn = sn & 3;
+        const int base = vb[(kxn & 1) ^ 1][s == NS - 1 ? 2 : kyn] + 4 * cn * PS + ((kxn + 1) >> 1);
+#pragma unroll
+        for (int g = 0; g < G; ++g) xf[(s + 1) & 1][g] = __builtin_bit_cast(bf8, img[base + 16 * g]);
+      }
+      if constexpr (PREV) {
+        if (s >= 1 && s < 1 + 3 * G) {
+          const int g = (s - 1) / 3, part = (s - 1) % 3;
+          if (part == 0) epi_pack(std::integral_constant<int, P ^ 1>{}, g, y - 1);
+          else if constexpr (STATS) epi_stats(g, part - 1);
+        }
+      }
+      if (s >= 13 && s < 13 + 4 * G) {                  // 2 G units, two steps each
+        const int u = (s - 13) / 2, hh = (s - 13) % 2;
+        const int rsel = u / G, j = u % G;
+        if (hh == 0) {
+          cv = rsel ? rawb[j] : rawa[j];
+          if constexpr (ACT) { ws_act_a(lpw, W4_CI, s_oc, 0, cv.x, cv.y, ct, csl); ws_act_b(ct, csl, cv.x, cv.y); }
+        } else {
+          if constexpr (ACT) { ws_act_a(lpw, W4_CI, s_oc, 1, cv.z, cv.w, ct, csl); ws_act_b(ct, csl, cv.z, cv.w); }
+          const unsigned keep = rsel ? keep_b : keep_a;
+          img[s_slot0 + 16 * j + ring[4 + rsel] * RP] = make_uint4(cv.x & keep, cv.y & keep, cv.z & keep, cv.w & keep);
+        }
+      }
+      const int f = ((ky * 4 + kx) * 2 + c) * 2;
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        const v4f z = {0.f, 0.f, 0.f, 0.f};
+        acc[P][g][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[f], xf[s & 1][g], s == 0 ? z : acc[P][g][0], 0, 0, 0);
+        acc[P][g][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[f + 1], xf[s & 1][g], s == 0 ? z : acc[P][g][1], 0, 0, 0);
+      }
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        WS_SGB(SG_DSR, 1);
+        WS_SGB(SG_MFMA, 1); WS_SGB(SG_VALU, 2);
+        WS_SGB(SG_MFMA, 1); WS_SGB(SG_VALU, 2);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
+
+  int rb = (2 * y0) % W4_R;
+  {   // step 0 of the first row: tap (0, 0), chunk 0: odd plane set, column offset 0
+    const int b0 = lbase + 8 * PS + rb * RP;
+#pragma unroll
+    for (int g = 0; g < G; ++g) xf[0][g] = __builtin_bit_cast(bf8, img[b0 + 16 * g]);
+  }
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  auto next_rb = [](int v) { return v + 2 < W4_R ? v + 2 : v + 2 - W4_R; };
+  row(I0{}, std::false_type{}, y0, rb);
+  rb = next_rb(rb);
+  int y = y0 + 1;
+  for (; y + 1 < y1; y += 2) {
+    row(I1{}, std::true_type{}, y, rb);
+    rb = next_rb(rb);
+    row(I0{}, std::true_type{}, y + 1, rb);
+    rb = next_rb(rb);
+  }
+  if (y < y1) {
+    row(I1{}, std::true_type{}, y, rb);
+    epi_all(I1{}, y);
+  } else {
+    epi_all(I0{}, y - 1);
+  }
+
+  if constexpr (STATS) {
+    float* red = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int ch = 32 * wave + 8 * kq + j;
+      red[ch * 16 + lm] = s1[j];
+      red[(WS_C + ch) * 16 + lm] = s2[j];
+    }
+    __syncthreads();
+    double t = 0.0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) t += (double)red[tid * 16 + i];
+    a.stat[(int64_t)blockIdx.x * 2 * WS_C + tid] = t;
+  }
+}
+
 bool ws_enabled() {
   static const bool off = getenv("BP_BF16_WS") && atoi(getenv("BP_BF16_WS")) == 0;
   return !off;
 }
 int g_ws_override = -1;       // bp_set_option("bf16_ws", v)
 
-int ws_G(const bp_view* v) { return v->w == 64 ? 4 : v->w == 32 ? 2 : v->w == 16 ? 1 : 0; }
+int ws_G(int w) { return w == 64 ? 4 : w == 32 ? 2 : w == 16 ? 1 : 0; }
 
 // rows per band: whole image per workgroup when there are many images, else bands of >= 4 rows so that ~256 workgroups exist
-void ws_bands(const bp_view* in, int* BR, int* bands) {
-  int br = in->h;
-  while (br > 4 && (int64_t)in->n * bp_ceil_div(in->h, br) < 256) br = bp_ceil_div(br, 2);
+void ws_bands(int n, int h, int* BR, int* bands) {
+  int br = h;
+  while (br > 4 && (int64_t)n * bp_ceil_div(h, br) < 256) br = bp_ceil_div(br, 2);
   *BR = br;
-  *bands = bp_ceil_div(in->h, br);
+  *bands = bp_ceil_div(h, br);
 }
 
-template <int G, bool ACT, bool STATS>
+template <int KIND, int G, bool ACT, bool STATS>
 int ws_launch(const WsArgs& a, unsigned grid, hipStream_t st) {
-  static const hipError_t optin = hipFuncSetAttribute(reinterpret_cast<const void*>(&ws3_bf16_kernel<G, ACT, STATS>),
-                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)WsGeom<G>::lds_bytes);
+  constexpr size_t lds = KIND == 3 ? WsGeom<G>::lds_bytes : W4Geom<G>::lds_bytes;
+  auto kern = [] {
+    if constexpr (KIND == 3) return &ws3_bf16_kernel<G, ACT, STATS>;
+    else return &ws4_bf16_kernel<G, ACT, STATS>;
+  }();
+  static const hipError_t optin = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (optin != hipSuccess) return BP_ELAUNCH;
-  hipLaunchKernelGGL((ws3_bf16_kernel<G, ACT, STATS>), dim3(grid), dim3(256), WsGeom<G>::lds_bytes, st, a);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a);
   BP_CHECK_LAUNCH();
   return BP_OK;
 }
-template <int G>
+template <int KIND, int G>
 int ws_launch_g(const WsArgs& a, bool act, bool stats, unsigned grid, hipStream_t st) {
-  if (act) return stats ? ws_launch<G, true, true>(a, grid, st) : ws_launch<G, true, false>(a, grid, st);
-  return stats ? ws_launch<G, false, true>(a, grid, st) : ws_launch<G, false, false>(a, grid, st);
+  if (act) return stats ? ws_launch<KIND, G, true, true>(a, grid, st) : ws_launch<KIND, G, true, false>(a, grid, st);
+  return stats ? ws_launch<KIND, G, false, true>(a, grid, st) : ws_launch<KIND, G, false, false>(a, grid, st);
+}
+template <int KIND>
+int ws_launch_k(int G, const WsArgs& a, bool act, bool stats, unsigned grid, hipStream_t st) {
+  switch (G) {
+    case 4: return ws_launch_g<KIND, 4>(a, act, stats, grid, st);
+    case 2: return ws_launch_g<KIND, 2>(a, act, stats, grid, st);
+    default: return ws_launch_g<KIND, 1>(a, act, stats, grid, st);
+  }
 }
 
 }  // namespace
 
 void bp_bf16_ws_set(int v) { g_ws_override = v; }
 
-bool bp_bf16_ws_geom_ok(const ConvGeom& g) {
-  return g.k == 3 && g.stride == 1 && g.pad == 1 && g.cin_g == WS_C && g.cout_g == WS_C && g.nphase == 1 && g.taps == 3 &&
-         g.IS == 1 && g.OS == 1;
+// 3: the k3 s1 p1 128 -> 128 trunk layer (either direction); 4: the strided gather k4 s2 p1 64 -> 128; 0: neither
+int bp_bf16_ws_kind(const ConvGeom& g) {
+  if (g.nphase != 1 || g.OS != 1) return 0;
+  if (g.k == 3 && g.stride == 1 && g.pad == 1 && g.cin_g == WS_C && g.cout_g == WS_C && g.taps == 3 && g.IS == 1) return 3;
+  if (g.k == 4 && g.stride == 2 && g.pad == 1 && g.cin_g == W4_CI && g.cout_g == WS_C && g.taps == 4 && g.IS == 2 &&
+      !g.gather_transposed)
+    return 4;
+  return 0;
 }
 
-int64_t bp_bf16_ws_packed_elems(const ConvGeom& g) { return bp_bf16_ws_geom_ok(g) ? (int64_t)4 * WS_NF * 64 * 8 : 0; }
+int64_t bp_bf16_ws_packed_elems(const ConvGeom& g) {
+  const int k = bp_bf16_ws_kind(g);
+  return k == 3 ? (int64_t)4 * WS_NF * 64 * 8 : k == 4 ? (int64_t)4 * W4_NF * 64 * 8 : 0;
+}
 
 int bp_bf16_ws_pack(const ConvGeom& g, const WeightMap& wm, const float* w_torch, u16* dst, hipStream_t st) {
-  if (!bp_bf16_ws_geom_ok(g)) return BP_EUNSUPPORTED;
+  const int k = bp_bf16_ws_kind(g);
+  if (!k) return BP_EUNSUPPORTED;
   const WsPackArgs a{w_torch, dst, wm.sa, wm.sb, g.gather_transposed};
-  hipLaunchKernelGGL(ws_pack_kernel, dim3(4 * WS_NF * 64 * 8 / 256), dim3(256), 0, st, a);
+  if (k == 3) hipLaunchKernelGGL(ws_pack_kernel, dim3(4 * WS_NF * 64 * 8 / 256), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(ws4_pack_kernel, dim3(4 * W4_NF * 64 * 8 / 256), dim3(256), 0, st, a);
   BP_CHECK_LAUNCH();
   return BP_OK;
 }
@@ -381,21 +666,27 @@ int bp_bf16_ws_pack(const ConvGeom& g, const WeightMap& wm, const float* w_torch
 // mode: 0 none, 1 batch-norm sums of the produced tensor
 bool bp_bf16_ws_ok(const ConvGeom& g, const bp_view* in, const bp_view* out, const float* bias, int mode) {
   if (!(g_ws_override < 0 ? ws_enabled() : g_ws_override != 0)) return false;
-  if (!bp_bf16_ws_geom_ok(g) || !in || !out || bias || (mode != 0 && mode != 1)) return false;
-  if (in->dtype != BP_BF16 || out->dtype != BP_BF16 || in->c != WS_C || out->c != WS_C) return false;
-  if (in->w != out->w || in->h != out->h || in->n != out->n || !ws_G(in)) return false;
+  const int k = bp_bf16_ws_kind(g);
+  if (!k || !in || !out || bias || (mode != 0 && mode != 1)) return false;
+  if (in->dtype != BP_BF16 || out->dtype != BP_BF16 || in->c != g.cin_g || out->c != g.cout_g) return false;
+  if (in->n != out->n || !ws_G(out->w)) return false;
+  if (k == 3 && (in->w != out->w || in->h != out->h)) return false;
+  if (k == 4 && (in->w != 2 * out->w || in->h != 2 * out->h)) return false;
   if (in->cstride % 8 || in->coff % 8 || reinterpret_cast<uintptr_t>(in->ptr) % 16) return false;
   if (out->cstride % 8 || out->coff % 8 || reinterpret_cast<uintptr_t>(out->ptr) % 16) return false;
+  // (row addresses are a 64-bit image base + 32-bit byte offsets inside the image)
+  if ((int64_t)in->h * in->w * in->cstride * 2 >= (int64_t)1 << 31 || (int64_t)out->h * out->w * out->cstride * 2 >= (int64_t)1 << 31)
+    return false;
   int BR, bands;
-  ws_bands(in, &BR, &bands);
-  if (mode == 1 && BR * ws_G(in) > 256) return false;          // a lane's fp32 partial sums: <= 256 terms
-  return (int64_t)in->n * bands <= 0x7fffffff;
+  ws_bands(out->n, out->h, &BR, &bands);
+  if (mode == 1 && BR * ws_G(out->w) > 256) return false;          // a lane's fp32 partial sums: <= 256 terms
+  return (int64_t)out->n * bands <= 0x7fffffff;
 }
 
 size_t bp_bf16_ws_stats_workspace(const ConvGeom& g, const bp_view* in, const bp_view* out) {
   int BR, bands;
-  ws_bands(in, &BR, &bands);
-  return bp_stats_rows_bytes((int64_t)in->n * bands, g.cout_g);
+  ws_bands(out->n, out->h, &BR, &bands);
+  return bp_stats_rows_bytes((int64_t)out->n * bands, g.cout_g);
 }
 
 int bp_bf16_ws_run(const ConvGeom& g, const bp_view* in, const PW& pw, const u16* packed_ws, const bp_view* out,
@@ -403,9 +694,9 @@ int bp_bf16_ws_run(const ConvGeom& g, const bp_view* in, const PW& pw, const u16
   WsArgs a{};
   a.in = reinterpret_cast<const u16*>(in->ptr); a.in_cs = in->cstride; a.in_co = in->coff;
   a.out = reinterpret_cast<u16*>(out->ptr); a.out_cs = out->cstride; a.out_co = out->coff;
-  a.n = in->n; a.h = in->h; a.wp = packed_ws; a.pw = pw;
-  ws_bands(in, &a.BR, &a.bands);
-  const int64_t rows = (int64_t)in->n * a.bands;
+  a.n = out->n; a.h = out->h; a.wp = packed_ws; a.pw = pw;
+  ws_bands(out->n, out->h, &a.BR, &a.bands);
+  const int64_t rows = (int64_t)out->n * a.bands;
   if (sr) {
     const size_t need = bp_stats_rows_bytes(rows, g.cout_g);
     if (sr->mode != 1 || !need) return BP_EUNSUPPORTED;
@@ -413,12 +704,8 @@ int bp_bf16_ws_run(const ConvGeom& g, const bp_view* in, const PW& pw, const u16
     a.stat = reinterpret_cast<double*>(sr->ws);
   }
   const bool act = pw.scale != nullptr;
-  int rc;
-  switch (ws_G(in)) {
-    case 4: rc = ws_launch_g<4>(a, act, sr != nullptr, (unsigned)rows, st); break;
-    case 2: rc = ws_launch_g<2>(a, act, sr != nullptr, (unsigned)rows, st); break;
-    default: rc = ws_launch_g<1>(a, act, sr != nullptr, (unsigned)rows, st); break;
-  }
+  const int rc = bp_bf16_ws_kind(g) == 3 ? ws_launch_k<3>(ws_G(out->w), a, act, sr != nullptr, (unsigned)rows, st)
+                                         : ws_launch_k<4>(ws_G(out->w), a, act, sr != nullptr, (unsigned)rows, st);
   if (rc != BP_OK || !sr) return rc;
   return bp_stats_rows_finish(a.stat, rows, g.cout_g, sr, st);
 }

@@ -226,20 +226,28 @@ def test_fp32_entry_points_refuse_bf16_views():
                                G.stream()) == -1            # BP_EINVAL: the fp32 kernels take fp32 views only
 
 
-# ---- the weights-stationary kernel of the 128 -> 128 k3 trunk (csrc/conv_bf16_ws.hip) against the tiled kernel it replaces
+# ---- the weights-stationary kernels (csrc/conv_bf16_ws.hip) against the tiled kernels they replace
+WS_LAYERS = {
+    # (transposed, cin, cout, k, stride, pad), input shapes (n, h, w) the stationary kernel takes in at least one direction
+    "k3": ((0, 128, 128, 3, 1, 1), [(2, 9, 16), (3, 20, 32), (2, 64, 64), (5, 16, 64), (70, 8, 16)]),
+    "k4s2": ((0, 64, 128, 4, 2, 1), [(2, 16, 32), (3, 12, 64), (2, 40, 128), (66, 8, 32)]),      # forward: strided gather
+    "t4s2": ((1, 128, 64, 4, 2, 1), [(2, 7, 16), (2, 9, 32), (3, 20, 64)]),                        # data gradient: the same gather
+}
+
+
 @pytest.mark.parametrize("act", ["none", "relu", "leaky"])
-@pytest.mark.parametrize("shape", [(2, 9, 16), (3, 20, 32), (2, 64, 64), (5, 16, 64), (70, 8, 16)],
-                         ids=lambda s: "%dx%dx%d" % s)
-def test_weights_stationary_trunk_kernel(shape, act):
+@pytest.mark.parametrize("layer,shape", [(k, sh) for k, (_, shs) in WS_LAYERS.items() for sh in shs],
+                         ids=lambda v: v if isinstance(v, str) else "%dx%dx%d" % v)
+def test_weights_stationary_kernels(layer, shape, act):
     """Forward (with and without the batch-norm sums) and data gradient: each kernel within 2^-8 of the float64
     convolution of the same bf16 operands, the two kernels' sums equal to 1e-6 of the sum of magnitudes; views that are
     channel slices of wider buffers; bands that end inside the image (n * h chosen so that several band sizes occur)."""
     lib = L.load()
     n, h, w = shape
-    ci = co = 128
-    rng = np.random.default_rng(n * 1000 + h * 10 + w)
+    tr, ci, co, k, st_, p = WS_LAYERS[layer][0]
+    rng = np.random.default_rng(n * 1000 + h * 10 + w + k)
     x = bf16_round(rng.standard_normal((n, ci, h, w)).astype(np.float32))
-    wt = (rng.standard_normal((co, ci, 3, 3)) * 0.05).astype(np.float32)
+    wt = (rng.standard_normal(((ci, co) if tr else (co, ci)) + (k, k)) * 0.05).astype(np.float32)
     scale = rng.uniform(0.5, 1.5, ci).astype(np.float32)
     shift = rng.uniform(0.2, 0.6, ci).astype(np.float32)
     slope = rng.uniform(0.0, 0.3, ci).astype(np.float32)
@@ -252,8 +260,9 @@ def test_weights_stationary_trunk_kernel(shape, act):
              + shift[None, :, None, None].astype(np.float64)).astype(np.float32)
         xa = bf16_round(np.where(t > 0, t, t * slope[None, :, None, None]).astype(np.float32)).astype(np.float64)
     w64 = bf16_round(wt).astype(np.float64)
-    y_ref = ops.conv2d_fwd(xa, w64, 1, 1)
-    cv = L.Conv(0, ci, co, 3, 1, 1, 0)
+    y_ref = ops.convT2d_fwd(xa, w64, st_, p, 0) if tr else ops.conv2d_fwd(xa, w64, st_, p)
+    _, _, ho, wo = y_ref.shape
+    cv = L.Conv(tr, ci, co, k, st_, p, 0)
     st = G.stream()
     xb, xv = to_view(x, True, cstride=ci + 16, coff=8)
     keep, pw = G.pointwise(scale, shift, slope)
@@ -265,12 +274,13 @@ def test_weights_stationary_trunk_kernel(shape, act):
     L.check(lib.bp_conv_bf16_pack(C.byref(cv), L.PACK_BWD, L.ptr(wd), L.ptr(pb), st))
     dy = bf16_round(rng.standard_normal(y_ref.shape).astype(np.float32))
     dyb, dyv = to_view(dy, True)
-    dx_ref = ops.conv2d_bwd_data(dy.astype(np.float64), w64, 1, 1, h, w)
+    dx_ref = ops.convT2d_bwd_data(dy.astype(np.float64), w64, st_, p) if tr else \
+        ops.conv2d_bwd_data(dy.astype(np.float64), w64, st_, p, h, w)
     res = {}
     try:
         for ws_on in (1, 0):
             assert lib.bp_set_option(b"bf16_ws", ws_on) == 0
-            yb, yv = empty_view(n, h, w, co, True, cstride=co + 8, coff=8)
+            yb, yv = empty_view(n, ho, wo, co, True, cstride=co + 8, coff=8)
             L.check(lib.bp_conv_forward(C.byref(cv), C.byref(xv), pwp, L.ptr(pf), L.ptr(wd), None, C.byref(yv),
                                         L.IMPL_BF16, st), "forward")
             got = from_view(yb, co, coff=8)
@@ -278,7 +288,7 @@ def test_weights_stationary_trunk_kernel(shape, act):
             assert torch.isnan(yb.to(torch.float32)[..., :8]).all(), "stores outside the view"
             nb = lib.bp_conv_stats_workspace(C.byref(cv), L.PACK_FWD, C.byref(xv), C.byref(yv), L.IMPL_BF16)
             assert nb > 0
-            yb2, yv2 = empty_view(n, h, w, co, True, cstride=co + 8, coff=8)
+            yb2, yv2 = empty_view(n, ho, wo, co, True, cstride=co + 8, coff=8)
             sums = torch.full((2 * co,), float("nan"), dtype=torch.float64, device="cuda")
             wss = torch.full((nb // 8 + 8,), float("nan"), dtype=torch.float64, device="cuda")
             L.check(lib.bp_conv_forward_stats(C.byref(cv), C.byref(xv), pwp, L.ptr(pf), C.byref(yv2), L.ptr(sums),
@@ -299,7 +309,12 @@ def test_weights_stationary_trunk_kernel(shape, act):
         lib.bp_set_option(b"bf16_ws", -1)
     # the two kernels differ by accumulation order only: a bf16 ulp (2^-8 of the value, at most 2^-7 of the maximum) here and there
     assert G.rel_err(res[1][0], res[0][0]) < 8e-3 and G.rel_err(res[1][1], res[0][1]) < 8e-3
-    assert np.mean(res[1][0] != res[0][0]) < 0.05
+    assert np.mean(res[1][0] != res[0][0]) < 0.05 and np.mean(res[1][1] != res[0][1]) < 0.05
+    # ... and the stationary kernel did run where it should (otherwise the two results are bit-equal)
+    if layer in ("k3", "k4s2"):
+        assert not np.array_equal(res[1][0], res[0][0]), "the forward never reached the weights-stationary kernel"
+    if layer in ("k3", "t4s2"):
+        assert not np.array_equal(res[1][1], res[0][1]), "the data gradient never reached the weights-stationary kernel"
 
 
 @pytest.mark.parametrize("ws_on", [1, 0], ids=["stationary", "tiled"])

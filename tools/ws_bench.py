@@ -9,18 +9,21 @@ from baryon_painter_amd import _lib as L
 
 n, h, w = (int(v) for v in sys.argv[1:4]) if len(sys.argv) > 3 else (64, 64, 64)
 rounds = int(sys.argv[4]) if len(sys.argv) > 4 else 15
+LAYER = os.environ.get("LAYER", "k3")        # k3: 128->128 k3 (h, w = the layer's grid); k4s2 / t4s2: h, w = the COARSE grid
 lib = L.load()
-ci = co = 128
-cv = L.Conv(0, ci, co, 3, 1, 1, 0)
-x = torch.randn((n, h, w, ci), device="cuda").to(torch.bfloat16)
-y = torch.empty((n, h, w, co), device="cuda", dtype=torch.bfloat16)
-dy = torch.randn((n, h, w, co), device="cuda").to(torch.bfloat16)
+tr, ci, co, k, s_, p_ = {"k3": (0, 128, 128, 3, 1, 1), "k4s2": (0, 64, 128, 4, 2, 1), "t4s2": (1, 128, 64, 4, 2, 1)}[LAYER]
+cv = L.Conv(tr, ci, co, k, s_, p_, 0)
+hi, wi = (h, w) if LAYER != "k4s2" else (2 * h, 2 * w)          # module input
+ho, wo = (h, w) if LAYER != "t4s2" else (2 * h, 2 * w)          # module output
+x = torch.randn((n, hi, wi, ci), device="cuda").to(torch.bfloat16)
+y = torch.empty((n, ho, wo, co), device="cuda", dtype=torch.bfloat16)
+dy = torch.randn((n, ho, wo, co), device="cuda").to(torch.bfloat16)
 dx = torch.empty_like(x)
-wt = torch.randn((co, ci, 3, 3), device="cuda") * 0.05
-xv = L.View(x.data_ptr(), n, h, w, ci, ci, 0, L.BF16)
-yv = L.View(y.data_ptr(), n, h, w, co, co, 0, L.BF16)
-dyv = L.View(dy.data_ptr(), n, h, w, co, co, 0, L.BF16)
-dxv = L.View(dx.data_ptr(), n, h, w, ci, ci, 0, L.BF16)
+wt = torch.randn(((ci, co) if tr else (co, ci)) + (k, k), device="cuda") * 0.05
+xv = L.View(x.data_ptr(), n, hi, wi, ci, ci, 0, L.BF16)
+yv = L.View(y.data_ptr(), n, ho, wo, co, co, 0, L.BF16)
+dyv = L.View(dy.data_ptr(), n, ho, wo, co, co, 0, L.BF16)
+dxv = L.View(dx.data_ptr(), n, hi, wi, ci, ci, 0, L.BF16)
 pwk = [torch.rand(ci, device="cuda") + 0.5, torch.rand(ci, device="cuda") - 0.5, torch.zeros(ci, device="cuda")]
 pw = L.Pointwise(*[t.data_ptr() for t in pwk])
 st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -31,7 +34,7 @@ L.check(lib.bp_conv_bf16_pack(C.byref(cv), 1, L.ptr(wt), L.ptr(pb), st))
 nb = max(lib.bp_conv_stats_workspace(C.byref(cv), 0, C.byref(xv), C.byref(yv), L.IMPL_BF16), 8)
 sums = torch.zeros(2 * co, dtype=torch.float64, device="cuda")
 wss = torch.zeros(nb // 8 + 8, dtype=torch.float64, device="cuda")
-flop = 2.0 * n * h * w * 9 * ci * co
+flop = 2.0 * n * h * w * (9 if LAYER == "k3" else 16) * ci * co
 
 legs = {
     "fwd": lambda: lib.bp_conv_forward(C.byref(cv), C.byref(xv), None, L.ptr(pf), L.ptr(wt), None, C.byref(yv), L.IMPL_BF16, st),
@@ -54,7 +57,7 @@ for r in range(rounds + 2):
             if r >= 2:
                 times[(k, o)].append(e0.elapsed_time(e1) * 1e3 / REP)
 lib.bp_set_option(b"bf16_ws", -1)
-print(f"128->128 k3 bf16, batch {n} of {h}x{w}: us per launch incl. its reductions (median / min over {rounds} rounds of {REP})")
+print(f"{LAYER} bf16, batch {n} of {h}x{w}: us per launch incl. its reductions (median / min over {rounds} rounds of {REP})")
 for k in legs:
     a, b = np.array(times[(k, 1)]), np.array(times[(k, 0)])
     print(f"  {k:14s} stationary {np.median(a):7.1f} / {a.min():7.1f} us = {flop/np.median(a)/1e6:7.1f} TF/s ({flop/np.median(a)/1e6/2500:.3f} of 2.5 PF)"
