@@ -242,6 +242,9 @@ def test_backward_chain_layer_by_layer(size, n):
     assert rows[0][0] <= 1.0, rows[:5]
 
 
+TWIN_SEEDS = (1234, 1235, 1236, 1237)
+
+
 @pytest.mark.parametrize("size,n", [(128, 4), (512, 2)])
 def test_bf16_gradients_per_tensor_and_chain_against_rounding_twin(size, n):
     """Throughput mode (CVAE(dtype="bf16"), BASELINE.json configs[3]) held PER TENSOR, on the well-conditioned softened
@@ -253,68 +256,85 @@ def test_bf16_gradients_per_tensor_and_chain_against_rounding_twin(size, n):
     (the 1-channel latent up-sampler's batch-norm parameters are 1000 : 1 cancelling sums: their bf16 gradients are
     30 % - 100 % noise in any execution; a 128-channel trunk weight sits at 1e-2).  So the yardstick is measured, per
     tensor, in the test: the ROUNDING TWIN -- the same float64 graph with a bf16 round-trip wherever the HIP path
-    stores or stages bf16 (TorchRefCVAE(bf16=True)): same noise, same places, no kernels.  Criterion:
-        distance(HIP, truth) <= max(3 x distance(twin, truth), floor)     floor: 5e-3 gradients, 2e-3 chain tensors
-    and the twin must BE a noise model of this path: the median ratio over all tensors within [1/3, 3].  A kernel that is
-    5 % off in one trunk tensor (twin distance 1e-2) fails; the whole-vector cosine this replaces could not see it.
+    stores or stages bf16 (TorchRefCVAE(bf16=True)): same noise, same places, no kernels.  Measured on MI355X the two
+    agree to a few percent layer by layer (d_raw 2.72e-2 vs 2.63e-2, ...), median ratio over the parameters 1.0.
+    Criterion, over four batches (a tensor's distance is ONE draw of its noise; for the one- and two-element batch-norm
+    tensors of the latent path the ratio of two single draws is heavy-tailed, the ratio of two four-draw RMS values is not):
+        rms distance(HIP, truth) <= max(m x rms distance(twin, truth), 5e-3),   m = 2 (>= 64 elements) or 4 (tiny tensors)
+    and for the chain tensors of the first batch  distance(HIP) <= max(3 x distance(twin), 2e-3).  The twin must BE a
+    noise model of this path: the median ratio over all tensors within [1/2, 2].  (measured: HIP / twin <= 1.16 on every tensor.)  A kernel that is 3 % off in one trunk
+    tensor (twin distance 1e-2) fails; the whole-vector cosine this replaces could not see it.
     The step is /root/reference/baryon_painter/painter.py:224-228."""
     from oracle.torch_ref import TorchRefCVAE
     fid = A.fiducial_architecture(512)
     arch = syn.softened_architecture(fid if size == 512 else syn.scaled_architecture(fid, size), SLOPE)
     m, P = _model(arch, soft=True, dtype="bf16")
-    x, y, aux = syn.synthetic_batch(n, size, size, seed=1234)
-    eps = syn.synthetic_eps((1, n, *arch["dim_z"]), seed=99)
-    m._eps_override = eps
     m.train(True)
-    elbo = m(torch.from_numpy(x), torch.from_numpy(y), torch.from_numpy(aux))
-    (-elbo).backward()
-    torch.cuda.synchronize()
-    runs = {}
-    for name, twin in (("truth", False), ("twin", True)):
-        tap = {}
-        r = TorchRefCVAE(arch, P, dtype=torch.float64, tap=tap, bf16=twin)
-        (-r.forward(x, y, aux, eps)).backward()
-        runs[name] = (r, tap)
-    assert abs(float(elbo) - float(runs["truth"][0].ELBO.detach())) <= 2e-3 * abs(float(runs["truth"][0].ELBO.detach()))
 
     def rel(a, b):
         a, b = a.double(), b.double()
         return float((a - b).norm() / b.norm().clamp_min(1e-300))
 
-    # ---- parameter gradients
+    d_hip = {k: [] for k, _ in m.named_parameters()}
+    d_twin = {k: [] for k in d_hip}
+    for it, seed in enumerate(TWIN_SEEDS):
+        x, y, aux = syn.synthetic_batch(n, size, size, seed=seed)
+        eps = syn.synthetic_eps((1, n, *arch["dim_z"]), seed=seed + 99)
+        for p_ in m.parameters():
+            p_.grad = None
+        m._eps_override = eps
+        elbo = m(torch.from_numpy(x), torch.from_numpy(y), torch.from_numpy(aux))
+        (-elbo).backward()
+        torch.cuda.synchronize()
+        runs = {}
+        for name, twin in (("truth", False), ("twin", True)):
+            tap = {}
+            r = TorchRefCVAE(arch, P, dtype=torch.float64, tap=tap, bf16=twin)
+            (-r.forward(x, y, aux, eps)).backward()
+            runs[name] = (r, tap)
+        e64 = float(runs["truth"][0].ELBO.detach())
+        assert abs(float(elbo) - e64) <= 2e-3 * abs(e64)
+        for k, p_ in m.named_parameters():
+            g = p_.grad.detach().cpu()
+            assert torch.isfinite(g).all(), k
+            t, w = runs["truth"][0].P[k].grad, runs["twin"][0].P[k].grad
+            d_hip[k].append(rel(g, t))
+            d_twin[k].append(rel(w, t))
+        if it:
+            continue
+        # ---- the chain, layer by layer (first batch)
+        crow, nb16 = [], 0
+        for u in _conv_units(m._last):
+            t64, tw = runs["truth"][1][u.name + "."], runs["twin"][1][u.name + "."]
+            s = u.out
+            nb16 += s.buf.dtype == torch.bfloat16
+            raw = s.buf[..., s.coff:s.coff + s.c].permute(0, 3, 1, 2).float().cpu()
+            r_hip, r_twin = rel(raw, t64.detach()), rel(tw.detach(), t64.detach())
+            assert r_hip <= max(3 * r_twin, 2e-5), (u.name, r_hip, r_twin)
+            if t64.grad is None:
+                continue
+            g = s.grad_buf[..., s.coff:s.coff + s.c].permute(0, 3, 1, 2).float().cpu()
+            g_hip, g_twin = rel(g, t64.grad), rel(tw.grad, t64.grad)
+            crow.append((g_hip / max(3 * g_twin, 2e-3), g_hip, g_twin, r_hip, r_twin, u.name))
+        crow.sort(reverse=True)
+        print("bf16 chain: d_raw distance / limit, HIP, twin | raw HIP, twin")
+        for r_ in crow:
+            print("  %.3f  %.2e  %.2e | %.2e  %.2e  %s" % r_)
+        assert nb16 >= 15, "the trunk's slots should be bf16"
+        assert len(crow) >= 30 and crow[0][0] <= 1.0, crow[:5]
+
+    # ---- parameter gradients: rms over the batches
+    numel = {k: p_.numel() for k, p_ in m.named_parameters()}
     rows = []
-    for k, p in m.named_parameters():
-        g = p.grad.detach().cpu()
-        assert torch.isfinite(g).all(), k
-        t, w = runs["truth"][0].P[k].grad, runs["twin"][0].P[k].grad
-        d_hip, d_twin = rel(g, t), rel(w, t)
-        rows.append((d_hip / max(3 * d_twin, 5e-3), d_hip, d_twin, k))
+    for k in d_hip:
+        h, t = float(np.sqrt(np.mean(np.square(d_hip[k])))), float(np.sqrt(np.mean(np.square(d_twin[k]))))
+        mult = 2.0 if numel[k] >= 64 else 4.0
+        rows.append((h / max(mult * t, 5e-3), h, t, numel[k], k))
     rows.sort(reverse=True)
-    print("bf16 parameter gradients: distance from float64 / limit, HIP distance, twin distance (worst first)")
+    print("bf16 parameter gradients: rms distance from float64 / limit, HIP, twin, elements (worst first)")
     for r_ in rows[:14]:
-        print("  %.3f  %.2e  %.2e  %s" % r_)
+        print("  %.3f  %.2e  %.2e  %7d  %s" % r_)
     ratios = [r_[1] / r_[2] for r_ in rows if r_[2] > 1e-4]
     print("  median HIP / twin %.2f over %d tensors; median HIP distance %.2e" % (np.median(ratios), len(ratios), np.median([r_[1] for r_ in rows])))
     assert rows[0][0] <= 1.0, rows[:6]
-    assert 1 / 3 <= np.median(ratios) <= 3, np.median(ratios)
-
-    # ---- the chain, layer by layer
-    crow, nb16 = [], 0
-    for u in _conv_units(m._last):
-        t64, tw = runs["truth"][1][u.name + "."], runs["twin"][1][u.name + "."]
-        s = u.out
-        nb16 += s.buf.dtype == torch.bfloat16
-        raw = s.buf[..., s.coff:s.coff + s.c].permute(0, 3, 1, 2).float().cpu()
-        r_hip, r_twin = rel(raw, t64.detach()), rel(tw.detach(), t64.detach())
-        assert r_hip <= max(3 * r_twin, 2e-5), (u.name, r_hip, r_twin)
-        if t64.grad is None:
-            continue
-        g = s.grad_buf[..., s.coff:s.coff + s.c].permute(0, 3, 1, 2).float().cpu()
-        g_hip, g_twin = rel(g, t64.grad), rel(tw.grad, t64.grad)
-        crow.append((g_hip / max(3 * g_twin, 2e-3), g_hip, g_twin, r_hip, r_twin, u.name))
-    crow.sort(reverse=True)
-    print("bf16 chain: d_raw distance / limit, HIP, twin | raw HIP, twin")
-    for r_ in crow:
-        print("  %.3f  %.2e  %.2e | %.2e  %.2e  %s" % r_)
-    assert nb16 >= 15, "the trunk's slots should be bf16"
-    assert len(crow) >= 30 and crow[0][0] <= 1.0, crow[:5]
+    assert 0.5 <= np.median(ratios) <= 2, np.median(ratios)
