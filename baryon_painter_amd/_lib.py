@@ -85,6 +85,13 @@ SIGNATURES = {
     "bp_conv_backward_weight": (C.c_int, [_CP, _VP, _PWP, _VP, _P, _P, _P, C.c_size_t, C.c_int, _P]),
     "bp_wgrad_defer_begin": (C.c_int, []),
     "bp_wgrad_defer_flush": (C.c_int, [C.c_int, _P]),
+    "bp_peer_handle_bytes": (C.c_int, []),
+    "bp_peer_max_doubles": (C.c_int, []),
+    "bp_peer_create": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_void_p), _P]),
+    "bp_peer_open": (C.c_int, [_P, _P]),
+    "bp_peer_all_reduce": (C.c_int, [_P, _P, C.c_int, C.c_int64, _P]),
+    "bp_peer_status": (C.c_int64, [_P]),
+    "bp_peer_destroy": (C.c_int, [_P]),
     "bp_channel_sums_workspace": (C.c_size_t, [_VP]),
     "bp_channel_sums": (C.c_int, [_VP, _P, _P, C.c_size_t, _P]),
     "bp_bn_finalize": (C.c_int, [_P, C.c_double, C.c_int32, _P, _P, C.c_float, C.c_float, _P, _P, _P,

@@ -237,13 +237,18 @@ def _collective_report(sync, step):
         per.setdefault(kind, []).append(e0.elapsed_time(e1) * 1e3)
     stats = {k: {"per_step": len(v) // 2, "ms_per_step": round(sum(v) / 2e3, 3), "min_us": round(min(v), 1),
                  "median_us": round(float(np.median(v)), 1), "max_us": round(max(v), 1)} for k, v in per.items()}
-    return {"collectives_per_step": {"batch_norm_statistics": (sync.n_small - n0) // 2,
-                                     "gradient_buffers": (sync.n_grad - g0) // 2},
+    sync.check()                                  # (a timed-out peer-memory collective would have corrupted the steps)
+    n_grad = (sync.n_grad - g0) // 2
+    return {"collectives_per_step": {"batch_norm_statistics": (sync.n_small - n0) // 2, "gradient_buffers": n_grad},
             "gradient_bytes_per_step": (sync.bytes_grad - b0) // 2,
             "inside_collectives": stats,
+            # (what RAN, from the count of gradient collectives: BP_GRAD_COMM=1 alone selects a second communicator but
+            #  not the early schedule)
             "gradient_all_reduce": "generator trunk + heads (97 % of the bytes) early on the weight-gradient stream, own "
                                    "communicator (BP_EARLY_ALLREDUCE=1); the rest after the backward pass"
-                                   if sync.overlap else "one flat buffer after the backward pass",
+                                   if n_grad > 1 else "one flat buffer after the backward pass",
+            "statistics_transport": "one kernel per collective over IPC-mapped peer memory (csrc/peer_comm.hip)"
+                                    if getattr(sync, "peer", None) is not None else "process group",
             "backend": torch.distributed.get_backend()}
 
 

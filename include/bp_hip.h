@@ -405,6 +405,24 @@ int bp_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg
 int bp_adam_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                      const float* hyper, void* stream);
 
+/* ---- data parallel: small-message all-reduce over peer memory (csrc/peer_comm.hip) --------------------------
+ * The reference is single-device; sharding its minibatch keeps its arithmetic only if every BatchNorm2d sees the
+ * statistics of the GLOBAL batch (painter.py:224 feeds the whole minibatch through the module): 44 dependent all-reduces
+ * of <= 2 KB per step.  One process per GPU; each rank calls bp_peer_create (allocates its fine-grained exchange buffer,
+ * returns an opaque communicator and an IPC handle of bp_peer_handle_bytes() bytes), the host exchanges the handles
+ * (any transport: torch.distributed all_gather), each rank passes the world_size handles, in rank order, to bp_peer_open.
+ * bp_peer_all_reduce then sums `n` (<= bp_peer_max_doubles()) doubles in place over the ranks with ONE kernel on `stream`:
+ * peer stores over xGMI, per-rank flags, a fixed rank-order sum (bitwise the same result on every rank).  Every rank must
+ * issue the same sequence of calls.  Spins are bounded (`spin_limit` polls, <= 0: default): a timeout is counted in the
+ * communicator's status word (bp_peer_status, synchronising) and the call's result is then undefined. */
+int bp_peer_handle_bytes(void);
+int bp_peer_max_doubles(void);
+int bp_peer_create(int rank, int world, void** comm_out, void* handle_out);
+int bp_peer_open(void* comm, const void* handles);
+int bp_peer_all_reduce(void* comm, double* data, int n, int64_t spin_limit, void* stream);
+int64_t bp_peer_status(void* comm);
+int bp_peer_destroy(void* comm);
+
 #ifdef __cplusplus
 }
 #endif

@@ -109,6 +109,9 @@ if early == "1":
     os.environ["BP_EARLY_ALLREDUCE"] = "1"
 dp, e_dp = run(sync, slice(r * h, (r + 1) * h))
 assert sync.n_grad == (3 if early == "1" else 1), sync.n_grad
+# the batch-norm statistics travelled through the peer-memory kernel (csrc/peer_comm.hip), not the process group
+assert sync.peer is not None and sync.peer.world == w, "peer-memory all-reduce was not set up"
+sync.check()
 t = torch.tensor([e_dp], dtype=torch.float64, device=dev if backend == "nccl" else "cpu"); dist.all_reduce(t); e_mean = t.item() / w
 if r == 0:
     ref, e_ref = run(None, slice(0, n))
@@ -199,6 +202,8 @@ for early in ("0", "1"):
     assert sync.active and sync.overlap == (early == "1") and (sync.grad_group is not sync.group) == (early == "1")
     dp, e_dp = run(sync)
     assert sync.n_small == 44 and sync.n_grad == (3 if early == "1" else 1), (sync.n_small, sync.n_grad)
+    assert (sync.peer is not None) == (os.environ.get("BP_PEER_SYNC", "1") != "0")
+    sync.check()
     assert abs(e_dp - e_ref) <= 1e-6 * abs(e_ref), (e_dp, e_ref)
     for (k, a), (_, b) in zip(dp.named_parameters(), ref.named_parameters()):
         worst = max(worst, float((a.grad.double() - b.grad.double()).abs().max() / b.grad.double().abs().max().clamp_min(1e-30)))
@@ -224,6 +229,61 @@ def test_data_parallel_schedule_through_rccl_with_one_rank(tmp_path):
                          timeout=600)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
     assert (tmp_path / "rccl.ok").exists()
+
+
+_PEER_WORKER = r"""
+import os, sys, time
+sys.path.insert(0, sys.argv[1])
+import numpy as np, torch, torch.distributed as dist
+from baryon_painter_amd.dist import PeerAllReduce
+torch.cuda.set_device(0)
+dist.init_process_group("gloo")
+r, w = dist.get_rank(), dist.get_world_size()
+peer = PeerAllReduce.create(None, torch.device("cuda:0"))
+assert peer is not None, "the peer-memory path did not come up"
+rng = np.random.default_rng(100 + r)
+worst = 0
+for it in range(400):
+    n = int(np.random.default_rng(it).integers(1, peer.max_doubles + 1))       # the same length on every rank
+    mine = torch.from_numpy(rng.standard_normal(n))
+    want = mine.clone()
+    dist.all_reduce(want)                                                       # gloo, on the host
+    t = mine.cuda()
+    if (it + r) % 7 == 0:
+        time.sleep(0.002 * (1 + r))                                             # uneven arrival
+    peer.all_reduce_sum(t)
+    got = t.cpu()
+    # rank-order sum on the device vs gloo's order: equal to rounding; and bitwise equal across ranks
+    assert torch.allclose(got, want, rtol=1e-13, atol=1e-13), (it, n)
+    ref = got.clone()
+    dist.broadcast(ref, 0)
+    assert torch.equal(got, ref), ("ranks disagree", it)
+assert peer.timeouts() == 0
+if r == 0:
+    open(os.path.join(sys.argv[2], "peer.ok"), "w").write("ok")
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_peer_memory_all_reduce_between_processes(tmp_path, world):
+    """csrc/peer_comm.hip between `world` processes that share this GPU (IPC-mapped fine-grained buffers, system-scope
+    stores / flags / loads): 400 all-reduces of random lengths with ranks arriving unevenly -- the sums equal gloo's to
+    rounding and are BITWISE equal on every rank (fixed rank-order sum), no spin ever times out.  What this cannot show
+    on a one-GPU box is the xGMI hop itself; the protocol, the ring of slots and the IPC mapping are the same."""
+    import socket
+    script = tmp_path / "peer_worker.py"
+    script.write_text(_PEER_WORKER)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), str(script), ROOT, str(tmp_path)],
+                         capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    assert (tmp_path / "peer.ok").exists()
 
 
 def test_graphed_paint_matches_eager_statistics():

@@ -10,7 +10,7 @@ show() { python -c "
 import sys, json
 d = json.loads(sys.stdin.read().strip().splitlines()[-1])
 c = d['config']
-print('$1', d['value'], 'tiles/s', d['ms_per_step'], 'ms/step', json.dumps({k: c.get(k) for k in ('batch_norm', 'collectives_per_step', 'gradient_bytes_per_step', 'inside_collectives', 'gradient_all_reduce', 'backend')}))"; }
+print('$1', d['value'], 'tiles/s', d['ms_per_step'], 'ms/step', json.dumps({k: c.get(k) for k in ("batch_norm", "collectives_per_step", "gradient_bytes_per_step", "inside_collectives", "gradient_all_reduce", "statistics_transport", "backend")}))"; }
 A="--legs none --steps 8 --warmup 3 --no-cpu-baseline --no-paint"
 python bench.py $A 2>gpurun_out/rccl1.err | show "cvae f32 parity-mode"
 BP_EARLY_ALLREDUCE=1 python bench.py $A 2>>gpurun_out/rccl1.err | show "cvae f32 early-allreduce"
