@@ -10,6 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libbp_hip.so")
 
 BP_OK = 0
+BP_EINVAL, BP_EUNSUPPORTED, BP_ELAUNCH, BP_EWORKSPACE = -1, -2, -3, -4
 IMPL_AUTO, IMPL_DIRECT, IMPL_MFMA, IMPL_BF16 = 0, 1, 2, 3
 IMPL_SHARED = 0x100
 IMPL_DEFER = 0x200

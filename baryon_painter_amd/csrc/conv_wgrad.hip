@@ -314,6 +314,9 @@ int bp_wgrad_defer_begin_impl() {
 
 int bp_wgrad_defer_flush_impl(hipStream_t st, int end) {
   int rc = BP_OK;
+  // (the state is per host thread: a flush from another thread than the one that called bp_wgrad_defer_begin would find
+  //  an empty list, report success and leave every deferred dW unreduced -- refuse it instead)
+  if (end >= 0 && !t_defer.on) return BP_EINVAL;
   if (end < 0) t_defer.jobs.clear();          // abandon
   if (!t_defer.jobs.empty()) {
     rc = wgrad_reduce_flush_class<16>(t_defer.jobs, true, st);

@@ -77,16 +77,15 @@ def paint_plane(painter, delta, tile_relative_size, n_pixel_tile, z, min_tile_ov
                 t = scipy.ndimage.zoom(t, zoom=n_pixel_tile / t.shape[0], mode="reflect")
             tiles.append(np.asarray(t, dtype=np.float32))
     painted = None
-    if hasattr(painter, "paint_stream"):
+    # eligibility is decided UP FRONT (no capture attempted, no random number consumed): an error raised later, deep
+    # inside the device pipeline, then propagates instead of silently selecting the slow host path
+    if hasattr(painter, "paint_stream") and getattr(painter, "can_paint_stream", lambda z=0.0: True)(z):
         if seed is None:
             import torch
             seed = int(torch.randint(0, 2 ** 62, (1,)).item())
         ids = first_tile_id + np.arange(len(tiles), dtype=np.int64)
-        try:
-            painted = painter.paint_stream(np.stack(tiles), z, batch_size=min(batch_size, len(tiles)), tile_ids=ids,
-                                           seed=seed)
-        except NotImplementedError:
-            painted = None                   # no device form of this painter's transform / architecture
+        painted = painter.paint_stream(np.stack(tiles), z, batch_size=min(batch_size, len(tiles)), tile_ids=ids,
+                                       seed=seed)
     if painted is None:
         painted = painter.paint_batch(np.stack(tiles), z, batch_size=batch_size)
     plane = np.zeros((n_plane, n_plane))

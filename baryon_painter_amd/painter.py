@@ -352,6 +352,26 @@ class CVAEPainter(Painter):
         s_out = np.sqrt(T.interpolate_z_many(st_out, zs, "var"))
         return s_in, k_in, k_out, s_out
 
+    def can_paint_stream(self, z=0.0):
+        """Whether ``paint_stream`` has a device form for this painter (single-channel tiles, one label field, the
+        'shift-log' range compression on both sides, L = 1 and a prior network) -- WITHOUT side effects: nothing is
+        captured, no random number is drawn.  ``lightcone.paint_plane`` asks this before it draws a plane's seed, so that
+        a NotImplementedError raised later, from inside a capture, is an error and not a silent fall-back."""
+        model = self.model
+        if model.dim_y[0] != 1 or getattr(model, "L", 1) != 1 or getattr(model, "prior_network", None) is None:
+            return False
+        try:
+            self._shift_log_parameters(np.atleast_1d(np.asarray(z, dtype=np.float64))[:1])
+        except NotImplementedError:
+            return False
+        return True
+
+    def release_paint_buffers(self):
+        """Free the page-locked host staging buffers ``paint_stream`` keeps between calls: two parameter blocks plus up to
+        four (batch, 1, H, W) fp32 buffers -- 256 MiB of pinned memory at batch 64 of 512^2 tiles -- which otherwise live
+        as long as the painter (page-locking them costs tens of milliseconds per call, hence the cache)."""
+        self.__dict__.pop("_paint_host_buffers", None)
+
     def paint_stream(self, inputs, z, batch_size=64, tile_ids=None, seed=0, rank=0, world_size=1, out=None):
         """Paint MANY raw tiles: ``inputs`` (N, H, W) float32 host array (NumPy, memory map, or a pinned torch tensor),
         redshifts ``z`` (scalar or (N,)) -> (N, H, W) float32 physical tiles.  The production form of ``paint``
@@ -391,7 +411,8 @@ class CVAEPainter(Painter):
         # Two slots = the graph's own two buffer sets (CVAE.paint_graph): uploads land where bp_paint_load reads,
         # downloads leave from where bp_paint_store writes.  Per slot one pinned parameter block (one copy per batch).
         layout = g["block_layout"]
-        # pinned host buffers are kept between calls (page-locking 4 x 64 MiB costs tens of milliseconds per call)
+        # pinned host buffers are kept between calls (page-locking 4 x 64 MiB costs tens of milliseconds per call);
+        # release_paint_buffers() frees them; the tile buffers are only allocated for NumPy inputs / outputs
         cache = self.__dict__.setdefault("_paint_host_buffers", {})
         key = (B, H, W, g["block_bytes"], str(dev))
         if key not in cache:

@@ -659,6 +659,12 @@ def main():
         except Exception as e:                      # a secondary leg must not cost the headline
             import traceback
             traceback.print_exc()
+            if world > 1:
+                # ... but under N > 1 the other ranks are inside this leg's collectives and would wait for this rank for
+                # ever: leave loudly instead (the launcher then ends every rank; a hang would outlive the driver's clock)
+                sys.stderr.write(f"rank {rank}: secondary leg '{name}' failed under world size {world}: aborting all ranks\n")
+                sys.stderr.flush()
+                os._exit(3)
             extra[name] = {"error": f"{type(e).__name__}: {e}"}
             _free()
 

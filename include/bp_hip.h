@@ -202,7 +202,9 @@ int bp_conv_backward_weight(const bp_conv* cv, const bp_view* x, const bp_pointw
  * flagged call its own workspace until the flush, and flush on the stream (or behind the streams) the calls ran on.
  * Measured on the fiducial step: -0.3 ms for the fp32 layers (28-way splits, partial sums of 0.6 ... 16 MB); the
  * 128 ... 512-way splits of the bf16 kernels are better reduced at once, while their partial sums are still in L2.
- * end = 0 flushes and keeps deferring; end < 0 drops what was recorded and stops (error paths).  (Replaces nothing in the reference: torch's autograd launches one cuDNN
+ * end = 0 flushes and keeps deferring; end < 0 drops what was recorded and stops (error paths).  The recorded state is
+ * per host thread: a flush (end >= 0) on a thread without an active bp_wgrad_defer_begin returns BP_EINVAL instead of
+ * silently leaving the deferred gradients unreduced.  (Replaces nothing in the reference: torch's autograd launches one cuDNN
  * weight-gradient kernel per layer, cvae.py:392 loss.backward().) */
 int bp_wgrad_defer_begin(void);
 int bp_wgrad_defer_flush(int end, void* stream);
