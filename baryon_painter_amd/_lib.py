@@ -64,6 +64,7 @@ _CP = C.POINTER(Conv)
 SIGNATURES = {
     "bp_version": (C.c_int, []),
     "bp_set_option": (C.c_int, [C.c_char_p, C.c_int]),
+    "bp_conv_ws_kind": (C.c_int, [_CP, C.c_int, _VP, _VP]),
     "bp_strerror": (C.c_char_p, [C.c_int]),
     "bp_conv_packed_floats": (C.c_int64, [_CP, C.c_int]),
     "bp_conv_kernel_id": (C.c_int, [_CP, C.c_int]),

@@ -33,7 +33,11 @@ size_t bp_wgrad_bf16_workspace(const bp_conv* cv, const bp_view* X, const bp_vie
 int bp_wgrad_bf16_run(const bp_conv* cv, const bp_view* X, const PW& pwx, const bp_view* Y, const PW& pwy, float* dst,
                       void* workspace, size_t workspace_bytes, hipStream_t st);
 
+void bp_f32_ws_set(int v);        // conv_ws_f32.hip
+bool bp_f32_ws_ok(const ConvGeom& g, const bp_view* in, const bp_view* out, const float* bias, int stats_mode);
 void bp_bf16_ws_set(int v);       // conv_bf16_ws.hip
+int bp_bf16_ws_kind(const ConvGeom& g);
+bool bp_bf16_ws_ok(const ConvGeom& g, const bp_view* in, const bp_view* out, const float* bias, int mode);
 
 namespace {
 
@@ -69,6 +73,7 @@ int bp_version(void) { return 100; }
 int bp_set_option(const char* name, int value) {
   if (!name) return BP_EINVAL;
   if (!strcmp(name, "bf16_ws")) { bp_bf16_ws_set(value); return BP_OK; }
+  if (!strcmp(name, "f32_ws")) { bp_f32_ws_set(value); return BP_OK; }
   return BP_EUNSUPPORTED;
 }
 
@@ -124,6 +129,13 @@ int bp_conv_bf16_pack(const bp_conv* cv, int dir, const float* w_torch, void* pa
   if (!conv_ok(cv) || !w_torch || !packed || (dir != BP_PACK_FWD && dir != BP_PACK_BWD)) return BP_EINVAL;
   const ConvGeom g = dir == BP_PACK_FWD ? bp_geom_forward(cv) : bp_geom_backward_data(cv);
   return bp_bf16_pack(g, bp_wmap(cv, dir), w_torch, packed, bp_stream(stream));
+}
+
+int bp_conv_ws_kind(const bp_conv* cv, int dir, const bp_view* in, const bp_view* out) {
+  if (!conv_ok(cv) || (dir != BP_PACK_FWD && dir != BP_PACK_BWD) || !bp_view_ok_any(in) || !bp_view_ok_any(out)) return 0;
+  const ConvGeom g = dir == BP_PACK_FWD ? bp_geom_forward(cv) : bp_geom_backward_data(cv);
+  if (in->dtype == BP_F32 && out->dtype == BP_F32) return bp_f32_ws_ok(g, in, out, nullptr, 0) ? 3 : 0;
+  return bp_bf16_ws_ok(g, in, out, nullptr, 0) ? bp_bf16_ws_kind(g) : 0;
 }
 
 int bp_conv_bf16_supported(const bp_conv* cv, int dir, const bp_view* in, const bp_view* out) {

@@ -1684,7 +1684,21 @@ int bp_stats_rows_finish(double* ws, int64_t rows, int C, const IgemmStatsReq* s
   return stats_finish(p, ws, sr, st);
 }
 
+// conv_ws_f32.hip: weights-stationary kernel of the 128 -> 128 k3 trunk layers (reads the tiled image packed above)
+bool bp_f32_ws_ok(const ConvGeom& g, const bp_view* in, const bp_view* out, const float* bias, int stats_mode);
+size_t bp_f32_ws_stats_workspace(const ConvGeom& g, const bp_view* out);
+int bp_f32_ws_run(const ConvGeom& g, const bp_view* in, const PW& pw, const float* packed_tiled, const bp_view* out,
+                  hipStream_t st, const IgemmStatsReq* sr);
+
 size_t bp_igemm_stats_workspace(const ConvGeom& g, const bp_view* in, const bp_view* out, int mode) {
+  if (bp_f32_ws_ok(g, in, out, nullptr, mode)) {        // (the larger of the two: bp_set_option may switch kernels later)
+    const IgemmConfig c = igemm_config(g);
+    IgemmLaunch l;
+    StatsPlan p;
+    const size_t tiled = (c.ok && igemm_launch_of(g, c, in, out, l) && stats_plan(g, c, l, p)) ? p.bytes : 0;
+    const size_t ws = bp_f32_ws_stats_workspace(g, out);
+    return ws > tiled ? ws : tiled;
+  }
   if (bp_enc_ok(g)) return bp_enc_stats_workspace(g, in, out, mode);
   if (bp_stem_ok(g)) return mode == 1 ? bp_stem_stats_workspace(out) : 0;
   if (bp_flat_ok(g)) return bp_flat_stats_workspace(out, mode);
@@ -1714,6 +1728,8 @@ int bp_igemm_run(const ConvGeom& g, const bp_view* in, const PW& pw, const float
   if (bp_small_ok(g)) return bp_small_run(g, in, pw, packed, bias, out, st, sr);
   const IgemmConfig c = igemm_config(g);
   if (!c.ok) return BP_EUNSUPPORTED;
+  if (c.CC == 16 && c.PP == 1 && c.cout_padP == 128 && bp_f32_ws_ok(g, in, out, bias, sr ? sr->mode : 0))
+    return bp_f32_ws_run(g, in, pw, packed, out, st, sr);
   IgemmLaunch l;
   if (!igemm_launch_of(g, c, in, out, l)) return BP_EUNSUPPORTED;
   IgemmArgs a{};

@@ -23,6 +23,7 @@ Timing: W untimed warm-up steps, then exactly K steps between barrier + synchron
 """
 import argparse
 import json
+import re
 import os
 import sys
 import time
@@ -63,8 +64,18 @@ def kernel_name(kind, unit, lib):
     if getattr(unit, "bf16", False):
         cv = unit.cv
         tag = "%s%d->%d k%ds%d" % ("T" if cv.transposed else "C", cv.cin, cv.cout, cv.k, cv.stride)
-        return ("wgrad_bf16_kernel[%s]" if kind == "backward_weight" else
-                "igemm_bf16_kernel[%s fwd]" if kind == "forward" else "igemm_bf16_kernel[%s dgrad]") % tag
+        if kind == "backward_weight":
+            return "wgrad_bf16_kernel[%s]" % tag
+        # the weights-stationary kernels (csrc/conv_bf16_ws.hip) serve a layer's forward AND data gradient with one
+        # instance family: one label, so that the dominant kernel is picked by instance, not by direction
+        fwd = kind == "forward"
+        vin = unit.inp.view if fwd else unit.out.grad
+        vout = unit.out.view if fwd else unit.dx
+        ws = lib.bp_conv_ws_kind(C.byref(cv), L.PACK_FWD if fwd else L.PACK_BWD, C.byref(vin), C.byref(vout)) \
+            if vin is not None and vout is not None else 0
+        if ws:
+            return "ws%d_bf16_kernel[%s]" % (ws, tag)
+        return ("igemm_bf16_kernel[%s fwd]" if fwd else "igemm_bf16_kernel[%s dgrad]") % tag
     if kind == "backward_weight":
         cv = unit.cv
         cx, cy = (cv.cout, cv.cin) if cv.transposed else (cv.cin, cv.cout)
@@ -207,21 +218,29 @@ def _free():
     torch.cuda.empty_cache()
 
 
-def _traffic(kernel):
-    """HBM bytes per launch from the PMC passes (rocprofv3 cannot run inside bench.py); only quoted when the stamp says
-    the counters were collected on these very kernel sources."""
+def _pmc_leg(dtype):
+    """This dtype's leg of profiles/pmc_traffic.json (tools/pmc_to_json.py: per kernel instance and launch shape, per
+    step) -- only when the stamp says the counters were collected on these very kernel sources."""
     try:
         pj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
         if pj.get("source_hash") == source_hash():
-            tab = pj["hbm_bytes_per_launch"]
-            if kernel in tab:
-                return tab[kernel]
-            # (streaming passes: the counter file names the template instances, bench.py the family)
-            inst = [v for k, v in tab.items() if k.startswith(kernel + "<")]
-            return int(sum(inst) / len(inst)) if inst else None
+            return pj.get("legs", {}).get(dtype)
     except Exception:
         pass
     return None
+
+
+def _traffic(kernel, dtype):
+    """HBM bytes per launch of the kernel bench.py labels `kernel`, from the PMC passes of the SAME dtype's step
+    (rocprofv3 cannot run inside bench.py); launch-weighted over the launch shapes the label covers."""
+    leg = _pmc_leg(dtype)
+    if leg is None:
+        return None
+    tab = leg["by_label"]
+    if kernel in tab:
+        return tab[kernel]["hbm_bytes_per_launch"]
+    fam = re.sub(r"[<\[].*", "", kernel)          # (streaming passes: the counter file names the family)
+    return tab[fam]["hbm_bytes_per_launch"] if fam in tab else None
 
 
 def _collective_report(sync, step):
@@ -346,12 +365,12 @@ def cvae_leg(args, dtype, dev, world, rank, sync, steps, warmup, paint=True):
     mfma_peak = PEAK_BF16_MFMA_TFLOPS if "bf16" in dom else PEAK_FP32_MFMA_TFLOPS
     if hbm:
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(gbs_dom, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                    "frac": round(gbs_dom / PEAK_HBM_GBS, 4), "traffic": _traffic(dom),
+                    "frac": round(gbs_dom / PEAK_HBM_GBS, 4), "traffic": _traffic(dom, dtype),
                     "algorithmic_bytes_per_launch": d["bytes"] / d["launches"],
                     "mfma_tflops": round(tflops_dom, 1), "mfma_frac": round(tflops_dom / mfma_peak, 4)}
     else:
         roofline = {"bound": "mfma", "kernel": dom, "achieved": round(tflops_dom, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(tflops_dom / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": _traffic(dom),
+                    "unit": "TFLOP/s", "frac": round(tflops_dom / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": _traffic(dom, dtype),
                     "flop_per_launch": d["flop"] / d["launches"],
                     "algorithmic_bytes_per_launch": d["bytes"] / d["launches"]}
     all_bytes = sum(v["bytes"] for v in per.values()) / PROF_STEPS
@@ -365,7 +384,10 @@ def cvae_leg(args, dtype, dev, world, rank, sync, steps, warmup, paint=True):
         "measured_on": f"{PROF_STEPS} steps of the serial schedule run right after the timed region (there weight "
                        "gradients overlap the backward chain on a second stream: per-launch times are not kernel times)",
         "serial_kernels_ms_per_step": round(serial_ms, 2), "conv_kernels_ms_per_step": round(conv_ms, 2),
-        "whole_step": {"tflops": round(step_flop / step_s / 1e12, 1),
+        # Sigma of the counter-derived HBM bytes of ONE step of this dtype (every dispatch) over the survey's fused-ideal bytes
+        "whole_step": {"traffic_bytes": (_pmc_leg(dtype) or {}).get("step_bytes"),
+                       "traffic_ratio": (round(_pmc_leg(dtype)["step_bytes"] / step_bytes, 3) if _pmc_leg(dtype) else None),
+                       "tflops": round(step_flop / step_s / 1e12, 1),
                        "mfma_frac": round(step_flop / step_s / 1e12 / (PEAK_BF16_MFMA_TFLOPS if hbm else PEAK_FP32_MFMA_TFLOPS), 4),
                        "algorithmic_GBs": round(step_bytes / step_s / 1e9, 1),
                        "hbm_frac": round(step_bytes / step_s / 1e9 / PEAK_HBM_GBS, 4),
@@ -597,8 +619,10 @@ def main():
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
                     help="headline arithmetic. f32: the reference's (configs[1]); bf16: bf16 activations / gradients "
                          "in the generator trunk, fp32 accumulation, master weights and statistics (configs[3])")
-    ap.add_argument("--workload", choices=["cvae", "cgan"], default="cvae",
-                    help="headline workload. cvae: BASELINE.json configs[1]; cgan: configs[2] (alternating D/G step)")
+    ap.add_argument("--workload", choices=["cvae", "cgan", "paint"], default="cvae",
+                    help="headline workload. cvae: BASELINE.json configs[1]; cgan: configs[2] (alternating D/G step); "
+                         "paint: configs[4] per GPU alone (paint_stream on a freshly built model: no training kernel runs -- "
+                         "what tools/prof_paint.sh profiles)")
     ap.add_argument("--legs", default=None,
                     help="comma list of secondary legs beside the headline: bf16,cgan (default: bf16,cgan on one GPU, "
                          "bf16 on several; 'none' for the headline alone)")
@@ -643,6 +667,24 @@ def main():
         legs = [s for s in args.legs.split(",") if s and s != "none"]
     t_start = time.time()
 
+    if args.workload == "paint":
+        import contextlib
+        from baryon_painter_amd.models import arch as A
+        from baryon_painter_amd.models.cvae import CVAE
+        torch.manual_seed(1234)
+        with contextlib.redirect_stdout(sys.stderr):
+            model = CVAE(A.fiducial_architecture(args.tile), dev, sync=None, dtype=args.dtype)
+        leg = _paint_leg(args, model, args.dtype, dev, world, rank, args.batch)
+        if rank == 0:
+            leg.update({"n_gpus": world, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
+                        "data": "synthetic",
+                        "config": {"workload": f"paint_stream, {args.paint_tiles} raw {args.tile}x{args.tile} tiles per GPU through "
+                                               "the CVAE fiducial prior + generator (random-init weights), batch "
+                                               f"{min(args.batch, 64)}, host tile in -> host tile out"}})
+            print(json.dumps(leg), flush=True)
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            torch.distributed.destroy_process_group()
+        return
     if args.workload == "cgan":
         head = cgan_leg(args, dev, world, rank, sync, args.steps, args.warmup)
         legs = []

@@ -79,8 +79,9 @@ enum { BP_PACK_FWD = 0, BP_PACK_BWD = 1 };
 /* ---- library ------------------------------------------------------------------------------ */
 int bp_version(void);
 /* Kernel-selection switches for A/B measurements and tests inside ONE process (the environment variables of the same
- * names are read once, at the first call).  "bf16_ws": 1 / 0 = use / do not use the weights-stationary kernel for the
- * 128 -> 128 k3 bf16 trunk layers (csrc/conv_bf16_ws.hip), -1 = back to the environment's choice (BP_BF16_WS).
+ * names are read once, at the first call).  "bf16_ws" / "f32_ws": 1 / 0 = use / do not use the weights-stationary kernels
+ * (csrc/conv_bf16_ws.hip: bf16 128 -> 128 k3 and 64 -> 128 k4 s2; csrc/conv_ws_f32.hip: fp32 128 -> 128 k3), -1 = back to the
+ * environment's choice (BP_BF16_WS / BP_F32_WS).
  * Not thread-safe against concurrent launches; results of either kernel meet the same tolerances.
  * Returns BP_EUNSUPPORTED for an unknown name. */
 int bp_set_option(const char* name, int value);
@@ -124,6 +125,11 @@ int bp_conv_pack_jobs(const void* jobs_dev, const int64_t* first_block_dev, int3
  * flattened-K weight image behind the generic one (csrc/conv_bf16_flat.hip), and the run picks the kernel by the
  * views it is given -- always size the buffer with bp_conv_bf16_packed_elems. */
 int64_t bp_conv_bf16_packed_elems(const bp_conv* cv, int dir);
+/* Which weights-stationary kernel serves this layer / direction with these views (`in` = the gathered tensor of the
+ * direction: x for BP_PACK_FWD, dy for BP_PACK_BWD; `out` = the produced one): 3 = the k3 s1 128 -> 128 trunk kernel (bf16
+ * views: csrc/conv_bf16_ws.hip; fp32 views: csrc/conv_ws_f32.hip), 4 = the bf16 strided gather k4 s2 64 -> 128, 0 = none
+ * (the tiled / flattened-K kernels).  For profiles and bench.py's kernel labels; follows bp_set_option. */
+int bp_conv_ws_kind(const bp_conv* cv, int dir, const bp_view* in, const bp_view* out);
 int bp_conv_bf16_pack(const bp_conv* cv, int dir, const float* w_torch, void* packed, void* stream);
 int bp_conv_bf16_supported(const bp_conv* cv, int dir, const bp_view* in, const bp_view* out);
 

@@ -53,30 +53,31 @@ def test_model_gradients_equal_with_and_without_deferral():
 
 
 def test_more_deferred_jobs_than_one_batch_launch_takes():
-    """97 flagged calls (the batch kernel takes 40 jobs per launch) on one layer shape with different data: each dW equals
+    """97 flagged calls (the batch kernel takes 40 jobs per launch) on the trunk layer's shape with different data: each dW equals
     the dW of the same call without deferral, bit for bit; nothing is reduced before the flush."""
     lib = L.load()
     st = G.stream()
-    cv = L.Conv(0, 16, 32, 4, 2, 1, 0)
-    n, h, w = 2, 24, 40
-    ho, wo = h // 2, w // 2
+    cv = L.Conv(0, 128, 128, 3, 1, 1, 0)          # the trunk layer: tap-blocked kernel + wgrad_reduce (the deferrable path)
+    ci, co, k = 128, 128, 3
+    n, h, w = 1, 10, 12
+    ho, wo = h, w
     rng = np.random.default_rng(3)
     njob = 97
-    xs = [G.to_nhwc(rng.standard_normal((n, 16, h, w)).astype(np.float32)) for _ in range(3)]
-    dys = [G.to_nhwc(rng.standard_normal((n, 32, ho, wo)).astype(np.float32)) for _ in range(3)]
+    xs = [G.to_nhwc(rng.standard_normal((n, ci, h, w)).astype(np.float32)) for _ in range(3)]
+    dys = [G.to_nhwc(rng.standard_normal((n, co, ho, wo)).astype(np.float32)) for _ in range(3)]
     nb = lib.bp_conv_backward_weight_workspace(C.byref(cv), C.byref(xs[0][1]), C.byref(dys[0][1]))
     assert nb > 0
     want = {}
     ws0 = torch.zeros(nb // 8 + 8, dtype=torch.float64, device="cuda")
     for i in range(3):
         for j in range(3):
-            dw = torch.full((32, 16, 4, 4), float("nan"), device="cuda")
+            dw = torch.full((co, ci, k, k), float("nan"), device="cuda")
             L.check(lib.bp_conv_backward_weight(C.byref(cv), C.byref(xs[i][1]), None, C.byref(dys[j][1]), L.ptr(dw), None,
                                                 L.ptr(ws0), ws0.numel() * 8, L.IMPL_MFMA, st))
             want[(i, j)] = dw
     torch.cuda.synchronize()
     wss = [torch.zeros(nb // 8 + 8, dtype=torch.float64, device="cuda") for _ in range(njob)]
-    dws = [torch.full((32, 16, 4, 4), float("nan"), device="cuda") for _ in range(njob)]
+    dws = [torch.full((co, ci, k, k), float("nan"), device="cuda") for _ in range(njob)]
     assert lib.bp_wgrad_defer_begin() == 0
     for q in range(njob):
         i, j = q % 3, (q // 3) % 3

@@ -606,3 +606,89 @@ def test_auto_takes_the_direct_kernel_for_views_the_register_resident_kernels_re
     assert lib.bp_conv_forward(C.byref(cv), C.byref(xv), None, L.ptr(pf), L.ptr(wd), None, C.byref(yv), L.IMPL_MFMA, st) == -2
     L.check(lib.bp_conv_forward(C.byref(cv), C.byref(xv), None, L.ptr(pf), L.ptr(wd), None, C.byref(yv), L.IMPL_AUTO, st))
     assert G.rel_err(G.from_nhwc(yb, co, coff=1), y_ref) < 2e-5
+
+
+# ---- the weights-stationary fp32 kernel of the 128 -> 128 k3 trunk (csrc/conv_ws_f32.hip) against the tiled kernel
+@pytest.mark.parametrize("act", ["none", "relu", "leaky"])
+@pytest.mark.parametrize("shape", [(2, 9, 16), (3, 20, 32), (2, 64, 64), (70, 8, 16)], ids=lambda s: "%dx%dx%d" % s)
+def test_weights_stationary_fp32_trunk_kernel(shape, act):
+    """Forward (+ the batch-norm sums from the epilogue) and data gradient of Conv2d(128, 128, 3, 1, 1) through both fp32
+    kernels (bp_set_option("f32_ws", 1 / 0)): each within 2e-5 of the float64 convolution, the sums within 1e-10 of the sum of
+    magnitudes of the tensor as stored; views that are channel slices of wider buffers; a NaN activation reaches its
+    3 x 3 footprint through the fused batch-norm + ReLU staging (torch.relu(NaN) is NaN)."""
+    lib = L.load()
+    n, h, w = shape
+    ci = co = 128
+    rng = np.random.default_rng(n * 100 + h + w)
+    x = rng.standard_normal((n, ci, h, w)).astype(np.float32)
+    wt = (rng.standard_normal((co, ci, 3, 3)) * 0.05).astype(np.float32)
+    scale = rng.uniform(0.5, 1.5, ci).astype(np.float32)
+    shift = rng.uniform(0.2, 0.6, ci).astype(np.float32)
+    slope = rng.uniform(0.0, 0.3, ci).astype(np.float32)
+    if act == "relu":
+        slope[:] = 0.0
+    if act == "none":
+        xa = x.astype(np.float64)
+    else:
+        t = x * scale[None, :, None, None] + shift[None, :, None, None]
+        xa = np.where(t > 0, t, t * slope[None, :, None, None]).astype(np.float64)
+    w64 = wt.astype(np.float64)
+    y_ref = ops.conv2d_fwd(xa, w64, 1, 1)
+    cv = L.Conv(0, ci, co, 3, 1, 1, 0)
+    st = G.stream()
+    xb, xv = G.to_nhwc(x, cstride=ci + 8, coff=4)
+    keep, pw = G.pointwise(scale, shift, slope)
+    pwp = None if act == "none" else C.byref(pw)
+    wd = G.dev(wt)
+    pf = torch.zeros(lib.bp_conv_packed_floats(C.byref(cv), L.PACK_FWD), device="cuda")
+    pb = torch.zeros(lib.bp_conv_packed_floats(C.byref(cv), L.PACK_BWD), device="cuda")
+    L.check(lib.bp_conv_pack(C.byref(cv), L.PACK_FWD, L.ptr(wd), L.ptr(pf), st))
+    L.check(lib.bp_conv_pack(C.byref(cv), L.PACK_BWD, L.ptr(wd), L.ptr(pb), st))
+    dy = rng.standard_normal(y_ref.shape).astype(np.float32)
+    dyb, dyv = G.to_nhwc(dy)
+    dx_ref = ops.conv2d_bwd_data(dy.astype(np.float64), w64, 1, 1, h, w)
+    res = {}
+    try:
+        for on in (1, 0):
+            assert lib.bp_set_option(b"f32_ws", on) == 0
+            yb, yv = G.empty_nhwc(n, h, w, co, cstride=co + 12, coff=4)
+            assert lib.bp_conv_ws_kind(C.byref(cv), L.PACK_FWD, C.byref(xv), C.byref(yv)) == (3 if on else 0)
+            L.check(lib.bp_conv_forward(C.byref(cv), C.byref(xv), pwp, L.ptr(pf), L.ptr(wd), None, C.byref(yv),
+                                        L.IMPL_MFMA, st), "forward")
+            got = G.from_nhwc(yb, co, coff=4)
+            assert G.rel_err(got, y_ref) < 2e-5, f"forward ws={on}"
+            assert torch.isnan(yb[..., :4]).all() and torch.isnan(yb[..., 4 + co:]).all(), "stores outside the view"
+            nb = lib.bp_conv_stats_workspace(C.byref(cv), L.PACK_FWD, C.byref(xv), C.byref(yv), L.IMPL_MFMA)
+            assert nb > 0
+            yb2, yv2 = G.empty_nhwc(n, h, w, co, cstride=co + 12, coff=4)
+            sums = torch.full((2 * co,), float("nan"), dtype=torch.float64, device="cuda")
+            wss = torch.full((nb // 8 + 8,), float("nan"), dtype=torch.float64, device="cuda")
+            L.check(lib.bp_conv_forward_stats(C.byref(cv), C.byref(xv), pwp, L.ptr(pf), C.byref(yv2), L.ptr(sums),
+                                              L.ptr(wss), nb, L.IMPL_MFMA, st), "forward + statistics")
+            assert np.array_equal(G.from_nhwc(yb2, co, coff=4), got), "the statistics epilogue must not change the output"
+            g64 = got.astype(np.float64)
+            sm = sums.cpu().numpy()
+            assert (np.abs(sm[:co] - g64.sum(axis=(0, 2, 3))) <= 1e-10 * np.abs(g64).sum(axis=(0, 2, 3)) + 1e-12).all()
+            assert np.allclose(sm[co:], (g64 ** 2).sum(axis=(0, 2, 3)), rtol=1e-10, atol=1e-12)
+            dxb, dxv = G.empty_nhwc(n, h, w, ci, cstride=ci + 4, coff=0)
+            L.check(lib.bp_conv_backward_data(C.byref(cv), C.byref(dyv), L.ptr(pb), L.ptr(wd), C.byref(dxv), L.IMPL_MFMA, st),
+                    "backward_data")
+            dx = G.from_nhwc(dxb, ci)
+            assert G.rel_err(dx, dx_ref) < 2e-5, f"backward_data ws={on}"
+            assert torch.isnan(dxb[..., ci:]).all(), "stores outside the view"
+            res[on] = (got, dx)
+        assert not np.array_equal(res[1][0], res[0][0]) and not np.array_equal(res[1][1], res[0][1]), \
+            "the weights-stationary kernel never ran (both results bit-equal)"
+        # NaN propagation through the staging's activation
+        if act == "relu":
+            assert lib.bp_set_option(b"f32_ws", 1) == 0
+            x2 = x.copy()
+            x2[n - 1, 37, h // 2, w // 2] = np.nan
+            xb2, xv2 = G.to_nhwc(x2, cstride=ci + 8, coff=4)
+            yb, yv = G.empty_nhwc(n, h, w, co)
+            L.check(lib.bp_conv_forward(C.byref(cv), C.byref(xv2), pwp, L.ptr(pf), L.ptr(wd), None, C.byref(yv),
+                                        L.IMPL_MFMA, st), "forward")
+            bad = np.isnan(G.from_nhwc(yb, co))
+            assert bad[n - 1, :, h // 2 - 1:h // 2 + 2, w // 2 - 1:w // 2 + 2].all() and bad.sum() == co * 9
+    finally:
+        lib.bp_set_option(b"f32_ws", -1)

@@ -17,7 +17,9 @@ timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/write -o r -
 # the same two passes for the bf16 step (its dominant kernel is priced against HBM)
 timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/fetch_bf16 -o r --output-format csv -- python3 $ARGS --dtype bf16 > $OUT/fetch_bf16.log 2>&1
 timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/write_bf16 -o r --output-format csv -- python3 $ARGS --dtype bf16 > $OUT/write_bf16.log 2>&1
-python3 $R/tools/pmc_to_json.py $(ls $OUT/fetch/*counter_collection.csv | head -1) $(ls $OUT/write/*counter_collection.csv | head -1) $OUT/pmc_traffic.json $(ls $OUT/fetch_bf16/*counter_collection.csv | head -1) $(ls $OUT/write_bf16/*counter_collection.csv | head -1)
+python3 $R/tools/pmc_to_json.py $OUT/pmc_traffic.json \
+  f32:$(ls $OUT/fetch/*counter_collection.csv | head -1):$(ls $OUT/write/*counter_collection.csv | head -1) \
+  bf16:$(ls $OUT/fetch_bf16/*counter_collection.csv | head -1):$(ls $OUT/write_bf16/*counter_collection.csv | head -1)
 python3 $R/tools/pmc_summary.py $(ls $OUT/fetch/*counter_collection.csv | head -1) $(ls $OUT/write/*counter_collection.csv | head -1) > $OUT/pmc_hbm_traffic_per_kernel.txt
 python3 $R/tools/prof_summary.py $(ls $OUT/stats/*kernel_stats.csv | head -1) 5 40 > $OUT/default_kernel_stats_summary.txt
 python3 $R/tools/prof_summary.py $(ls $OUT/stats_serial/*kernel_stats.csv | head -1) 5 40 > $OUT/serial_kernel_stats_summary.txt
