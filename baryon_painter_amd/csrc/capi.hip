@@ -34,6 +34,7 @@ int bp_wgrad_bf16_run(const bp_conv* cv, const bp_view* X, const PW& pwx, const 
                       void* workspace, size_t workspace_bytes, hipStream_t st);
 
 void bp_f32_ws_set(int v);        // conv_ws_f32.hip
+void bp_f32_wgrad_ws_set(int v);  // conv_wgrad_ws_f32.hip
 bool bp_f32_ws_ok(const ConvGeom& g, const bp_view* in, const bp_view* out, const float* bias, int stats_mode);
 void bp_bf16_ws_set(int v);       // conv_bf16_ws.hip
 int bp_bf16_ws_kind(const ConvGeom& g);
@@ -74,6 +75,7 @@ int bp_set_option(const char* name, int value) {
   if (!name) return BP_EINVAL;
   if (!strcmp(name, "bf16_ws")) { bp_bf16_ws_set(value); return BP_OK; }
   if (!strcmp(name, "f32_ws")) { bp_f32_ws_set(value); return BP_OK; }
+  if (!strcmp(name, "f32_wgrad_ws")) { bp_f32_wgrad_ws_set(value); return BP_OK; }
   return BP_EUNSUPPORTED;
 }
 

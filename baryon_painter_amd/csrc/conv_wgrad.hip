@@ -248,13 +248,23 @@ int bp_wgrad_enc(const bp_conv* cv, const bp_view* X, const PW& pwx, const bp_vi
                  size_t ws_bytes, size_t* need, int* nsplit, int* cxp, int* cyp, hipStream_t st, bool dry);
 int bp_wgrad_thin(const bp_conv* cv, const bp_view* X, const PW& pwx, const bp_view* Y, const PW& pwy, float* ws,
                   size_t ws_bytes, size_t* need, int* nsplit, int* cxp, int* cyp, hipStream_t st, bool dry);
+int bp_wgrad_ws_f32(const bp_conv* cv, const bp_view* X, const PW& pwx, const bp_view* Y, const PW& pwy, float* ws,
+                    size_t ws_bytes, size_t* need, int* nsplit, int* cxp, int* cyp, hipStream_t st, bool dry);
 
 // the k8 stride-4 encoder layer (conv_enc.hip), one-channel tails (conv_wgrad_thin.hip), the tap-packed few-channel
 // kernel, then the tap-blocked one;
 // BP_EUNSUPPORTED -> generic kernel
 static int wgrad_fast(const bp_conv* cv, const bp_view* X, const PW& pwx, const bp_view* Y, const PW& pwy, float* ws,
                       size_t ws_bytes, size_t* need, int* nsplit, int* cxp, int* cyp, hipStream_t st, bool dry) {
-  int rc = bp_wgrad_enc(cv, X, pwx, Y, pwy, ws, ws_bytes, need, nsplit, cxp, cyp, st, dry);
+  // the output-stationary kernel of the 128 <-> 128 k3 trunk layers (conv_wgrad_ws_f32.hip)
+  int rc = bp_wgrad_ws_f32(cv, X, pwx, Y, pwy, ws, ws_bytes, need, nsplit, cxp, cyp, st, dry);
+  if (rc == BP_OK && dry) {        // (size the workspace for either kernel: bp_set_option may switch later)
+    size_t need2 = 0;
+    int ns2, cx2, cy2;
+    if (bp_wgrad_tiles(cv, X, pwx, Y, pwy, ws, ws_bytes, &need2, &ns2, &cx2, &cy2, st, true) == BP_OK && need2 > *need) *need = need2;
+  }
+  if (rc != BP_EUNSUPPORTED) return rc;
+  rc = bp_wgrad_enc(cv, X, pwx, Y, pwy, ws, ws_bytes, need, nsplit, cxp, cyp, st, dry);
   if (rc == BP_EUNSUPPORTED) rc = bp_wgrad_thin(cv, X, pwx, Y, pwy, ws, ws_bytes, need, nsplit, cxp, cyp, st, dry);
   if (rc == BP_EUNSUPPORTED) rc = bp_wgrad_small(cv, X, pwx, Y, pwy, ws, ws_bytes, need, nsplit, cxp, cyp, st, dry);
   if (rc == BP_EUNSUPPORTED) rc = bp_wgrad_tiles(cv, X, pwx, Y, pwy, ws, ws_bytes, need, nsplit, cxp, cyp, st, dry);

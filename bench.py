@@ -93,6 +93,13 @@ def kernel_name(kind, unit, lib):
     cv = unit.cv
     if kind == "backward_data" and getattr(unit, "_sub", None) is not None:
         cv = unit._sub["cv"]           # data gradient restricted to a channel slice
+    elif kind in ("forward", "backward_data"):
+        # the fp32 weights-stationary trunk kernel (csrc/conv_ws_f32.hip) takes the layer by its views, not by its id
+        fwd = kind == "forward"
+        vin, vout = (unit.inp.view, unit.out.view) if fwd else (unit.out.grad, unit.dx)
+        if vin is not None and vout is not None and \
+                lib.bp_conv_ws_kind(C.byref(cv), L.PACK_FWD if fwd else L.PACK_BWD, C.byref(vin), C.byref(vout)) == 3:
+            return "ws3_f32_kernel[C%d->%d k%ds%d]" % (cv.cin, cv.cout, cv.k, cv.stride)
     kid = lib.bp_conv_kernel_id(C.byref(cv), L.PACK_FWD if kind == "forward" else L.PACK_BWD)
     if kid in (780001, 780002):
         return "enc0_fwd_kernel<%d>" % (kid - 780000)

@@ -692,3 +692,59 @@ def test_weights_stationary_fp32_trunk_kernel(shape, act):
             assert bad[n - 1, :, h // 2 - 1:h // 2 + 2, w // 2 - 1:w // 2 + 2].all() and bad.sum() == co * 9
     finally:
         lib.bp_set_option(b"f32_ws", -1)
+
+
+@pytest.mark.parametrize("act", ["none", "relu"])
+@pytest.mark.parametrize("shape", [(2, 9, 16), (3, 20, 32), (2, 64, 64), (70, 8, 16)], ids=lambda s: "%dx%dx%d" % s)
+def test_output_stationary_fp32_trunk_weight_gradient(shape, act):
+    """bp_conv_backward_weight of Conv2d(128, 128, 3, 1, 1) through the output-stationary kernel (csrc/conv_wgrad_ws_f32.hip)
+    and through the tap-blocked tiled kernel (bp_set_option("f32_wgrad_ws", 1 / 0)): both within 1e-4 of the float64
+    correlation (fp32 products, fp32 partial sums per band, double across bands); views that are channel slices; a NaN in X
+    reaches exactly the gradients of its input channel."""
+    lib = L.load()
+    n, h, w = shape
+    ci = co = 128
+    rng = np.random.default_rng(n + 10 * h + w)
+    x = rng.standard_normal((n, ci, h, w)).astype(np.float32)
+    dy = rng.standard_normal((n, co, h, w)).astype(np.float32)
+    scale = rng.uniform(0.5, 1.5, ci).astype(np.float32)
+    shift = rng.uniform(-0.3, 0.6, ci).astype(np.float32)
+    slope = np.zeros(ci, np.float32)
+    if act == "none":
+        xa = x.astype(np.float64)
+    else:
+        t = x * scale[None, :, None, None] + shift[None, :, None, None]
+        xa = np.where(t > 0, t, t * slope[None, :, None, None]).astype(np.float64)
+    dw_ref = ops.conv2d_bwd_weight(xa, dy.astype(np.float64), 1, 1, 3, 3)
+    cv = L.Conv(0, ci, co, 3, 1, 1, 0)
+    st = G.stream()
+    xb, xv = G.to_nhwc(x, cstride=ci + 8, coff=4)
+    dyb, dyv = G.to_nhwc(dy, cstride=co + 4, coff=0)
+    keep, pw = G.pointwise(scale, shift, slope)
+    pwp = None if act == "none" else C.byref(pw)
+    res = {}
+    try:
+        for on in (1, 0):
+            assert lib.bp_set_option(b"f32_wgrad_ws", on) == 0
+            nb = lib.bp_conv_backward_weight_workspace(C.byref(cv), C.byref(xv), C.byref(dyv))
+            assert nb > 0
+            ws = torch.full((nb // 8 + 8,), float("nan"), dtype=torch.float64, device="cuda")
+            dw = torch.full((co, ci, 3, 3), float("nan"), device="cuda")
+            L.check(lib.bp_conv_backward_weight(C.byref(cv), C.byref(xv), pwp, C.byref(dyv), L.ptr(dw), None, L.ptr(ws),
+                                                ws.numel() * 8, L.IMPL_MFMA, st), "backward_weight")
+            got = dw.cpu().numpy()
+            assert G.rel_err(got, dw_ref) < 1e-4, f"ws={on}"
+            res[on] = got
+        assert not np.array_equal(res[1], res[0]), "the output-stationary kernel never ran (both results bit-equal)"
+        assert G.rel_err(res[1], res[0]) < 1e-4
+        assert lib.bp_set_option(b"f32_wgrad_ws", 1) == 0
+        x2 = x.copy()
+        x2[0, 77, h // 2, w // 2] = np.nan
+        xb2, xv2 = G.to_nhwc(x2, cstride=ci + 8, coff=4)
+        dw = torch.zeros((co, ci, 3, 3), device="cuda")
+        L.check(lib.bp_conv_backward_weight(C.byref(cv), C.byref(xv2), pwp, C.byref(dyv), L.ptr(dw), None, L.ptr(ws),
+                                            ws.numel() * 8, L.IMPL_MFMA, st), "backward_weight")
+        bad = torch.isnan(dw).cpu().numpy()
+        assert bad[:, 77].all() and not np.delete(bad, 77, axis=1).any()
+    finally:
+        lib.bp_set_option(b"f32_wgrad_ws", -1)

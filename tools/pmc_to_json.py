@@ -43,6 +43,10 @@ def label(name):
     m = re.match(r"igemm_dmaf_kernel<(\d+), (\d+), (\d+), (\d+)>", name)
     if m:
         return "igemm_dmaf_kernel<%s,%s,1,4>" % m.groups()[:2]
+    if name.startswith("ws3_f32_kernel"):
+        return "ws3_f32_kernel[C128->128 k3s1]"
+    if name.startswith("ws4_bf16_kernel"):
+        return "ws4_bf16_kernel"
     if name.startswith("ws3_bf16_kernel"):
         return "ws3_bf16_kernel[C128->128 k3s1]"
     if name.startswith("wgrad_bf16_kernel<3, 3, 1, 2, 2, 2, 2, 4"):
