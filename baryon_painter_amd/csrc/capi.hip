@@ -35,6 +35,7 @@ int bp_wgrad_bf16_run(const bp_conv* cv, const bp_view* X, const PW& pwx, const 
 
 void bp_f32_ws_set(int v);        // conv_ws_f32.hip
 void bp_f32_wgrad_ws_set(int v);  // conv_wgrad_ws_f32.hip
+void bp_bf16_wgrad_ws_set(int v); // conv_wgrad_ws_bf16.hip
 bool bp_f32_ws_ok(const ConvGeom& g, const bp_view* in, const bp_view* out, const float* bias, int stats_mode);
 void bp_bf16_ws_set(int v);       // conv_bf16_ws.hip
 int bp_bf16_ws_kind(const ConvGeom& g);
@@ -76,6 +77,7 @@ int bp_set_option(const char* name, int value) {
   if (!strcmp(name, "bf16_ws")) { bp_bf16_ws_set(value); return BP_OK; }
   if (!strcmp(name, "f32_ws")) { bp_f32_ws_set(value); return BP_OK; }
   if (!strcmp(name, "f32_wgrad_ws")) { bp_f32_wgrad_ws_set(value); return BP_OK; }
+  if (!strcmp(name, "bf16_wgrad_ws")) { bp_bf16_wgrad_ws_set(value); return BP_OK; }
   return BP_EUNSUPPORTED;
 }
 

@@ -863,11 +863,25 @@ bool wb_view_ok(const bp_view* v) {
 }  // namespace
 
 // Same contract as bp_wgrad_tiles (conv_wgrad_tiles.hip): partial sums to ws, BP_EUNSUPPORTED if no variant fits.
+int bp_wgrad_ws_bf16(const bp_conv* cv, const bp_view* X, const PW& pwx, const bp_view* Y, const PW& pwy, float* ws,
+                     size_t ws_bytes, size_t* need, int* nsplit, int* cxp, int* cyp, hipStream_t st, bool dry);
+
 int bp_wgrad_bf16(const bp_conv* cv, const bp_view* X, const PW& pwx, const bp_view* Y, const PW& pwy, float* ws,
                   size_t ws_bytes, size_t* need, int* nsplit, int* cxp, int* cyp, hipStream_t st, bool dry) {
   if (!wb_view_ok(X) || !wb_view_ok(Y)) return BP_EUNSUPPORTED;
   if (wf_ok(cv, X, Y, pwy)) return wf_launch(X, pwx, Y, ws, ws_bytes, need, nsplit, cxp, cyp, st, dry);
   if (sf_ok(cv, X, Y, pwy)) return sf_launch(X, pwx, Y, ws, ws_bytes, need, nsplit, cxp, cyp, st, dry);
+  {      // the output-stationary kernel of the 128 <-> 128 k3 trunk layers (conv_wgrad_ws_bf16.hip)
+    const int rc = bp_wgrad_ws_bf16(cv, X, pwx, Y, pwy, ws, ws_bytes, need, nsplit, cxp, cyp, st, dry);
+    if (rc == BP_OK && dry) {      // (size the workspace for either kernel: bp_set_option may switch later)
+      size_t need2 = 0;
+      int ns2, cx2, cy2;
+      if (wb_launch<3, 3, 1, 2, 2, 2, 2, 4>(cv, X, pwx, Y, pwy, ws, ws_bytes, &need2, &ns2, &cx2, &cy2, st, true) == BP_OK &&
+          need2 > *need)
+        *need = need2;
+    }
+    if (rc != BP_EUNSUPPORTED) return rc;
+  }
   const int k = cv->k, s = cv->stride, cx = X->c, cy = Y->c;
 #define BP_WB_(...) return wb_launch<__VA_ARGS__>(cv, X, pwx, Y, pwy, ws, ws_bytes, need, nsplit, cxp, cyp, st, dry)
   if (k == 3 && s == 1) {

@@ -81,8 +81,8 @@ int bp_version(void);
 /* Kernel-selection switches for A/B measurements and tests inside ONE process (the environment variables of the same
  * names are read once, at the first call).  "bf16_ws" / "f32_ws": 1 / 0 = use / do not use the weights-stationary kernels
  * (csrc/conv_bf16_ws.hip: bf16 128 -> 128 k3 and 64 -> 128 k4 s2; csrc/conv_ws_f32.hip: fp32 128 -> 128 k3), -1 = back to the
- * environment's choice (BP_BF16_WS / BP_F32_WS); "f32_wgrad_ws": the output-stationary fp32 weight gradient of the same
- * trunk layers (csrc/conv_wgrad_ws_f32.hip, BP_F32_WGRAD_WS).
+ * environment's choice (BP_BF16_WS / BP_F32_WS); "f32_wgrad_ws" / "bf16_wgrad_ws": the output-stationary weight gradients of
+ * the same trunk layers (csrc/conv_wgrad_ws_f32.hip, csrc/conv_wgrad_ws_bf16.hip; BP_F32_WGRAD_WS / BP_BF16_WGRAD_WS).
  * Not thread-safe against concurrent launches; results of either kernel meet the same tolerances.
  * Returns BP_EUNSUPPORTED for an unknown name. */
 int bp_set_option(const char* name, int value);

@@ -357,3 +357,62 @@ def test_bf16_relu_staging_propagates_nan(ws_on):
                                         L.ptr(ws), ws.numel() * 8, L.IMPL_BF16, st), "backward_weight")
     dwn = torch.isnan(dw).cpu().numpy()
     assert dwn[:, 37].all() and not np.delete(dwn, 37, axis=1).any()
+
+
+@pytest.mark.parametrize("act", ["none", "relu", "leaky"])
+@pytest.mark.parametrize("shape", [(2, 9, 32), (2, 64, 64), (3, 21, 64), (66, 8, 32)], ids=lambda s: "%dx%dx%d" % s)
+def test_output_stationary_bf16_trunk_weight_gradient(shape, act):
+    """bp_conv_backward_weight (impl BP_IMPL_BF16) of Conv2d(128, 128, 3, 1, 1) on bf16 views through the output-stationary
+    kernel (csrc/conv_wgrad_ws_bf16.hip) and through the tiled one (bp_set_option("bf16_wgrad_ws", 1 / 0)): exact bf16
+    products, fp32 accumulation -- both within 1e-4 of the float64 correlation of the same bf16-rounded operands (activation
+    applied in fp32, then rounded, as the staging does); views that are channel slices; a NaN in X reaches exactly the
+    gradients of its input channel."""
+    lib = L.load()
+    n, h, w = shape
+    ci = co = 128
+    rng = np.random.default_rng(n + 7 * h + w)
+    x = bf16_round(rng.standard_normal((n, ci, h, w)).astype(np.float32))
+    dy = bf16_round(rng.standard_normal((n, co, h, w)).astype(np.float32))
+    scale = rng.uniform(0.5, 1.5, ci).astype(np.float32)
+    shift = rng.uniform(-0.3, 0.6, ci).astype(np.float32)
+    slope = rng.uniform(0.0, 0.3, ci).astype(np.float32)
+    if act == "relu":
+        slope[:] = 0.0
+    if act == "none":
+        xa = x.astype(np.float64)
+    else:
+        t = (x.astype(np.float64) * scale[None, :, None, None].astype(np.float64)
+             + shift[None, :, None, None].astype(np.float64)).astype(np.float32)
+        xa = bf16_round(np.where(t > 0, t, t * slope[None, :, None, None]).astype(np.float32)).astype(np.float64)
+    dw_ref = ops.conv2d_bwd_weight(xa, dy.astype(np.float64), 1, 1, 3, 3)
+    cv = L.Conv(0, ci, co, 3, 1, 1, 0)
+    st = G.stream()
+    xb, xv = to_view(x, True, cstride=ci + 16, coff=8)
+    dyb, dyv = to_view(dy, True, cstride=co + 8, coff=0)
+    keep, pw = G.pointwise(scale, shift, slope)
+    pwp = None if act == "none" else C.byref(pw)
+    res = {}
+    try:
+        for on in (1, 0):
+            assert lib.bp_set_option(b"bf16_wgrad_ws", on) == 0
+            nb = lib.bp_conv_backward_weight_workspace(C.byref(cv), C.byref(xv), C.byref(dyv))
+            assert nb > 0
+            ws = torch.full((nb // 8 + 8,), float("nan"), dtype=torch.float64, device="cuda")
+            dw = torch.full((co, ci, 3, 3), float("nan"), device="cuda")
+            L.check(lib.bp_conv_backward_weight(C.byref(cv), C.byref(xv), pwp, C.byref(dyv), L.ptr(dw), None, L.ptr(ws),
+                                                ws.numel() * 8, L.IMPL_BF16, st), "backward_weight")
+            got = dw.cpu().numpy()
+            assert G.rel_err(got, dw_ref) < 1e-4, f"ws={on}"
+            res[on] = got
+        assert not np.array_equal(res[1], res[0]), "the output-stationary kernel never ran (both results bit-equal)"
+        assert lib.bp_set_option(b"bf16_wgrad_ws", 1) == 0
+        x2 = x.copy()
+        x2[n - 1, 77, h // 2, w // 2] = np.nan
+        xb2, xv2 = to_view(x2, True, cstride=ci + 16, coff=8)
+        dw = torch.zeros((co, ci, 3, 3), device="cuda")
+        L.check(lib.bp_conv_backward_weight(C.byref(cv), C.byref(xv2), pwp, C.byref(dyv), L.ptr(dw), None, L.ptr(ws),
+                                            ws.numel() * 8, L.IMPL_BF16, st), "backward_weight")
+        bad = torch.isnan(dw).cpu().numpy()
+        assert bad[:, 77].all() and not np.delete(bad, 77, axis=1).any()
+    finally:
+        lib.bp_set_option(b"bf16_wgrad_ws", -1)
