@@ -590,6 +590,278 @@ __global__ __launch_bounds__(256) void ws4_bf16_kernel(WsArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// ... and for the transposed form  k4 s2 p1, 128 -> 64 channels  (forward of p_y_z_in.16, data gradient of p_y_z_in.9:
+// architecture_built.txt:51,94): four output phases (py, px), each a 2 x 2-tap correlation over the coarse grid.  Wave =
+// phase: it keeps the phase's 4 taps x 128 gathered x 64 produced channels (64 A-fragments) and produces ALL 64 channels of
+// its phase's pixels, so a B-fragment (16 coarse pixels x 32 channels) feeds four MFMAs: 64 B/clk of LDS reads per CU.
+// The coarse rows y - 1, y, y + 1 serve both row phases: the same ring of four rows as the k3 kernel.  The pipeline unit
+// is HALF a coarse row (32 pixels x 4 channel blocks = 32 accumulator registers, double-buffered).
+constexpr int WT_CI = 128, WT_CO = 64, WT_NF = 64, WT_FV = 16;
+
+// fragment f = ((ty*2 + tx)*4 + chunk)*4 + block of wave (phase) p; lane (lm, kq): produced channel
+// 32 (block >> 1) + 8 (lm >> 2) + 4 (block & 1) + (lm & 3), gathered channel 32 chunk + 8 kq + j
+__global__ __launch_bounds__(256) void wst_pack_kernel(WsPackArgs a) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= 4 * WT_NF * 64 * 8) return;
+  const int j = i & 7, lane = (i >> 3) & 63, f = (i >> 9) % WT_NF, p = i / (512 * WT_NF);
+  const int lm = lane & 15, kq = lane >> 4;
+  const int blk = f & 3, chunk = (f >> 2) & 3, tap = f >> 4;
+  const int ty = tap >> 1, tx = tap & 1, py = p >> 1, px = p & 1;
+  const int co = 32 * (blk >> 1) + 8 * (lm >> 2) + 4 * (blk & 1) + (lm & 3);
+  const int ci = 32 * chunk + 8 * kq + j;
+  const int ky = bp_t_ky(py, 1, 2, 2, ty), kx = bp_t_ky(px, 1, 2, 2, tx);
+  a.dst[i] = f2bf(a.w[ci * a.sa + co * a.sb + ky * 4 + kx]);
+}
+
+template <int G, bool ACT, bool STATS>
+__global__ __launch_bounds__(256) void wst_bf16_kernel(WsArgs a) {
+  using GM = WsGeom<G>;                                 // the k3 kernel's image: 16 octet planes x 4 ring rows x (W + 2) slots
+  constexpr int W = GM::W, RP = GM::RP, PS = GM::PS;
+  constexpr int HG = G >= 2 ? G / 2 : 1;                // pixel groups per pipeline unit
+  constexpr int NUNIT = G / HG;                         // units per coarse row
+  constexpr int NS = 16;                                // K-steps per unit: 4 taps x 4 chunks
+  extern __shared__ __attribute__((aligned(16))) u16 smem[];
+  uint4* img = reinterpret_cast<uint4*>(smem);
+  float* lpw = reinterpret_cast<float*>(smem + GM::img_bytes / 2);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int py = wave >> 1, px = wave & 1;
+  const int lm = lane & 15, kq = lane >> 4;
+  const int n = blockIdx.x / a.bands, band = blockIdx.x % a.bands;
+  const int y0 = band * a.BR;                           // coarse rows [y0, y1); a.h coarse rows, 2 a.h produced rows
+  const int y1 = min(y0 + a.BR, a.h);
+
+  int s_slot[G], s_oc[G];
+  unsigned s_off[G];
+#pragma unroll
+  for (int i = 0; i < G; ++i) {
+    const int ub = wave + 4 * i;
+    s_oc[i] = (lane >> 3) + 8 * (ub & 1);
+    const int pxl = (lane & 7) + 8 * (ub >> 1);
+    s_slot[i] = s_oc[i] * PS + 1 + pxl;
+    s_off[i] = (unsigned)(pxl * a.in_cs + s_oc[i] * 8) * 2u;
+  }
+  const char* in_img = reinterpret_cast<const char*>(a.in + (int64_t)n * a.h * W * a.in_cs + a.in_co);
+  const unsigned in_row = (unsigned)(W * a.in_cs) * 2u;
+  auto load_row = [&](int r, uint4 (&raw)[G]) {
+    const char* rowp = in_img + (size_t)((unsigned)r * in_row);
+#pragma unroll
+    for (int i = 0; i < G; ++i) raw[i] = *reinterpret_cast<const uint4*>(rowp + s_off[i]);
+  };
+  auto commit_row = [&](int r, bool inside, const uint4 (&raw)[G]) {
+    const int rr = (r + 1) & (WS_R - 1);
+#pragma unroll
+    for (int i = 0; i < G; ++i) {
+      uint4 v = raw[i];
+      if constexpr (ACT) {
+        float t[4], sl[4];
+        ws_act_a(lpw, WT_CI, s_oc[i], 0, v.x, v.y, t, sl); ws_act_b(t, sl, v.x, v.y);
+        ws_act_a(lpw, WT_CI, s_oc[i], 1, v.z, v.w, t, sl); ws_act_b(t, sl, v.z, v.w);
+      }
+      if (!inside) v = make_uint4(0u, 0u, 0u, 0u);
+      img[s_slot[i] + rr * RP] = v;
+    }
+  };
+
+  // ---- prologue
+  uint4 raw0[G], raw1[G];
+  const bool in0 = y0 - 1 >= 0, in2 = y0 + 1 < a.h;
+  load_row(in0 ? y0 - 1 : y0, raw0);
+  load_row(y0, raw1);
+  bf8 wf[WT_NF];
+  {
+    const uint4* wsrc = reinterpret_cast<const uint4*>(a.wp) + (size_t)wave * WT_NF * 64 + lane;
+#pragma unroll
+    for (int f = 0; f < WT_NF; ++f) wf[f] = __builtin_bit_cast(bf8, wsrc[f * 64]);
+#pragma unroll
+    for (int f = 0; f < WT_NF; ++f) {
+      if (f < WT_FV) asm volatile("" : "+v"(wf[f]));
+      else asm volatile("" : "+a"(wf[f]));
+    }
+  }
+  if (tid < 128) {
+    const int plane = tid >> 3, rr = (tid >> 1) & 3, side = tid & 1;
+    img[plane * PS + rr * RP + (side ? RP - 1 : 0)] = make_uint4(0u, 0u, 0u, 0u);
+  }
+  if constexpr (ACT) {
+    for (int i = tid; i < WT_CI; i += 256) { lpw[i] = a.pw.scale[i]; lpw[WT_CI + i] = a.pw.shift[i]; lpw[2 * WT_CI + i] = a.pw.slope[i]; }
+    __syncthreads();
+  }
+  commit_row(y0 - 1, in0, raw0);
+  commit_row(y0, true, raw1);
+  load_row(in2 ? y0 + 1 : y0, raw0);
+  commit_row(y0 + 1, in2, raw0);
+  __syncthreads();
+
+  float s1[16], s2[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+  // fragment base of this lane and phase: plane kq, pixel lm + px (+ tx), tap row ty lives in ring slot (y + py + ty) & 3
+  const int lbase = kq * PS + lm + px;
+  char* out_img = reinterpret_cast<char*>(a.out + (int64_t)n * (2 * a.h) * (2 * W) * a.out_cs + a.out_co);
+  const unsigned out_row = (unsigned)(2 * W * a.out_cs) * 2u;
+  // produced pixel 2 (16 g + lm) + px of row 2 y + py; a lane's channels: 32 hb + 8 kq + [0, 8), hb = 0, 1
+  const unsigned o_off = (unsigned)((2 * lm + px) * a.out_cs + 8 * kq) * 2u, o_g = (unsigned)(32 * a.out_cs) * 2u;
+
+  v4f acc[2][HG][4];
+  bf8 xf[2][HG];
+  uint4 pk[HG][2];
+  auto epi_pack = [&](auto P_, int g, int hb, int gg, int yp) {         // unit-local group g, channel half hb, row-global group gg
+    constexpr int P = decltype(P_)::value;
+    pk[g][hb] = make_uint4(pack2(acc[P][g][2 * hb][0], acc[P][g][2 * hb][1]), pack2(acc[P][g][2 * hb][2], acc[P][g][2 * hb][3]),
+                           pack2(acc[P][g][2 * hb + 1][0], acc[P][g][2 * hb + 1][1]), pack2(acc[P][g][2 * hb + 1][2], acc[P][g][2 * hb + 1][3]));
+    char* rowp = out_img + (size_t)((unsigned)(2 * yp + py) * out_row);
+    *reinterpret_cast<uint4*>(rowp + (o_off + (unsigned)gg * o_g + 64u * (unsigned)hb)) = pk[g][hb];
+  };
+  auto epi_stats = [&](int g, int hb, int hh) {         // channels 32 hb + 8 kq + 4 hh + [0, 4) of the values AS STORED
+    const unsigned w0 = hh ? pk[g][hb].z : pk[g][hb].x, w1 = hh ? pk[g][hb].w : pk[g][hb].y;
+    const float v0 = bf2f((u16)(w0 & 0xffffu)), v1 = bf2f((u16)(w0 >> 16)), v2 = bf2f((u16)(w1 & 0xffffu)), v3 = bf2f((u16)(w1 >> 16));
+    const int o = 8 * hb + 4 * hh;
+    s1[o] += v0; s2[o] = fmaf(v0, v0, s2[o]);
+    s1[o + 1] += v1; s2[o + 1] = fmaf(v1, v1, s2[o + 1]);
+    s1[o + 2] += v2; s2[o + 2] = fmaf(v2, v2, s2[o + 2]);
+    s1[o + 3] += v3; s2[o + 3] = fmaf(v3, v3, s2[o + 3]);
+  };
+  auto epi_all = [&](auto P_, int u, int yp) {
+#pragma unroll
+    for (int g = 0; g < HG; ++g)
+#pragma unroll
+      for (int hb = 0; hb < 2; ++hb) {
+        epi_pack(P_, g, hb, u * HG + g, yp);
+        if constexpr (STATS) { epi_stats(g, hb, 0); epi_stats(g, hb, 1); }
+      }
+  };
+
+  // unit (y, u): pixel groups u HG .. u HG + HG - 1 of coarse row y.  The first unit of a row requests coarse row y + 2; its
+  // G staging units are committed over the row's units; the last unit of a row ends with the barrier.
+  auto unit = [&](auto P_, auto PREV_, auto U_, int y, int yprev, int uprev) {
+    constexpr int P = decltype(P_)::value;
+    constexpr bool PREV = decltype(PREV_)::value;
+    constexpr int U = decltype(U_)::value;
+    const bool in_next = y + 2 < a.h;
+    if constexpr (U == 0) load_row(in_next ? y + 2 : a.h - 1, raw0);
+    const int rr_next = (y + 3) & (WS_R - 1);
+    const unsigned keep = in_next ? 0xffffffffu : 0u;
+    int rb[2];                                          // tap rows ty = 0, 1 of this phase
+#pragma unroll
+    for (int ty = 0; ty < 2; ++ty) rb[ty] = lbase + ((y + py + ty) & (WS_R - 1)) * RP;
+    // next unit's first fragments: same row (U + 1 < NUNIT) or row y + 1, whose tap row 0 is this row's tap row 1
+    uint4 cv = make_uint4(0u, 0u, 0u, 0u);
+    float ct[4] = {0.f, 0.f, 0.f, 0.f}, csl[4] = {0.f, 0.f, 0.f, 0.f};
+    constexpr int CPU_ = (G + NUNIT - 1) / NUNIT;       // staging units committed per pipeline unit
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const int t = s >> 2, c = s & 3;                  // tap (ty, tx) = (t >> 1, t & 1), channel chunk c
+      {
+        const int sn = (s + 1) % NS;
+        const int tn = sn >> 2, cn = sn & 3;
+        int base, gofs;
+        if (s == NS - 1) {                              // first step of the next unit: tap (0, 0), chunk 0
+          base = U + 1 < NUNIT ? rb[0] : rb[1];
+          gofs = U + 1 < NUNIT ? 16 * HG * (U + 1) : 0;
+        } else {
+          base = rb[tn >> 1] + 4 * cn * PS + (tn & 1);
+          gofs = 16 * HG * U;
+        }
+#pragma unroll
+        for (int g = 0; g < HG; ++g) xf[(s + 1) & 1][g] = __builtin_bit_cast(bf8, img[base + gofs + 16 * g]);
+      }
+      if constexpr (PREV) {
+        // previous unit: per group and channel half: round + store | sums of 4 channels | sums of 4 channels
+        if (s < 6 * HG) {
+          const int g = s / 6, r6 = s % 6, hb = r6 / 3, part = r6 % 3;
+          if (part == 0) epi_pack(std::integral_constant<int, P ^ 1>{}, g, hb, uprev * HG + g, yprev);
+          else if constexpr (STATS) epi_stats(g, hb, part - 1);
+        }
+      }
+      if (s >= 8 && s < 8 + 2 * CPU_ && U * CPU_ + (s - 8) / 2 < G) {
+        const int i = U * CPU_ + (s - 8) / 2, hh = (s - 8) % 2;
+        if (hh == 0) {
+          cv = raw0[i];
+          if constexpr (ACT) { ws_act_a(lpw, WT_CI, s_oc[i], 0, cv.x, cv.y, ct, csl); ws_act_b(ct, csl, cv.x, cv.y); }
+        } else {
+          if constexpr (ACT) { ws_act_a(lpw, WT_CI, s_oc[i], 1, cv.z, cv.w, ct, csl); ws_act_b(ct, csl, cv.z, cv.w); }
+          img[s_slot[i] + rr_next * RP] = make_uint4(cv.x & keep, cv.y & keep, cv.z & keep, cv.w & keep);
+        }
+      }
+      const int f = (t * 4 + c) * 4;
+#pragma unroll
+      for (int g = 0; g < HG; ++g) {
+        const v4f z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb)
+          acc[P][g][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[f + nb], xf[s & 1][g], s == 0 ? z : acc[P][g][nb], 0, 0, 0);
+      }
+#pragma unroll
+      for (int g = 0; g < HG; ++g) {
+        WS_SGB(SG_DSR, 1);
+        WS_SGB(SG_MFMA, 1); WS_SGB(SG_VALU, 2);
+        WS_SGB(SG_MFMA, 1); WS_SGB(SG_VALU, 2);
+        WS_SGB(SG_MFMA, 1); WS_SGB(SG_VALU, 2);
+        WS_SGB(SG_MFMA, 1); WS_SGB(SG_VALU, 2);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if constexpr (U == NUNIT - 1) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+    }
+  };
+
+  {   // first fragments of the first unit: tap (0, 0), chunk 0
+    const int b0 = lbase + ((y0 + py) & (WS_R - 1)) * RP;
+#pragma unroll
+    for (int g = 0; g < HG; ++g) xf[0][g] = __builtin_bit_cast(bf8, img[b0 + 16 * g]);
+  }
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  // NS is even, so the fragment buffer parity is the same for every unit; the accumulator parity alternates per unit
+  if constexpr (NUNIT == 2) {
+    unit(I0{}, std::false_type{}, I0{}, y0, y0, 0);
+    unit(I1{}, std::true_type{}, I1{}, y0, y0, 0);
+    for (int y = y0 + 1; y < y1; ++y) {
+      unit(I0{}, std::true_type{}, I0{}, y, y - 1, 1);
+      unit(I1{}, std::true_type{}, I1{}, y, y, 0);
+    }
+    epi_all(I1{}, 1, y1 - 1);
+  } else {
+    unit(I0{}, std::false_type{}, I0{}, y0, y0, 0);
+    int y = y0 + 1;
+    for (; y + 1 < y1; y += 2) {
+      unit(I1{}, std::true_type{}, I0{}, y, y - 1, 0);
+      unit(I0{}, std::true_type{}, I0{}, y + 1, y, 0);
+    }
+    if (y < y1) {
+      unit(I1{}, std::true_type{}, I0{}, y, y - 1, 0);
+      epi_all(I1{}, 0, y);
+    } else {
+      epi_all(I0{}, 0, y - 1);
+    }
+  }
+
+  if constexpr (STATS) {
+    // per-lane fp32 partials -> LDS [stat][channel 64][phase 4][lm 16] -> one double row per workgroup (fixed order)
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int ch = 32 * (j >> 3) + 8 * kq + (j & 7);
+      red[(ch * 4 + wave) * 16 + lm] = s1[j];
+      red[((WT_CO + ch) * 4 + wave) * 16 + lm] = s2[j];
+    }
+    __syncthreads();
+    if (tid < 2 * WT_CO) {
+      double t = 0.0;
+#pragma unroll
+      for (int i = 0; i < 64; ++i) t += (double)red[tid * 64 + i];
+      a.stat[(int64_t)blockIdx.x * 2 * WT_CO + tid] = t;
+    }
+  }
+}
+
 bool ws_enabled() {
   static const bool off = getenv("BP_BF16_WS") && atoi(getenv("BP_BF16_WS")) == 0;
   return !off;
@@ -608,10 +880,13 @@ void ws_bands(int n, int h, int* BR, int* bands) {
 
 template <int KIND, int G, bool ACT, bool STATS>
 int ws_launch(const WsArgs& a, unsigned grid, hipStream_t st) {
-  constexpr size_t lds = KIND == 3 ? WsGeom<G>::lds_bytes : W4Geom<G>::lds_bytes;
+  // (the transposed kernel folds its statistics through 32 KB of LDS: more than the image at W = 16)
+  constexpr size_t lds = KIND == 3 ? WsGeom<G>::lds_bytes : KIND == 4 ? W4Geom<G>::lds_bytes
+                         : (WsGeom<G>::lds_bytes > 32768 ? WsGeom<G>::lds_bytes : 32768);
   auto kern = [] {
     if constexpr (KIND == 3) return &ws3_bf16_kernel<G, ACT, STATS>;
-    else return &ws4_bf16_kernel<G, ACT, STATS>;
+    else if constexpr (KIND == 4) return &ws4_bf16_kernel<G, ACT, STATS>;
+    else return &wst_bf16_kernel<G, ACT, STATS>;
   }();
   static const hipError_t optin = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -638,8 +913,12 @@ int ws_launch_k(int G, const WsArgs& a, bool act, bool stats, unsigned grid, hip
 
 void bp_bf16_ws_set(int v) { g_ws_override = v; }
 
-// 3: the k3 s1 p1 128 -> 128 trunk layer (either direction); 4: the strided gather k4 s2 p1 64 -> 128; 0: neither
+// 3: the k3 s1 p1 128 -> 128 trunk layer (either direction); 4: the strided gather k4 s2 p1 64 -> 128; 5: the transposed
+// form k4 s2 p1 128 -> 64; 0: none
 int bp_bf16_ws_kind(const ConvGeom& g) {
+  if (g.gather_transposed && g.k == 4 && g.stride == 2 && g.pad == 1 && g.nphase == 2 && g.taps == 2 && g.IS == 1 && g.OS == 2 &&
+      g.cin_g == WT_CI && g.cout_g == WT_CO)
+    return 5;
   if (g.nphase != 1 || g.OS != 1) return 0;
   if (g.k == 3 && g.stride == 1 && g.pad == 1 && g.cin_g == WS_C && g.cout_g == WS_C && g.taps == 3 && g.IS == 1) return 3;
   if (g.k == 4 && g.stride == 2 && g.pad == 1 && g.cin_g == W4_CI && g.cout_g == WS_C && g.taps == 4 && g.IS == 2 &&
@@ -650,7 +929,7 @@ int bp_bf16_ws_kind(const ConvGeom& g) {
 
 int64_t bp_bf16_ws_packed_elems(const ConvGeom& g) {
   const int k = bp_bf16_ws_kind(g);
-  return k == 3 ? (int64_t)4 * WS_NF * 64 * 8 : k == 4 ? (int64_t)4 * W4_NF * 64 * 8 : 0;
+  return k == 3 ? (int64_t)4 * WS_NF * 64 * 8 : k == 4 ? (int64_t)4 * W4_NF * 64 * 8 : k == 5 ? (int64_t)4 * WT_NF * 64 * 8 : 0;
 }
 
 int bp_bf16_ws_pack(const ConvGeom& g, const WeightMap& wm, const float* w_torch, u16* dst, hipStream_t st) {
@@ -658,7 +937,8 @@ int bp_bf16_ws_pack(const ConvGeom& g, const WeightMap& wm, const float* w_torch
   if (!k) return BP_EUNSUPPORTED;
   const WsPackArgs a{w_torch, dst, wm.sa, wm.sb, g.gather_transposed};
   if (k == 3) hipLaunchKernelGGL(ws_pack_kernel, dim3(4 * WS_NF * 64 * 8 / 256), dim3(256), 0, st, a);
-  else hipLaunchKernelGGL(ws4_pack_kernel, dim3(4 * W4_NF * 64 * 8 / 256), dim3(256), 0, st, a);
+  else if (k == 4) hipLaunchKernelGGL(ws4_pack_kernel, dim3(4 * W4_NF * 64 * 8 / 256), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(wst_pack_kernel, dim3(4 * WT_NF * 64 * 8 / 256), dim3(256), 0, st, a);
   BP_CHECK_LAUNCH();
   return BP_OK;
 }
@@ -669,23 +949,26 @@ bool bp_bf16_ws_ok(const ConvGeom& g, const bp_view* in, const bp_view* out, con
   const int k = bp_bf16_ws_kind(g);
   if (!k || !in || !out || bias || (mode != 0 && mode != 1)) return false;
   if (in->dtype != BP_BF16 || out->dtype != BP_BF16 || in->c != g.cin_g || out->c != g.cout_g) return false;
-  if (in->n != out->n || !ws_G(out->w)) return false;
+  const bp_view* grid_v = k == 5 ? in : out;            // the view whose rows the kernel walks (the coarse one)
+  if (in->n != out->n || !ws_G(grid_v->w)) return false;
   if (k == 3 && (in->w != out->w || in->h != out->h)) return false;
   if (k == 4 && (in->w != 2 * out->w || in->h != 2 * out->h)) return false;
+  if (k == 5 && (out->w != 2 * in->w || out->h != 2 * in->h)) return false;
   if (in->cstride % 8 || in->coff % 8 || reinterpret_cast<uintptr_t>(in->ptr) % 16) return false;
   if (out->cstride % 8 || out->coff % 8 || reinterpret_cast<uintptr_t>(out->ptr) % 16) return false;
   // (row addresses are a 64-bit image base + 32-bit byte offsets inside the image)
   if ((int64_t)in->h * in->w * in->cstride * 2 >= (int64_t)1 << 31 || (int64_t)out->h * out->w * out->cstride * 2 >= (int64_t)1 << 31)
     return false;
   int BR, bands;
-  ws_bands(out->n, out->h, &BR, &bands);
-  if (mode == 1 && BR * ws_G(out->w) > 256) return false;          // a lane's fp32 partial sums: <= 256 terms
+  ws_bands(grid_v->n, grid_v->h, &BR, &bands);
+  if (mode == 1 && BR * ws_G(grid_v->w) > 256) return false;          // a lane's fp32 partial sums: <= 256 terms
   return (int64_t)out->n * bands <= 0x7fffffff;
 }
 
 size_t bp_bf16_ws_stats_workspace(const ConvGeom& g, const bp_view* in, const bp_view* out) {
+  const bp_view* grid_v = bp_bf16_ws_kind(g) == 5 ? in : out;
   int BR, bands;
-  ws_bands(out->n, out->h, &BR, &bands);
+  ws_bands(grid_v->n, grid_v->h, &BR, &bands);
   return bp_stats_rows_bytes((int64_t)out->n * bands, g.cout_g);
 }
 
@@ -694,8 +977,10 @@ int bp_bf16_ws_run(const ConvGeom& g, const bp_view* in, const PW& pw, const u16
   WsArgs a{};
   a.in = reinterpret_cast<const u16*>(in->ptr); a.in_cs = in->cstride; a.in_co = in->coff;
   a.out = reinterpret_cast<u16*>(out->ptr); a.out_cs = out->cstride; a.out_co = out->coff;
-  a.n = out->n; a.h = out->h; a.wp = packed_ws; a.pw = pw;
-  ws_bands(out->n, out->h, &a.BR, &a.bands);
+  const int kind = bp_bf16_ws_kind(g);
+  const bp_view* grid_v = kind == 5 ? in : out;
+  a.n = out->n; a.h = grid_v->h; a.wp = packed_ws; a.pw = pw;
+  ws_bands(grid_v->n, grid_v->h, &a.BR, &a.bands);
   const int64_t rows = (int64_t)out->n * a.bands;
   if (sr) {
     const size_t need = bp_stats_rows_bytes(rows, g.cout_g);
@@ -704,8 +989,10 @@ int bp_bf16_ws_run(const ConvGeom& g, const bp_view* in, const PW& pw, const u16
     a.stat = reinterpret_cast<double*>(sr->ws);
   }
   const bool act = pw.scale != nullptr;
-  const int rc = bp_bf16_ws_kind(g) == 3 ? ws_launch_k<3>(ws_G(out->w), a, act, sr != nullptr, (unsigned)rows, st)
-                                         : ws_launch_k<4>(ws_G(out->w), a, act, sr != nullptr, (unsigned)rows, st);
+  const int G = ws_G(grid_v->w);
+  const int rc = kind == 3 ? ws_launch_k<3>(G, a, act, sr != nullptr, (unsigned)rows, st)
+                 : kind == 4 ? ws_launch_k<4>(G, a, act, sr != nullptr, (unsigned)rows, st)
+                             : ws_launch_k<5>(G, a, act, sr != nullptr, (unsigned)rows, st);
   if (rc != BP_OK || !sr) return rc;
   return bp_stats_rows_finish(a.stat, rows, g.cout_g, sr, st);
 }

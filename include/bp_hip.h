@@ -128,7 +128,8 @@ int bp_conv_pack_jobs(const void* jobs_dev, const int64_t* first_block_dev, int3
 int64_t bp_conv_bf16_packed_elems(const bp_conv* cv, int dir);
 /* Which weights-stationary kernel serves this layer / direction with these views (`in` = the gathered tensor of the
  * direction: x for BP_PACK_FWD, dy for BP_PACK_BWD; `out` = the produced one): 3 = the k3 s1 128 -> 128 trunk kernel (bf16
- * views: csrc/conv_bf16_ws.hip; fp32 views: csrc/conv_ws_f32.hip), 4 = the bf16 strided gather k4 s2 64 -> 128, 0 = none
+ * views: csrc/conv_bf16_ws.hip; fp32 views: csrc/conv_ws_f32.hip), 4 = the bf16 strided gather k4 s2 64 -> 128, 5 = the bf16
+ * transposed form k4 s2 128 -> 64, 0 = none
  * (the tiled / flattened-K kernels).  For profiles and bench.py's kernel labels; follows bp_set_option. */
 int bp_conv_ws_kind(const bp_conv* cv, int dir, const bp_view* in, const bp_view* out);
 int bp_conv_bf16_pack(const bp_conv* cv, int dir, const float* w_torch, void* packed, void* stream);

@@ -230,8 +230,10 @@ def test_fp32_entry_points_refuse_bf16_views():
 WS_LAYERS = {
     # (transposed, cin, cout, k, stride, pad), input shapes (n, h, w) the stationary kernel takes in at least one direction
     "k3": ((0, 128, 128, 3, 1, 1), [(2, 9, 16), (3, 20, 32), (2, 64, 64), (5, 16, 64), (70, 8, 16)]),
-    "k4s2": ((0, 64, 128, 4, 2, 1), [(2, 16, 32), (3, 12, 64), (2, 40, 128), (66, 8, 32)]),      # forward: strided gather
-    "t4s2": ((1, 128, 64, 4, 2, 1), [(2, 7, 16), (2, 9, 32), (3, 20, 64)]),                        # data gradient: the same gather
+    # forward: the strided gather (kind 4), data gradient: the transposed gather (kind 5)
+    "k4s2": ((0, 64, 128, 4, 2, 1), [(2, 16, 32), (3, 12, 64), (2, 40, 128), (66, 8, 32)]),
+    # forward: the transposed gather, data gradient: the strided one
+    "t4s2": ((1, 128, 64, 4, 2, 1), [(2, 7, 16), (2, 9, 32), (3, 20, 64), (40, 5, 16)]),
 }
 
 
@@ -311,10 +313,8 @@ def test_weights_stationary_kernels(layer, shape, act):
     assert G.rel_err(res[1][0], res[0][0]) < 8e-3 and G.rel_err(res[1][1], res[0][1]) < 8e-3
     assert np.mean(res[1][0] != res[0][0]) < 0.05 and np.mean(res[1][1] != res[0][1]) < 0.05
     # ... and the stationary kernel did run where it should (otherwise the two results are bit-equal)
-    if layer in ("k3", "k4s2"):
-        assert not np.array_equal(res[1][0], res[0][0]), "the forward never reached the weights-stationary kernel"
-    if layer in ("k3", "t4s2"):
-        assert not np.array_equal(res[1][1], res[0][1]), "the data gradient never reached the weights-stationary kernel"
+    assert not np.array_equal(res[1][0], res[0][0]), "the forward never reached the weights-stationary kernel"
+    assert not np.array_equal(res[1][1], res[0][1]), "the data gradient never reached the weights-stationary kernel"
 
 
 @pytest.mark.parametrize("ws_on", [1, 0], ids=["stationary", "tiled"])

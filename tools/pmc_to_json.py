@@ -47,6 +47,8 @@ def label(name):
         return "ws3_f32_kernel[C128->128 k3s1]"
     if name.startswith("ws4_bf16_kernel"):
         return "ws4_bf16_kernel"
+    if name.startswith("wst_bf16_kernel"):
+        return "ws5_bf16_kernel"
     if name.startswith("ws3_bf16_kernel"):
         return "ws3_bf16_kernel[C128->128 k3s1]"
     if name.startswith("wgrad_bf16_kernel<3, 3, 1, 2, 2, 2, 2, 4"):
