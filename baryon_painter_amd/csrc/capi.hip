@@ -221,16 +221,26 @@ int bp_conv_backward_data_stats(const bp_conv* cv, const bp_view* dy, const floa
 }
 
 size_t bp_conv_backward_data_act_workspace(const bp_conv* cv, const bp_view* dy, const bp_view* g) {
-  if (!conv_ok(cv) || !shapes_ok(cv, g, dy)) return 0;
+  const bool b16 = g && g->dtype == BP_BF16;              // the bf16 kernel's epilogue (conv_bf16_head.hip)
+  if (!conv_ok(cv) || !shapes_ok(cv, g, dy, b16)) return 0;
+  if (b16) return bp_bf16_stats_workspace(bp_geom_backward_data(cv), dy, g, 3);
   return bp_igemm_stats_workspace(bp_geom_backward_data(cv), dy, g, 3);
 }
 
 int bp_conv_backward_data_act(const bp_conv* cv, const bp_view* dy, const float* packed_bwd, const bp_view* g,
                               const bp_view* x_raw, const bp_pointwise* x_pw, double* sums, void* workspace,
                               size_t workspace_bytes, void* stream) {
-  if (!conv_ok(cv) || !shapes_ok(cv, g, dy) || !packed_bwd || !sums || !bp_view_ok(x_raw)) return BP_EINVAL;
+  const bool b16 = g && g->dtype == BP_BF16;
+  if (!conv_ok(cv) || !shapes_ok(cv, g, dy, b16) || !packed_bwd || !sums || !bp_view_ok_any(x_raw)) return BP_EINVAL;
   if (x_raw->n != g->n || x_raw->h != g->h || x_raw->w != g->w || x_raw->c != g->c) return BP_EINVAL;
   const IgemmStatsReq sr{3, x_raw, bp_pw(x_pw), sums, workspace, workspace_bytes};
+  if (b16) {
+    // (only the head kernel has this epilogue: the generic bf16 kernel would ignore the request)
+    const ConvGeom gm = bp_geom_backward_data(cv);
+    if (!bp_bf16_stats_workspace(gm, dy, g, 3)) return BP_EUNSUPPORTED;
+    return bp_bf16_igemm_run(gm, dy, PW{nullptr, nullptr, nullptr}, packed_bwd, nullptr, g, bp_stream(stream), &sr);
+  }
+  if (!bp_view_ok(x_raw)) return BP_EINVAL;
   return bp_igemm_run(bp_geom_backward_data(cv), dy, PW{nullptr, nullptr, nullptr}, packed_bwd, nullptr, g,
                       bp_stream(stream), &sr);
 }

@@ -25,6 +25,14 @@ size_t bp_bf16_ws_stats_workspace(const ConvGeom& g, const bp_view* in, const bp
 int bp_bf16_ws_run(const ConvGeom& g, const bp_view* in, const PW& pw, const u16* packed_ws, const bp_view* out,
                    hipStream_t st, const IgemmStatsReq* sr);
 
+// conv_bf16_head.hip: data gradient (+ activation backward) of the heads' 8 -> 1 k5 layer; its weight image comes last
+int64_t bp_bf16_head_packed_elems(const ConvGeom& g);
+int bp_bf16_head_pack(const ConvGeom& g, const WeightMap& wm, const float* w_torch, u16* dst, hipStream_t st);
+bool bp_bf16_head_ok(const ConvGeom& g, const bp_view* in, const bp_view* out, const float* bias, int mode);
+size_t bp_bf16_head_stats_workspace(const ConvGeom& g, const bp_view* in, const bp_view* out, int mode);
+int bp_bf16_head_run(const ConvGeom& g, const bp_view* in, const u16* packed_head, const bp_view* out, hipStream_t st,
+                     const IgemmStatsReq* sr);
+
 namespace {
 
 struct BPackArgs {
@@ -93,12 +101,12 @@ static int64_t generic_packed_elems(const ConvGeom& g, const BConfig& c) {
   return (int64_t)g.nphase * g.nphase * g.taps * c.nrun * c.nchunk * c.cout_padP * 32;
 }
 
-// [generic image | flattened-K image (conv_bf16_flat.hip) | weights-stationary image (conv_bf16_ws.hip)], the last
-// two where those kernels apply
+// [generic image | flattened-K image (conv_bf16_flat.hip) | weights-stationary image (conv_bf16_ws.hip) | head image
+// (conv_bf16_head.hip)], the last three where those kernels apply
 int64_t bp_bf16_packed_elems(const ConvGeom& g) {
   const BConfig c = b_config(g);
   if (!c.ok) return -1;
-  return generic_packed_elems(g, c) + bp_bf16_flat_packed_elems(g) + bp_bf16_ws_packed_elems(g);
+  return generic_packed_elems(g, c) + bp_bf16_flat_packed_elems(g) + bp_bf16_ws_packed_elems(g) + bp_bf16_head_packed_elems(g);
 }
 
 int bp_bf16_pack(const ConvGeom& g, const WeightMap& wm, const float* w_torch, void* packed, hipStream_t st) {
@@ -117,7 +125,12 @@ int bp_bf16_pack(const ConvGeom& g, const WeightMap& wm, const float* w_torch, v
     const int rc = bp_bf16_flat_pack(g, wm, w_torch, a.dst + a.total, st);
     if (rc != BP_OK) return rc;
   }
-  if (bp_bf16_ws_packed_elems(g) > 0) return bp_bf16_ws_pack(g, wm, w_torch, a.dst + a.total + bp_bf16_flat_packed_elems(g), st);
+  if (bp_bf16_ws_packed_elems(g) > 0) {
+    const int rc = bp_bf16_ws_pack(g, wm, w_torch, a.dst + a.total + bp_bf16_flat_packed_elems(g), st);
+    if (rc != BP_OK) return rc;
+  }
+  if (bp_bf16_head_packed_elems(g) > 0)
+    return bp_bf16_head_pack(g, wm, w_torch, a.dst + a.total + bp_bf16_flat_packed_elems(g) + bp_bf16_ws_packed_elems(g), st);
   return BP_OK;
 }
 
@@ -133,9 +146,11 @@ static int64_t bf16_stat_rows(const ConvGeom& g, const BConfig& c, const bp_view
 // workspace for bp_bf16_igemm_run with statistics (0: not available for this layer / these views)
 size_t bp_bf16_stats_workspace(const ConvGeom& g, const bp_view* in, const bp_view* out, int mode) {
   const BConfig c = b_config(g);
-  if (!c.ok || !bp_bf16_igemm_ok(g, in, out)) return 0;
+  if (!c.ok) return 0;
+  if (mode == 3) return bp_bf16_head_stats_workspace(g, in, out, mode);      // (activation backward: the head kernel only)
+  if (!bp_bf16_igemm_ok(g, in, out)) return 0;
   if (bp_bf16_flat_ok(g, in, out, nullptr, mode)) return bp_bf16_flat_stats_workspace(g, in, out, mode);
-  if (mode != 1) return 0;                                    // (mode 2: the two flattened-K kernels only)
+  if (mode != 1) return 0;                                    // (mode 2: the flattened-K kernels only)
   const size_t generic = bp_stats_rows_bytes(bf16_stat_rows(g, c, in, out), g.cout_g);
   if (bp_bf16_ws_ok(g, in, out, nullptr, mode)) {        // (the larger of the two: bp_set_option may switch kernels later)
     const size_t ws = bp_bf16_ws_stats_workspace(g, in, out);
@@ -147,7 +162,12 @@ size_t bp_bf16_stats_workspace(const ConvGeom& g, const bp_view* in, const bp_vi
 int bp_bf16_igemm_run(const ConvGeom& g, const bp_view* in, const PW& pw, const void* packed, const float* bias,
                       const bp_view* out, hipStream_t st, const IgemmStatsReq* sr) {
   const BConfig c = b_config(g);
-  if (!c.ok || !bp_bf16_igemm_ok(g, in, out)) return BP_EUNSUPPORTED;
+  if (!c.ok) return BP_EUNSUPPORTED;
+  // (the head kernel reads its one gathered channel with scalar loads: any channel stride)
+  if (!pw.scale && bp_bf16_head_ok(g, in, out, bias, sr ? sr->mode : 0))
+    return bp_bf16_head_run(g, in, reinterpret_cast<const u16*>(packed) + generic_packed_elems(g, c) +
+                            bp_bf16_flat_packed_elems(g) + bp_bf16_ws_packed_elems(g), out, st, sr);
+  if (!bp_bf16_igemm_ok(g, in, out)) return BP_EUNSUPPORTED;
   if (bp_bf16_flat_ok(g, in, out, bias, sr ? sr->mode : 0))
     return bp_bf16_flat_run(g, in, pw, reinterpret_cast<const u16*>(packed) + generic_packed_elems(g, c), out, st, sr);
   if (bp_bf16_ws_ok(g, in, out, bias, sr ? sr->mode : 0))

@@ -1050,8 +1050,10 @@ __global__ __launch_bounds__(256) void flatb_pack_kernel(FbPackArgs a) {
 }
 
 // which instance serves this geometry: 0 none, 1 k7 16->8, 2 k7 8->16, 3 k5 3(4)->16 (stem forward), 4 k5 16->(1..4),
-// 5 stride-2 k4 transposed form 32->16, 6 stride-2 k4 conv form 16->32
+// 5 stride-2 k4 transposed form 32->16, 6 stride-2 k4 conv form 16->32, 7 / 8 the same for 64->32 / 32->64,
+// 9 k5 8->(1..4) (second layer of the heads, bf16 in)
 struct FbKind { int kind, ks, cinp, coutp; };
+static inline bool fb_s2(int kind) { return kind >= 5 && kind <= 8; }
 static FbKind fb_kind(const ConvGeom& g) {
   static const bool off = getenv("BP_BF16_NOFLAT") != nullptr;
   static const bool off5 = getenv("BP_BF16_NOFLAT5") != nullptr;
@@ -1073,6 +1075,8 @@ static FbKind fb_kind(const ConvGeom& g) {
   if (g.k == 7 && g.cin_g == 8 && g.cout_g == 16) return FbKind{2, 7, 8, 16};
   if (g.k == 5 && !off5 && g.cin_g <= 4 && g.cin_g >= 1 && g.cout_g == 16) return FbKind{3, 5, 4, 16};
   if (g.k == 5 && !off5 && g.cin_g == 16 && g.cout_g >= 1 && g.cout_g <= 4) return FbKind{4, 5, 16, 4};
+  static const bool off9 = getenv("BP_BF16_NOFLAT9") != nullptr;
+  if (g.k == 5 && !off9 && g.cin_g == 8 && g.cout_g >= 1 && g.cout_g <= 4 && !g.gather_transposed) return FbKind{9, 5, 8, 4};
   return none;
 }
 
@@ -1092,8 +1096,8 @@ static void fb_launch(const FbArgs& a, dim3 grid, hipStream_t st) {
 int64_t bp_bf16_flat_packed_elems(const ConvGeom& g) {
   const FbKind f = fb_kind(g);
   if (!f.kind) return 0;
-  if (f.kind >= 7) return 64 * 512;
-  if (f.kind >= 5) return 16 * 512;
+  if (f.kind == 7 || f.kind == 8) return 64 * 512;
+  if (fb_s2(f.kind)) return 16 * 512;
   const int KB = (f.ks * f.cinp + 31) / 32, NP = f.ks + 16 / f.coutp - 1;
   return (int64_t)NP * KB * 64 * 8;
 }
@@ -1101,7 +1105,7 @@ int64_t bp_bf16_flat_packed_elems(const ConvGeom& g) {
 int bp_bf16_flat_pack(const ConvGeom& g, const WeightMap& wm, const float* w_torch, u16* dst, hipStream_t st) {
   const FbKind f = fb_kind(g);
   if (!f.kind) return BP_EUNSUPPORTED;
-  if (f.kind >= 5) {
+  if (fb_s2(f.kind)) {
     FtPackArgs t{w_torch, dst, wm.sa, wm.sb};
     if (f.kind == 5) hipLaunchKernelGGL(flatb_t2_pack_kernel, dim3(32), dim3(256), 0, st, t);
     else if (f.kind == 6) hipLaunchKernelGGL(flatb_s2_pack_kernel, dim3(32), dim3(256), 0, st, t);
@@ -1148,13 +1152,15 @@ bool bp_bf16_flat_ok(const ConvGeom& g, const bp_view* in, const bp_view* out, c
   const FbKind f = fb_kind(g);
   if (!f.kind || bias || !in || !out) return false;
   static const bool m2wide = !(getenv("BP_BF16_M2_WIDE") && atoi(getenv("BP_BF16_M2_WIDE")) == 0);
-  if (f.kind >= 5) return f2_ok(f, in, out) && (stats != 2 || f.kind == 5 || (m2wide && f.kind != 8));
+  if (fb_s2(f.kind)) return f2_ok(f, in, out) && (stats != 2 || f.kind == 5 || (m2wide && f.kind != 8));
   if (stats == 1 && f.kind != 3) return false;
   if (stats == 2 && f.kind != 2) return false;
+  if (stats > 2) return false;
   if (in->c != g.cin_g || out->c != g.cout_g || in->h != out->h || in->w != out->w || in->n != out->n) return false;
   const bool ib = in->dtype == BP_BF16, ob = out->dtype == BP_BF16;
-  // element types of the instances: the bf16 trunk on one side, the fp32 few-channel edge on the other
-  if ((f.kind == 1 || f.kind == 4) ? !(ib && !ob) : !(!ib && ob)) return false;
+  // element types of the instances: the bf16 trunk on one side; the few-channel edge on the other is fp32, or bf16 where
+  // the 8-channel slot of a head is stored as bf16 (kinds 1, 2)
+  if (f.kind == 1 ? !ib : f.kind == 2 ? !ob : (f.kind == 4 || f.kind == 9) ? !(ib && !ob) : !(!ib && ob)) return false;
   if (reinterpret_cast<uintptr_t>(in->ptr) % 16 || reinterpret_cast<uintptr_t>(out->ptr) % 16) return false;
   // staged units: 8 channels (16 bytes of bf16 / two float4) or, for the 4-channel stem, one float4 per pixel
   if (f.kind == 3) {
@@ -1167,7 +1173,7 @@ bool bp_bf16_flat_ok(const ConvGeom& g, const bp_view* in, const bp_view* out, c
 size_t bp_bf16_flat_stats_workspace(const ConvGeom& g, const bp_view* in, const bp_view* out, int mode) {
   if (!bp_bf16_flat_ok(g, in, out, nullptr, mode)) return 0;
   const FbKind f = fb_kind(g);
-  if (f.kind >= 5) {
+  if (fb_s2(f.kind)) {
     int tx, ty;
     return bp_stats_rows_bytes(f2_tiles(f.kind, in, out, &tx, &ty), g.cout_g);
   }
@@ -1177,7 +1183,7 @@ size_t bp_bf16_flat_stats_workspace(const ConvGeom& g, const bp_view* in, const 
 int bp_bf16_flat_run(const ConvGeom& g, const bp_view* in, const PW& pw, const u16* packed_flat, const bp_view* out,
                      hipStream_t st, const IgemmStatsReq* sr) {
   const FbKind f = fb_kind(g);
-  if (f.kind >= 5) {
+  if (fb_s2(f.kind)) {
     int tx, ty;
     const int64_t rows = f2_tiles(f.kind, in, out, &tx, &ty);
     double* stat = nullptr;
@@ -1262,11 +1268,20 @@ int bp_bf16_flat_run(const ConvGeom& g, const bp_view* in, const PW& pw, const u
     }
   }
   const dim3 grid((unsigned)rows);
+  const bool ib = in->dtype == BP_BF16, ob = out->dtype == BP_BF16;
   switch (f.kind) {
-    case 1: fb_launch<7, 16, 8, true, false, 0>(a, grid, st); break;
-    case 2: if (sr) fb_launch<7, 8, 16, false, true, 2>(a, grid, st);
-            else fb_launch<7, 8, 16, false, true, 0>(a, grid, st);
+    case 1: if (ob) fb_launch<7, 16, 8, true, true, 0>(a, grid, st);
+            else fb_launch<7, 16, 8, true, false, 0>(a, grid, st);
             break;
+    case 2: if (ib) {
+              if (sr) fb_launch<7, 8, 16, true, true, 2>(a, grid, st);
+              else fb_launch<7, 8, 16, true, true, 0>(a, grid, st);
+            } else {
+              if (sr) fb_launch<7, 8, 16, false, true, 2>(a, grid, st);
+              else fb_launch<7, 8, 16, false, true, 0>(a, grid, st);
+            }
+            break;
+    case 9: fb_launch<5, 8, 4, true, false, 0>(a, grid, st); break;
     case 3: if (sr) fb_launch<5, 4, 16, false, true, 1>(a, grid, st);
             else fb_launch<5, 4, 16, false, true, 0>(a, grid, st);
             break;

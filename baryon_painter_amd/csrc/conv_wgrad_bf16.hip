@@ -515,7 +515,7 @@ int wb_launch(const bp_conv* cv, const bp_view* X, const PW& pwx, const bp_view*
 //     tap meet through LDS, partials go to the workspace layout of conv_wgrad.hip (fixed-order reduce).
 struct WfArgs {
   const u16* X; int h, w, xcs, xco;
-  const float* Y; int ycs, yco;
+  const void* Y; int ycs, yco;          // fp32, or bf16 where the head's 8-channel slot is stored as bf16 (YB)
   int n;
   PW pwx;
   float* ws;
@@ -528,6 +528,7 @@ constexpr size_t WF_RED = (size_t)(WF_K + 1) * WF_K * 256 * sizeof(float);
 constexpr size_t WF_TILES = (size_t)(WF_XE + WF_YE) * 2 > WF_RED ? (size_t)(WF_XE + WF_YE) * 2 : WF_RED;
 constexpr size_t WF_LDS = WF_TILES + 3 * 16 * sizeof(float);
 
+template <bool YB>
 __global__ __launch_bounds__(256, 2) void wgrad_flatb_k7_kernel(WfArgs a) {
   extern __shared__ __attribute__((aligned(16))) u16 smem[];
   u16* xs = smem;
@@ -563,7 +564,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_flatb_k7_kernel(WfArgs a) {
     const int ty0 = (tr / a.tiles_x) * WF_TH, tx0 = (tr % a.tiles_x) * WF_TW;
     // ---- loads first (all in flight, raw words, clamped coordinates), then convert into LDS
     uint4 xr[XS];
-    float4 yr[YS][2];
+    float4 yr[YS][YB ? 1 : 2];
     unsigned xin = 0, yin = 0;
     const int64_t ximg = (int64_t)n * a.h * a.w * a.xcs + a.xco + cu * 8;
 #pragma unroll
@@ -583,9 +584,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_flatb_k7_kernel(WfArgs a) {
       const int gy = ty0 + row, gx = tx0 + px;
       if (gy < a.h && gx < a.w) yin |= 1u << i;
       const int cy = min(gy, a.h - 1), cx = min(gx, a.w - 1);
-      const float* q = a.Y + yimg + ((int64_t)cy * a.w + cx) * a.ycs;
-      yr[i][0] = *reinterpret_cast<const float4*>(q);
-      yr[i][1] = *reinterpret_cast<const float4*>(q + 4);
+      const int64_t yo = yimg + ((int64_t)cy * a.w + cx) * a.ycs;
+      if constexpr (YB) {
+        yr[i][0] = *reinterpret_cast<const float4*>(reinterpret_cast<const u16*>(a.Y) + yo);
+      } else {
+        const float* q = reinterpret_cast<const float*>(a.Y) + yo;
+        yr[i][0] = *reinterpret_cast<const float4*>(q);
+        yr[i][1] = *reinterpret_cast<const float4*>(q + 4);
+      }
     }
     __syncthreads();                            // the previous tile's readers are done with the images
 #pragma unroll
@@ -609,9 +615,15 @@ __global__ __launch_bounds__(256, 2) void wgrad_flatb_k7_kernel(WfArgs a) {
       const int e = tid + i * 256;
       const int row = e / WF_TW, px = e - row * WF_TW;
       const bool ok = (yin >> i) & 1u;
-      const float v[8] = {ok ? yr[i][0].x : 0.f, ok ? yr[i][0].y : 0.f, ok ? yr[i][0].z : 0.f, ok ? yr[i][0].w : 0.f,
-                          ok ? yr[i][1].x : 0.f, ok ? yr[i][1].y : 0.f, ok ? yr[i][1].z : 0.f, ok ? yr[i][1].w : 0.f};
-      lds_store_unit<8>(ys + (((row >> 1) * WF_TW + px) * 16) + (row & 1) * 8, v);       // row pairs interleaved
+      u16* yd = ys + (((row >> 1) * WF_TW + px) * 16) + (row & 1) * 8;                   // row pairs interleaved
+      if constexpr (YB) {
+        const uint4 w = __builtin_bit_cast(uint4, yr[i][0]);
+        *reinterpret_cast<uint4*>(yd) = ok ? w : make_uint4(0u, 0u, 0u, 0u);
+      } else {
+        const float v[8] = {ok ? yr[i][0].x : 0.f, ok ? yr[i][0].y : 0.f, ok ? yr[i][0].z : 0.f, ok ? yr[i][0].w : 0.f,
+                            ok ? yr[i][1].x : 0.f, ok ? yr[i][1].y : 0.f, ok ? yr[i][1].z : 0.f, ok ? yr[i][1].w : 0.f};
+        lds_store_unit<8>(yd, v);
+      }
     }
     __syncthreads();
     // ---- multiply: this wave's two pairs over the whole tile
@@ -655,10 +667,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_flatb_k7_kernel(WfArgs a) {
 static bool wf_ok(const bp_conv* cv, const bp_view* X, const bp_view* Y, const PW& pwy) {
   static const bool off = getenv("BP_BF16_NOFLATW") != nullptr;
   if (off || cv->transposed || cv->k != WF_K || cv->stride != 1 || cv->pad != 3 || X->c != 16 || Y->c != 8) return false;
-  if (X->dtype != BP_BF16 || Y->dtype != BP_F32 || pwy.scale) return false;
+  if (X->dtype != BP_BF16 || pwy.scale) return false;
   if (X->h != Y->h || X->w != Y->w || X->n != Y->n) return false;
   if ((X->cstride * 2) % 16 || (X->coff * 2) % 16 || reinterpret_cast<uintptr_t>(X->ptr) % 16) return false;
-  if (Y->cstride % 4 || Y->coff % 4 || reinterpret_cast<uintptr_t>(Y->ptr) % 16) return false;
+  const int yv = Y->dtype == BP_BF16 ? 8 : 4;         // channels per vector load of dY
+  if (Y->cstride % yv || Y->coff % yv || reinterpret_cast<uintptr_t>(Y->ptr) % 16) return false;
   return true;
 }
 
@@ -666,7 +679,7 @@ static int wf_launch(const bp_view* X, const PW& pwx, const bp_view* Y, float* w
                      int* nsplit_out, int* cxp, int* cyp, hipStream_t st, bool dry) {
   WfArgs a{};
   a.X = reinterpret_cast<const u16*>(X->ptr); a.h = X->h; a.w = X->w; a.xcs = X->cstride; a.xco = X->coff;
-  a.Y = reinterpret_cast<const float*>(Y->ptr); a.ycs = Y->cstride; a.yco = Y->coff;
+  a.Y = Y->ptr; a.ycs = Y->cstride; a.yco = Y->coff;
   a.n = X->n; a.pwx = pwx; a.ws = ws;
   a.tiles_x = bp_ceil_div(X->w, WF_TW); a.tiles_y = bp_ceil_div(X->h, WF_TH);
   const int64_t ntiles = (int64_t)a.tiles_x * a.tiles_y * a.n;
@@ -675,10 +688,13 @@ static int wf_launch(const bp_view* X, const PW& pwx, const bp_view* Y, float* w
   *nsplit_out = ns; *cxp = 16; *cyp = 8;
   if (dry) return BP_OK;
   if (!ws || ws_bytes < *need) return BP_EWORKSPACE;
-  static const hipError_t optin = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_flatb_k7_kernel),
+  static const hipError_t optin = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_flatb_k7_kernel<false>),
                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)WF_LDS);
-  if (optin != hipSuccess) return BP_ELAUNCH;
-  hipLaunchKernelGGL(wgrad_flatb_k7_kernel, dim3((unsigned)ns), dim3(256), WF_LDS, st, a);
+  static const hipError_t optin_b = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_flatb_k7_kernel<true>),
+                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)WF_LDS);
+  if (optin != hipSuccess || optin_b != hipSuccess) return BP_ELAUNCH;
+  if (Y->dtype == BP_BF16) hipLaunchKernelGGL(wgrad_flatb_k7_kernel<true>, dim3((unsigned)ns), dim3(256), WF_LDS, st, a);
+  else hipLaunchKernelGGL(wgrad_flatb_k7_kernel<false>, dim3((unsigned)ns), dim3(256), WF_LDS, st, a);
   BP_CHECK_LAUNCH();
   return BP_OK;
 }
@@ -852,6 +868,179 @@ static int sf_launch(const bp_view* X, const PW& pwx, const bp_view* Y, float* w
   return BP_OK;
 }
 
+// ---------------------------------------------------------------------------------------------- k5 head tail, 8 -> 1
+// Weight gradient of the heads' second layer (unit-stride k5, the head's 8-channel bf16 slot in, ONE fp32 gradient channel
+// out; architecture_built.txt:104): a matrix-VECTOR product per tap -- on the vector ALUs (wgrad_cy1_kernel<5, 8, 16>) 0.26 ms
+// for 0.3 GB.  Matrix form, K = 32 pixels of a row:
+//   * MFMA rows = 16 consecutive bf16 of the staged X row [pixel][8] = (column select s = 0, 1; channel c) of pixels
+//     x + kxb + s -- the transposing read starts at ANY pixel, so the three tap-column bases kxb = 0, 2, 4 cover kx = 0..5;
+//   * MFMA columns = tap row ky: for X row i the gradient rows i - ky, plain 8-byte reads of the [row][pixel] bf16 image of
+//     dy (one channel: K-contiguous as stored), zero rows around the tile; columns 5..15 repeat ky = 4 and are dropped.
+// 3 accumulators per wave for all 25 taps; the waves split the X rows and meet through LDS; persistent workgroups, one
+// partial each, fixed-order reduce (conv_wgrad.hip).
+struct WhArgs {
+  const u16* X; int h, w, xcs, xco;
+  const float* Y; int ycs, yco;
+  int n;
+  PW pwx;
+  float* ws;
+  int tiles_x, tiles_y;
+};
+
+constexpr int WH_K = 5, WH_C = 8, WH_TW = 64, WH_TH = 16, WH_LW = WH_TW + WH_K - 1, WH_LH = WH_TH + WH_K - 1;
+constexpr int WH_XE = WH_LH * WH_LW * WH_C + 64;          // (+ slack: the last tap-column base reads two pixels on)
+constexpr int WH_YR = WH_TH + 2 * (WH_K - 1), WH_YE = WH_YR * WH_TW;
+constexpr size_t WH_RED = (size_t)4 * 3 * 256 * sizeof(float);
+constexpr size_t WH_TILES = (size_t)(WH_XE + WH_YE) * 2 > WH_RED ? (size_t)(WH_XE + WH_YE) * 2 : WH_RED;
+constexpr size_t WH_LDS = WH_TILES + 3 * WH_C * sizeof(float);
+
+__global__ __launch_bounds__(256, 2) void wgrad_head_kernel(WhArgs a) {
+  extern __shared__ __attribute__((aligned(16))) u16 smem[];
+  u16* xs = smem;
+  u16* ys = smem + WH_XE;
+  float* lpw = reinterpret_cast<float*>(reinterpret_cast<char*>(smem) + WH_TILES);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, kq = lane >> 4;
+  const int trl = (4 * kq + (li >> 2)) * WH_C + 4 * (li & 3);      // [pixel][8] image: 16 elements = pixels P, P + 1
+
+  const bool on = a.pwx.scale != nullptr;
+  if (tid < WH_C) {
+    lpw[tid] = on ? a.pwx.scale[tid] : 1.f; lpw[WH_C + tid] = on ? a.pwx.shift[tid] : 0.f; lpw[2 * WH_C + tid] = on ? a.pwx.slope[tid] : 1.f;
+  }
+  // the slack behind the X image and the zero rows of the dy image stay zero for every tile
+  for (int e = tid; e < 64 / 8; e += 256) *reinterpret_cast<uint4*>(xs + WH_LH * WH_LW * WH_C + e * 8) = make_uint4(0u, 0u, 0u, 0u);
+  for (int e = tid; e < WH_YE / 8; e += 256) *reinterpret_cast<uint4*>(ys + e * 8) = make_uint4(0u, 0u, 0u, 0u);
+  __syncthreads();
+  float sc[8], sf[8], sl[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { sc[j] = lpw[j]; sf[j] = lpw[WH_C + j]; sl[j] = lpw[2 * WH_C + j]; }
+
+  v4f acc[3];
+#pragma unroll
+  for (int b = 0; b < 3; ++b) acc[b] = v4f{0.f, 0.f, 0.f, 0.f};
+
+  constexpr int NUX = WH_LH * WH_LW, XS = (NUX + 255) / 256;          // pixels of the X halo tile (16 bytes each)
+  constexpr int YS = WH_TH * WH_TW / 256;                             // pixels of the dy tile per thread
+  const int per_img = a.tiles_x * a.tiles_y;
+  const int ntiles = per_img * a.n;
+  const int kyl = min(li, WH_K - 1);                                  // this lane's tap row (MFMA column)
+  for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    const int n = t / per_img, tr = t - n * per_img;
+    const int ty0 = (tr / a.tiles_x) * WH_TH, tx0 = (tr % a.tiles_x) * WH_TW;
+    uint4 xr[XS];
+    float yr[YS];
+    unsigned xin = 0;
+    const int64_t ximg = (int64_t)n * a.h * a.w * a.xcs + a.xco;
+#pragma unroll
+    for (int i = 0; i < XS; ++i) {
+      const int e = tid + i * 256;
+      const int row = e / WH_LW, px = e - row * WH_LW;
+      const int gy = ty0 - 2 + row, gx = tx0 - 2 + px;
+      if (e < NUX && gy >= 0 && gy < a.h && gx >= 0 && gx < a.w) xin |= 1u << i;
+      const int cy = min(max(gy, 0), a.h - 1), cx = min(max(gx, 0), a.w - 1);
+      xr[i] = *reinterpret_cast<const uint4*>(a.X + ximg + ((int64_t)cy * a.w + cx) * a.xcs);
+    }
+    const int64_t yimg = (int64_t)n * a.h * a.w * a.ycs + a.yco;
+#pragma unroll
+    for (int i = 0; i < YS; ++i) {
+      const int e = tid + i * 256;
+      const int row = e / WH_TW, px = e - row * WH_TW;
+      const int gy = ty0 + row, gx = tx0 + px;
+      const int cy = min(gy, a.h - 1), cx = min(gx, a.w - 1);
+      const float v = a.Y[yimg + ((int64_t)cy * a.w + cx) * a.ycs];
+      yr[i] = (gy < a.h && gx < a.w) ? v : 0.f;
+    }
+    __syncthreads();                            // the previous tile's readers are done with the images
+#pragma unroll
+    for (int i = 0; i < XS; ++i) {
+      const int e = tid + i * 256;
+      if (e >= NUX) continue;
+      const unsigned w[4] = {xr[i].x, xr[i].y, xr[i].z, xr[i].w};
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { v[2 * j] = bf2f((u16)(w[j] & 0xffffu)); v[2 * j + 1] = bf2f((u16)(w[j] >> 16)); }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float x = v[j];
+        if (on) { x = fmaf(x, sc[j], sf[j]); x = x > 0.f ? x : x * sl[j]; }
+        v[j] = ((xin >> i) & 1u) ? x : 0.f;
+      }
+      lds_store_unit<8>(xs + e * 8, v);
+    }
+#pragma unroll
+    for (int i = 0; i < YS; ++i) {
+      const int e = tid + i * 256;
+      ys[(WH_K - 1) * WH_TW + e] = f2bf(yr[i]);           // tile row r lives in image row r + 4
+    }
+    __syncthreads();
+    // ---- multiply: X rows i = wave, wave + 4, ... (image row ty0 - 2 + i); tap row ky pairs it with tile row i - ky
+#pragma unroll 1
+    for (int i = wave; i < WH_LH; i += 4) {
+#pragma unroll
+      for (int seg = 0; seg < WH_TW / 32; ++seg) {
+        const u16* py = ys + (i - kyl + WH_K - 1) * WH_TW + seg * 32 + 4 * kq;
+        const uint2 y0 = *reinterpret_cast<const uint2*>(py), y1 = *reinterpret_cast<const uint2*>(py + 16);
+        const bf8 yf = __builtin_bit_cast(bf8, make_uint4(y0.x, y0.y, y1.x, y1.y));
+        const u16* px_ = xs + (i * WH_LW + seg * 32) * WH_C + trl;
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+          const bf8 xf = frag_of(lds_tr(px_ + 2 * b * WH_C), lds_tr(px_ + (2 * b + 16) * WH_C));
+          acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf, yf, acc[b], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // ---- waves meet through LDS: red[wave][b][row m = 4 kq + r = (s, c)][column li = ky]
+  __syncthreads();
+  float* red = reinterpret_cast<float*>(smem);
+#pragma unroll
+  for (int b = 0; b < 3; ++b)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[((wave * 3 + b) * 16 + 4 * kq + r) * 16 + li] = acc[b][r];
+  __syncthreads();
+  float* out = a.ws + (int64_t)blockIdx.x * WH_K * WH_K * WH_C;               // [ky][kx][1][ci]
+  for (int e = tid; e < WH_K * WH_K * WH_C; e += 256) {
+    const int ci = e & 7, tap = e >> 3;
+    const int ky = tap / WH_K, kx = tap - ky * WH_K;
+    const int b = kx >> 1, s_ = kx & 1;
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) v += red[((w * 3 + b) * 16 + s_ * 8 + ci) * 16 + ky];
+    out[e] = v;
+  }
+}
+
+static bool wh_ok(const bp_conv* cv, const bp_view* X, const bp_view* Y, const PW& pwy) {
+  static const bool off = getenv("BP_BF16_NOHEADW") != nullptr;
+  if (off || cv->transposed || cv->k != WH_K || cv->stride != 1 || cv->pad != 2 || X->c != WH_C || Y->c != 1) return false;
+  if (X->dtype != BP_BF16 || Y->dtype != BP_F32 || pwy.scale) return false;
+  if (X->h != Y->h || X->w != Y->w || X->n != Y->n) return false;
+  if ((X->cstride * 2) % 16 || (X->coff * 2) % 16 || reinterpret_cast<uintptr_t>(X->ptr) % 16) return false;
+  return true;
+}
+
+static int wh_launch(const bp_view* X, const PW& pwx, const bp_view* Y, float* ws, size_t ws_bytes, size_t* need,
+                     int* nsplit_out, int* cxp, int* cyp, hipStream_t st, bool dry) {
+  WhArgs a{};
+  a.X = reinterpret_cast<const u16*>(X->ptr); a.h = X->h; a.w = X->w; a.xcs = X->cstride; a.xco = X->coff;
+  a.Y = reinterpret_cast<const float*>(Y->ptr); a.ycs = Y->cstride; a.yco = Y->coff;
+  a.n = X->n; a.pwx = pwx; a.ws = ws;
+  a.tiles_x = bp_ceil_div(X->w, WH_TW); a.tiles_y = bp_ceil_div(X->h, WH_TH);
+  const int64_t ntiles = (int64_t)a.tiles_x * a.tiles_y * a.n;
+  const int ns = (int)(ntiles < 512 ? ntiles : 512);                 // two persistent workgroups per CU
+  *need = (size_t)ns * WH_K * WH_K * WH_C * sizeof(float);
+  *nsplit_out = ns; *cxp = WH_C; *cyp = 1;
+  if (dry) return BP_OK;
+  if (!ws || ws_bytes < *need) return BP_EWORKSPACE;
+  static const hipError_t optin = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_head_kernel),
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)WH_LDS);
+  if (optin != hipSuccess) return BP_ELAUNCH;
+  hipLaunchKernelGGL(wgrad_head_kernel, dim3((unsigned)ns), dim3(256), WH_LDS, st, a);
+  BP_CHECK_LAUNCH();
+  return BP_OK;
+}
+
 // 16-byte loads of 8 channels need 16-byte aligned pixel rows; ragged channel counts take the scalar path
 bool wb_view_ok(const bp_view* v) {
   const int esz = v->dtype == BP_BF16 ? 2 : 4;
@@ -871,6 +1060,7 @@ int bp_wgrad_bf16(const bp_conv* cv, const bp_view* X, const PW& pwx, const bp_v
   if (!wb_view_ok(X) || !wb_view_ok(Y)) return BP_EUNSUPPORTED;
   if (wf_ok(cv, X, Y, pwy)) return wf_launch(X, pwx, Y, ws, ws_bytes, need, nsplit, cxp, cyp, st, dry);
   if (sf_ok(cv, X, Y, pwy)) return sf_launch(X, pwx, Y, ws, ws_bytes, need, nsplit, cxp, cyp, st, dry);
+  if (wh_ok(cv, X, Y, pwy)) return wh_launch(X, pwx, Y, ws, ws_bytes, need, nsplit, cxp, cyp, st, dry);
   {      // the output-stationary kernel of the 128 <-> 128 k3 trunk layers (conv_wgrad_ws_bf16.hip)
     const int rc = bp_wgrad_ws_bf16(cv, X, pwx, Y, pwy, ws, ws_bytes, need, nsplit, cxp, cyp, st, dry);
     if (rc == BP_OK && dry) {      // (size the workspace for either kernel: bp_set_option may switch later)

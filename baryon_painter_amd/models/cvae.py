@@ -213,17 +213,21 @@ class _Plan:
             for u in self._flat(self.p_units):
                 u.side_name = "c"
 
-    # ---- bf16 policy (dtype="bf16", BASELINE.json configs[3]).  The generator trunk p_y_z_in and the first layer of
-    # each head run on the bf16 matrix-core kernels and every p_y_z_in activation / gradient is stored as bf16: that
-    # is 92 % of the activation bytes of a step (SURVEY.md 8a totals).  The recognition / prior networks, p_z_in and
-    # the 8-, 1-channel tails of the heads stay fp32: together 8 % of the bytes, and their few-channel layers have
-    # no 16-byte bf16 vectors to move.  Parameters, gradients of parameters, batch-norm statistics and every loss
-    # reduction are fp32 / fp64 in both modes.
+    # ---- bf16 policy (dtype="bf16", BASELINE.json configs[3]).  The generator trunk p_y_z_in and the first two layers
+    # of each head run on the bf16 matrix-core kernels; every p_y_z_in activation / gradient and the heads' 8-channel
+    # slot (one 16-byte bf16 vector per pixel at 512^2: 0.27 GB instead of 0.54 GB per pass) are stored as bf16: 96 %
+    # of the activation bytes of a step (SURVEY.md 8a totals).  The recognition / prior networks, p_z_in and the
+    # 1-channel tails of the heads stay fp32.  Parameters, gradients of parameters, batch-norm statistics and every
+    # loss reduction are fp32 / fp64 in both modes.  BP_BF16_HEAD_TAIL=0: the round-3 policy (8-channel slot in fp32,
+    # second head layer on the vector ALUs).
+    _HEAD_TAIL = os.environ.get("BP_BF16_HEAD_TAIL", "1") != "0"
+
     def bf16_unit(self, name):
-        return self.bf16 and (name.startswith("p_y_z_in.") or name in ("p_mu_out.0", "p_var_out.0"))
+        return self.bf16 and (name.startswith("p_y_z_in.") or name in ("p_mu_out.0", "p_var_out.0")
+                              or (self._HEAD_TAIL and name in ("p_mu_out.2", "p_var_out.2")))
 
     def bf16_out(self, name):
-        return self.bf16 and name.startswith("p_y_z_in.")
+        return self.bf16 and (name.startswith("p_y_z_in.") or (self._HEAD_TAIL and name in ("p_mu_out.0", "p_var_out.0")))
 
     # ---- helpers
     @staticmethod

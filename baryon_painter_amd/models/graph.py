@@ -566,7 +566,8 @@ class ConvUnit:
                 and os.environ.get("BP_BF16_BWD_STATS", "1") != "0":
             self.plan.need_ws(lib.bp_conv_stats_workspace(C.byref(self.cv), L.PACK_BWD, C.byref(self.inp.view),
                                                           C.byref(self.out.view), L.IMPL_BF16))
-        if self.dx is not None and self._sub is None and EPILOGUE_BWD and not self.bf16 and self.inp.dt == L.F32:
+        if self.dx is not None and self._sub is None and EPILOGUE_BWD \
+                and ((not self.bf16 and self.inp.dt == L.F32) or (self.bf16 and self.inp.dt == L.BF16 and self.out.dt == L.F32)):
             self.plan.need_ws(lib.bp_conv_backward_data_act_workspace(C.byref(self.cv), C.byref(self.out.view),
                                                                       C.byref(self.inp.view)))
         if self.dx is not None and self._sub is not None and self._sub["target"] is None:
@@ -685,16 +686,18 @@ class ConvUnit:
 
     def _producer_act_to_fuse(self):
         """The producer WITHOUT batch-norm whose whole activation backward this layer's data gradient can do in its
-        epilogue (bp_conv_backward_data_act): only producer / only consumer of ``inp``, fp32, and a kernel that has
-        the epilogue (the vector-ALU data gradient of the heads' 8 -> 1 k5 layer)."""
+        epilogue (bp_conv_backward_data_act): only producer / only consumer of ``inp`` and a kernel that has the
+        epilogue (the data gradient of the heads' 8 -> 1 k5 layer: on the vector ALUs between fp32 slots, on the
+        matrix cores -- conv_bf16_head.hip -- where the 8-channel slot is stored as bf16)."""
         if self._act_producer is None:
             self._act_producer = False
             p = getattr(self.inp, "producer", None)
             if EPILOGUE_BWD and isinstance(p, ConvUnit) and p.out is self.inp and p.bn is None and p.has_pw \
                     and p.act in ("relu", "leaky relu", "prelu") and p.plan is self.plan and p.ws_name == self.ws_name \
-                    and self.inp.n_consumers == 1 and self.inp.grad2 is None and self.inp.dt == L.F32 \
-                    and self.out.dt == L.F32 and self._sub is None and not self.bf16 and self.packed_bwd is not None \
-                    and self._impl("dgrad") in (L.IMPL_AUTO, L.IMPL_MFMA) and self.dx is not None:
+                    and self.inp.n_consumers == 1 and self.inp.grad2 is None \
+                    and self.out.dt == L.F32 and self._sub is None and self.packed_bwd is not None \
+                    and ((not self.bf16 and self.inp.dt == L.F32 and self._impl("dgrad") in (L.IMPL_AUTO, L.IMPL_MFMA))
+                         or (self.bf16 and self.inp.dt == L.BF16)) and self.dx is not None:
                 nb = self.plan.lib.bp_conv_backward_data_act_workspace(C.byref(self.cv), C.byref(self.out.view),
                                                                        C.byref(self.inp.view))
                 if 0 < nb <= self.plan.ws_bytes:

@@ -28,13 +28,28 @@ class _StoreBf16(torch.autograd.Function):
         return (g.to(torch.bfloat16).to(g.dtype) if ctx.both else g), None
 
 
+class _StageGradBf16(torch.autograd.Function):
+    """The gradient of a matrix-core layer's fp32 output is rounded to bf16 when the data- and weight-gradient kernels
+    stage it (the value itself stays fp32)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(torch.bfloat16).to(g.dtype)
+
+
 def _bf16_layer(bf16, p):
     """The bf16 policy of baryon_painter_amd.models.cvae._Plan.bf16_unit / bf16_out for the layer with state_dict
     prefix ``p``: (runs on bf16 matrix cores, output stored as bf16)."""
     if not bf16:
         return False, False
     name = p[:-1]
-    return name.startswith("p_y_z_in.") or name in ("p_mu_out.0", "p_var_out.0"), name.startswith("p_y_z_in.")
+    head0 = name in ("p_mu_out.0", "p_var_out.0")
+    return (name.startswith("p_y_z_in.") or head0 or name in ("p_mu_out.2", "p_var_out.2"),
+            name.startswith("p_y_z_in.") or head0)
 
 
 def _seq(architecture, x, P, prefix, training, tap=None, bf16=False):
@@ -64,6 +79,8 @@ def _seq(architecture, x, P, prefix, training, tap=None, bf16=False):
                                        padding=cfg.get("padding", 0), output_padding=cfg.get("output_padding", 0))
             if stored:
                 x = _StoreBf16.apply(x, True)
+            elif mm:
+                x = _StageGradBf16.apply(x)
             if tap is not None:
                 tap[p] = x
                 if x.requires_grad:

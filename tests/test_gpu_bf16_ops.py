@@ -59,7 +59,8 @@ CASES = [
     (1, 32, 16, 4, 2, 1, (2, 9, 21), None),
     (0, 16, 8, 7, 1, 3, (2, 19, 35), None),         # p_mu_out.0 (data gradient gathers 8 channels: CC = 8)
     (0, 16, 8, 7, 1, 3, (3, 37, 150), None),        # ... several 64 x 16 tiles of the flattened-K kernel (conv_bf16_flat.hip:
-    #                                                 bf16 -> fp32 forward, fp32 -> bf16 data gradient), ragged both ways
+    #                                                 bf16 -> fp32 / bf16 forward, fp32 / bf16 -> bf16 data gradient), ragged both ways
+    # (p_mu_out.2, 8 -> 1 k5, exists with one element-type pattern only: test_head_tail_layer_on_matrix_cores)
 ]
 
 
@@ -227,6 +228,77 @@ def test_fp32_entry_points_refuse_bf16_views():
 
 
 # ---- the weights-stationary kernels (csrc/conv_bf16_ws.hip) against the tiled kernels they replace
+@pytest.mark.parametrize("shape", [(2, 21, 37), (3, 37, 150), (1, 64, 128), (5, 130, 200)], ids=["ragged", "tiles3", "whole", "fold"])
+def test_head_tail_layer_on_matrix_cores(shape):
+    """The heads' 8 -> 1 k5 layer between the 8-channel bf16 slot and the fp32 one-channel tail (throughput-mode policy of
+    models/cvae.py): forward (conv_bf16_flat.hip kind 9), data gradient with the producer's PReLU backward in the epilogue
+    (conv_bf16_head.hip: g as bf16 and the three sums of bp_act_backward) and weight gradient (wgrad_head_kernel), against
+    the float64 oracle on the same bf16-rounded operands; views that are channel slices of wider buffers."""
+    lib = L.load()
+    n, h, w = shape
+    ci, co, k, p = 8, 1, 5, 2
+    rng = np.random.default_rng(h * 7 + w)
+    raw = bf16_round(rng.standard_normal((n, ci, h, w)).astype(np.float32))
+    wt = (rng.standard_normal((co, ci, k, k)) * 0.1).astype(np.float32)
+    scale = rng.uniform(0.5, 1.5, ci).astype(np.float32)
+    shift = rng.uniform(-0.4, 0.4, ci).astype(np.float32)
+    slope = rng.uniform(0.05, 0.3, ci).astype(np.float32)
+    dy = rng.standard_normal((n, co, h, w)).astype(np.float32)
+    t = (raw.astype(np.float64) * scale[None, :, None, None].astype(np.float64)
+         + shift[None, :, None, None].astype(np.float64)).astype(np.float32)
+    xa = bf16_round(np.where(t > 0, t, t * slope[None, :, None, None]).astype(np.float32)).astype(np.float64)
+    w64 = bf16_round(wt).astype(np.float64)
+    dy64 = bf16_round(dy).astype(np.float64)
+    cv = L.Conv(0, ci, co, k, 1, p, 0)
+    st = G.stream()
+    rb, rv = to_view(raw, True, cstride=ci + 8, coff=8)
+    dyb, dyv = to_view(dy, False, cstride=3, coff=1)
+    keep, pw = G.pointwise(scale, shift, slope)
+    wd = G.dev(wt)
+    pf = torch.zeros(lib.bp_conv_bf16_packed_elems(C.byref(cv), L.PACK_FWD), device="cuda", dtype=torch.bfloat16)
+    pb = torch.zeros(lib.bp_conv_bf16_packed_elems(C.byref(cv), L.PACK_BWD), device="cuda", dtype=torch.bfloat16)
+    L.check(lib.bp_conv_bf16_pack(C.byref(cv), L.PACK_FWD, L.ptr(wd), L.ptr(pf), st))
+    L.check(lib.bp_conv_bf16_pack(C.byref(cv), L.PACK_BWD, L.ptr(wd), L.ptr(pb), st))
+    # ---- forward
+    yb, yv = empty_view(n, h, w, co, False, cstride=3, coff=2)
+    L.check(lib.bp_conv_forward(C.byref(cv), C.byref(rv), C.byref(pw), L.ptr(pf), L.ptr(wd), None, C.byref(yv),
+                                L.IMPL_BF16, st), "forward")
+    assert G.rel_err(from_view(yb, co, coff=2), ops.conv2d_fwd(xa, w64, 1, p)) < 2e-5
+    assert torch.isnan(yb[..., :2]).all(), "stores outside the view"
+    # ---- data gradient + PReLU backward of the slot
+    d_ref = ops.conv2d_bwd_data(dy64, w64, 1, p, h, w)
+    g_ref = np.where(t > 0, d_ref, d_ref * slope[None, :, None, None].astype(np.float64))
+    gb, gv = empty_view(n, h, w, ci, True, cstride=ci + 4, coff=4)
+    nb = lib.bp_conv_backward_data_act_workspace(C.byref(cv), C.byref(dyv), C.byref(gv))
+    assert nb > 0
+    sums = torch.full((3 * ci,), float("nan"), dtype=torch.float64, device="cuda")
+    ws = torch.full((nb // 8 + 8,), float("nan"), dtype=torch.float64, device="cuda")
+    L.check(lib.bp_conv_backward_data_act(C.byref(cv), C.byref(dyv), L.ptr(pb), C.byref(gv), C.byref(rv), C.byref(pw),
+                                          L.ptr(sums), L.ptr(ws), nb, st), "backward_data + activation backward")
+    assert G.rel_err(from_view(gb, ci, coff=4), g_ref) < 4e-3
+    assert torch.isnan(gb.to(torch.float32)[..., :4]).all(), "stores outside the view"
+    got = sums.cpu().numpy()
+    r64 = raw.astype(np.float64)
+    refs = [g_ref, g_ref * r64, np.where(t > 0, 0.0, d_ref * t.astype(np.float64))]
+    for q in range(3):
+        ref_q, mag_q = refs[q].sum(axis=(0, 2, 3)), np.abs(refs[q]).sum(axis=(0, 2, 3))
+        assert (np.abs(got[q * ci:(q + 1) * ci] - ref_q) <= 2e-5 * mag_q + 1e-12).all(), q
+    assert lib.bp_conv_backward_data_act(C.byref(cv), C.byref(dyv), L.ptr(pb), C.byref(gv), C.byref(rv), C.byref(pw),
+                                         L.ptr(sums), L.ptr(ws), nb - 8, st) == -4
+    # ... and without the epilogue: d itself
+    dxb, dxv = empty_view(n, h, w, ci, True)
+    L.check(lib.bp_conv_backward_data(C.byref(cv), C.byref(dyv), L.ptr(pb), L.ptr(wd), C.byref(dxv), L.IMPL_BF16, st))
+    assert G.rel_err(from_view(dxb, ci), d_ref) < 4e-3
+    # ---- weight gradient
+    ws_bytes = lib.bp_conv_backward_weight_workspace(C.byref(cv), C.byref(rv), C.byref(dyv))
+    assert ws_bytes > 0
+    wsw = torch.zeros(ws_bytes // 8 + 8, dtype=torch.float64, device="cuda")
+    dw = torch.full(wt.shape, float("nan"), device="cuda")
+    L.check(lib.bp_conv_backward_weight(C.byref(cv), C.byref(rv), C.byref(pw), C.byref(dyv), L.ptr(dw), None,
+                                        L.ptr(wsw), wsw.numel() * 8, L.IMPL_BF16, st), "backward_weight")
+    assert G.rel_err(dw.cpu().numpy(), ops.conv2d_bwd_weight(xa, dy64, 1, p, k, k)) < 1e-4
+
+
 WS_LAYERS = {
     # (transposed, cin, cout, k, stride, pad), input shapes (n, h, w) the stationary kernel takes in at least one direction
     "k3": ((0, 128, 128, 3, 1, 1), [(2, 9, 16), (3, 20, 32), (2, 64, 64), (5, 16, 64), (70, 8, 16)]),
