@@ -49,7 +49,7 @@ struct FbArgs {
   PW spw;
 };
 
-constexpr int FB_TW = 64, FB_TH = 16, FB_R = 4;
+constexpr int FB_TW = 64, FB_TH = 16;          // (FB_R, output rows per pass: template parameter of the kernel, 4 by default)
 
 template <int KS, int CIN> struct FbShape {
   static constexpr int KB = (KS * CIN + 31) / 32;
@@ -69,8 +69,8 @@ __device__ __forceinline__ int fb_tile_of_block(int n) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
-template <int KS, int CIN, int COUTP, bool IN_BF16, bool OUT_BF16, int STATS>
-__global__ __launch_bounds__(256, 3) void flatb_kernel(FbArgs a) {
+template <int KS, int CIN, int COUTP, bool IN_BF16, bool OUT_BF16, int STATS, int FB_R = 4>
+__global__ __launch_bounds__(256, FB_R > 4 ? 2 : 3) void flatb_kernel(FbArgs a) {
   using S = FbShape<KS, CIN>;
   constexpr int KB = S::KB, ROWE = S::ROWE, LH = S::LH, PAD = KS / 2;
   constexpr int RS = 16 / COUTP;                // output rows per MFMA
@@ -1080,9 +1080,9 @@ static FbKind fb_kind(const ConvGeom& g) {
   return none;
 }
 
-template <int KS, int CIN, int COUTP, bool IB, bool OB, int ST>
+template <int KS, int CIN, int COUTP, bool IB, bool OB, int ST, int R = 4>
 static void fb_launch(const FbArgs& a, dim3 grid, hipStream_t st) {
-  auto k = flatb_kernel<KS, CIN, COUTP, IB, OB, ST>;
+  auto k = flatb_kernel<KS, CIN, COUTP, IB, OB, ST, R>;
   constexpr size_t lds = FbShape<KS, CIN>::LDS;
   static const int once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
                                                (int)lds), 0);
@@ -1270,11 +1270,19 @@ int bp_bf16_flat_run(const ConvGeom& g, const bp_view* in, const PW& pw, const u
   const dim3 grid((unsigned)rows);
   const bool ib = in->dtype == BP_BF16, ob = out->dtype == BP_BF16;
   switch (f.kind) {
-    case 1: if (ob) fb_launch<7, 16, 8, true, true, 0>(a, grid, st);
-            else fb_launch<7, 16, 8, true, false, 0>(a, grid, st);
-            break;
+    case 1: {
+      static const int rr = getenv("BP_FLAT_R") ? atoi(getenv("BP_FLAT_R")) : 4;
+      if (ob && rr == 8) fb_launch<7, 16, 8, true, true, 0, 8>(a, grid, st);
+      else if (ob && rr == 16) fb_launch<7, 16, 8, true, true, 0, 16>(a, grid, st);
+      else if (ob) fb_launch<7, 16, 8, true, true, 0>(a, grid, st);
+      else fb_launch<7, 16, 8, true, false, 0>(a, grid, st);
+      break;
+    }
     case 2: if (ib) {
-              if (sr) fb_launch<7, 8, 16, true, true, 2>(a, grid, st);
+              static const int rr = getenv("BP_FLAT_R") ? atoi(getenv("BP_FLAT_R")) : 4;
+              if (sr && rr == 8) fb_launch<7, 8, 16, true, true, 2, 8>(a, grid, st);
+              else if (sr && rr == 16) fb_launch<7, 8, 16, true, true, 2, 16>(a, grid, st);
+              else if (sr) fb_launch<7, 8, 16, true, true, 2>(a, grid, st);
               else fb_launch<7, 8, 16, true, true, 0>(a, grid, st);
             } else {
               if (sr) fb_launch<7, 8, 16, false, true, 2>(a, grid, st);

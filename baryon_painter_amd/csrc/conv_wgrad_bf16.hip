@@ -894,7 +894,7 @@ constexpr size_t WH_RED = (size_t)4 * 3 * 256 * sizeof(float);
 constexpr size_t WH_TILES = (size_t)(WH_XE + WH_YE) * 2 > WH_RED ? (size_t)(WH_XE + WH_YE) * 2 : WH_RED;
 constexpr size_t WH_LDS = WH_TILES + 3 * WH_C * sizeof(float);
 
-__global__ __launch_bounds__(256, 2) void wgrad_head_kernel(WhArgs a) {
+__global__ __launch_bounds__(256, 4) void wgrad_head_kernel(WhArgs a) {
   extern __shared__ __attribute__((aligned(16))) u16 smem[];
   u16* xs = smem;
   u16* ys = smem + WH_XE;
@@ -1028,7 +1028,7 @@ static int wh_launch(const bp_view* X, const PW& pwx, const bp_view* Y, float* w
   a.n = X->n; a.pwx = pwx; a.ws = ws;
   a.tiles_x = bp_ceil_div(X->w, WH_TW); a.tiles_y = bp_ceil_div(X->h, WH_TH);
   const int64_t ntiles = (int64_t)a.tiles_x * a.tiles_y * a.n;
-  const int ns = (int)(ntiles < 512 ? ntiles : 512);                 // two persistent workgroups per CU
+  const int ns = (int)(ntiles < 1024 ? ntiles : 1024);               // four persistent workgroups per CU (27 KB of LDS each)
   *need = (size_t)ns * WH_K * WH_K * WH_C * sizeof(float);
   *nsplit_out = ns; *cxp = WH_C; *cyp = 1;
   if (dry) return BP_OK;

@@ -268,15 +268,15 @@ def test_head_tail_layer_on_matrix_cores(shape):
     # ---- data gradient + PReLU backward of the slot
     d_ref = ops.conv2d_bwd_data(dy64, w64, 1, p, h, w)
     g_ref = np.where(t > 0, d_ref, d_ref * slope[None, :, None, None].astype(np.float64))
-    gb, gv = empty_view(n, h, w, ci, True, cstride=ci + 4, coff=4)
+    gb, gv = empty_view(n, h, w, ci, True, cstride=ci + 8, coff=8)
     nb = lib.bp_conv_backward_data_act_workspace(C.byref(cv), C.byref(dyv), C.byref(gv))
     assert nb > 0
     sums = torch.full((3 * ci,), float("nan"), dtype=torch.float64, device="cuda")
     ws = torch.full((nb // 8 + 8,), float("nan"), dtype=torch.float64, device="cuda")
     L.check(lib.bp_conv_backward_data_act(C.byref(cv), C.byref(dyv), L.ptr(pb), C.byref(gv), C.byref(rv), C.byref(pw),
                                           L.ptr(sums), L.ptr(ws), nb, st), "backward_data + activation backward")
-    assert G.rel_err(from_view(gb, ci, coff=4), g_ref) < 4e-3
-    assert torch.isnan(gb.to(torch.float32)[..., :4]).all(), "stores outside the view"
+    assert G.rel_err(from_view(gb, ci, coff=8), g_ref) < 4e-3
+    assert torch.isnan(gb.to(torch.float32)[..., :8]).all(), "stores outside the view"
     got = sums.cpu().numpy()
     r64 = raw.astype(np.float64)
     refs = [g_ref, g_ref * r64, np.where(t > 0, 0.0, d_ref * t.astype(np.float64))]
