@@ -57,11 +57,19 @@ __global__ __launch_bounds__(256) void small_conv_kernel(SmallArgs a) {
 
   // ---- thread = column `col`, output rows r0 .. r0+PXR-1
   const int col = tid & 63, r0 = (tid >> 6) * PXR;
-  float acc[PXR][CO];
+  // accumulators as PAIRS (v_pk_fma_f32: two fp32 FMAs per lane and issue): over produced channels where CO is even,
+  // otherwise over the parity of the gathered channel (two partial sums per output, added at the end)
+  constexpr bool PCO = CO % 2 == 0, PCI = !PCO && CI % 2 == 0;
+  constexpr int NA = PCO ? CO / 2 : CO;
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  f2 acc2[PXR][NA];
 #pragma unroll
   for (int j = 0; j < PXR; ++j)
 #pragma unroll
-    for (int co = 0; co < CO; ++co) acc[j][co] = a.bias ? a.bias[co] : 0.f;
+    for (int q = 0; q < NA; ++q) {
+      if constexpr (PCO) acc2[j][q] = f2{a.bias ? a.bias[2 * q] : 0.f, a.bias ? a.bias[2 * q + 1] : 0.f};
+      else acc2[j][q] = f2{a.bias ? a.bias[q] : 0.f, 0.f};
+    }
 
   // layers with more gathered channels than fit one tile (k9 32->1) run in chunks of CI channels
   for (int c0 = 0; c0 < CT; c0 += CI) {
@@ -153,16 +161,36 @@ __global__ __launch_bounds__(256) void small_conv_kernel(SmallArgs a) {
         for (int j = 0; j < PXR; ++j) {
           const int ky = dy - j;               // compile-time after unrolling
           if (ky >= 0 && ky < K) {
+            const float* wt = wk + ky * wrow;
+            if constexpr (PCO) {
 #pragma unroll
-            for (int ci = 0; ci < CI; ++ci)
+              for (int ci = 0; ci < CI; ++ci)
 #pragma unroll
-              for (int co = 0; co < CO; ++co)
-                acc[j][co] = fmaf(v[ci], wk[ky * wrow + ci * CO + co], acc[j][co]);
+                for (int q = 0; q < NA; ++q)
+                  acc2[j][q] = f2{v[ci], v[ci]} * f2{wt[ci * CO + 2 * q], wt[ci * CO + 2 * q + 1]} + acc2[j][q];
+            } else if constexpr (PCI) {
+#pragma unroll
+              for (int ci = 0; ci < CI; ci += 2)
+#pragma unroll
+                for (int co = 0; co < CO; ++co)
+                  acc2[j][co] = f2{v[ci], v[ci + 1]} * f2{wt[ci * CO + co], wt[(ci + 1) * CO + co]} + acc2[j][co];
+            } else {
+#pragma unroll
+              for (int ci = 0; ci < CI; ++ci)
+#pragma unroll
+                for (int co = 0; co < CO; ++co)
+                  acc2[j][co][0] = fmaf(v[ci], wt[ci * CO + co], acc2[j][co][0]);
+            }
           }
         }
       }
     }
   }
+  float acc[PXR][CO];
+#pragma unroll
+  for (int j = 0; j < PXR; ++j)
+#pragma unroll
+    for (int co = 0; co < CO; ++co) acc[j][co] = PCO ? acc2[j][co / 2][co & 1] : acc2[j][co][0] + acc2[j][co][1];
 
   float* out_n = a.out + (int64_t)n * a.out_h * a.out_w * a.out_cs + a.out_co;
   const int X = x0 + col;
