@@ -437,7 +437,9 @@ def _paint_leg(args, model, dtype, dev, world, rank, n):
     from baryon_painter_amd.painter import CVAEPainter
     from baryon_painter_amd.utils.datasets import SyntheticTileDataset
     model.train(False)
-    pb = min(n, 64)
+    # tiles per captured graph: independent of the training batch -- eval-mode tiles do not couple, and 128 (fp32) / 256
+    # (bf16) tiles per replay amortise the graph's ~70 launch gaps (bf16: 22.8k -> 25.0k tiles/s resident)
+    pb = args.paint_batch if args.paint_batch > 0 else (256 if dtype == "bf16" else 128)
     ds = SyntheticTileDataset(n_sample=8, tile_size=args.tile, seed=3)
     pt = CVAEPainter.__new__(CVAEPainter)
     pt.model, pt.compute_device, pt.sync = model, dev, None
@@ -617,7 +619,10 @@ def main():
     ap.add_argument("--local-bn", action="store_true", help="do not all-reduce batch-norm statistics")
     ap.add_argument("--layers", action="store_true", help="also print a per-layer table to stderr")
     ap.add_argument("--no-paint", action="store_true", help="skip the paint() throughput legs")
-    ap.add_argument("--paint-tiles", type=int, default=1024, help="tiles streamed through paint() per rank")
+    ap.add_argument("--paint-tiles", type=int, default=4096,
+                    help="tiles streamed through paint() per rank (configs[4] streams 100k: the un-overlapped first upload / "
+                         "last download of the pipeline are 8 %% of a 1024-tile run and 2 %% of this one)")
+    ap.add_argument("--paint-batch", type=int, default=0, help="tiles per captured paint graph (0: 128 for fp32, 256 for bf16)")
     ap.add_argument("--torch-adam", action="store_true", help="torch.optim.Adam instead of the fused FlatAdam")
     ap.add_argument("--graph", action="store_true",
                     help="replay the step (forward + backward + Adam, same launches) from one hipGraph "
