@@ -26,6 +26,7 @@ struct WwArgs {
   const float* X; int x_cs, x_co;
   const float* Y; int y_cs, y_co;
   int n, h;
+  int iw, strips;                    // image width, column strips of W = 16 G pixels per row (iw = W * strips)
   PW pwx;                            // pending activation of X (this layer's input) or nullptr
   float* ws;                         // [split][tap 9][co 128][ci 128]
   int BR, bands;
@@ -55,21 +56,30 @@ __global__ __launch_bounds__(256) void wgrad_ws_f32_kernel(WwArgs a) {
   const int lm = lane & 15, kq = lane >> 4;
   const int pair = blockIdx.x & 3, split = blockIdx.x >> 2;
   const int cib = pair & 1, cob = pair >> 1;
-  const int n = split / a.bands, band = split % a.bands;
+  const int strip = split % a.strips, nbd = split / a.strips;
+  const int n = nbd / a.bands, band = nbd % a.bands;
   const int y0 = band * a.BR;
   const int y1 = min(y0 + a.BR, a.h);
+  const int x0 = strip * W;          // (wider images: the X ring's pad columns hold the neighbouring strips' pixels)
 
   // staging: unit i of a row = pixel (tid >> 4) + 16 i, channel quad tid & 15 (16 lanes = the 256 contiguous bytes of a pixel's half)
   const int s_q = tid & 15, s_p = tid >> 4;
-  const char* x_img = reinterpret_cast<const char*>(a.X + (int64_t)n * a.h * W * a.x_cs + a.x_co + WW_B * cib);
-  const char* y_img = reinterpret_cast<const char*>(a.Y + (int64_t)n * a.h * W * a.y_cs + a.y_co + WW_B * cob);
-  const unsigned x_row = (unsigned)(W * a.x_cs) * 4u, y_row = (unsigned)(W * a.y_cs) * 4u;
+  const char* x_img = reinterpret_cast<const char*>(a.X + ((int64_t)n * a.h * a.iw + x0) * a.x_cs + a.x_co + WW_B * cib);
+  const char* y_img = reinterpret_cast<const char*>(a.Y + ((int64_t)n * a.h * a.iw + x0) * a.y_cs + a.y_co + WW_B * cob);
+  const unsigned x_row = (unsigned)(a.iw * a.x_cs) * 4u, y_row = (unsigned)(a.iw * a.y_cs) * 4u;
+  // halo columns x0 - 1 and x0 + W of an X row: threads 0..31 = (side, quad); outside the image they stay zero
+  const bool h_on = a.strips > 1 && tid < 32;
+  const int h_side = (tid >> 4) & 1;
+  const bool h_in = h_side ? x0 + W < a.iw : x0 > 0;
+  const unsigned h_keep = h_in ? 0xffffffffu : 0u;
+  const int h_off = ((h_in ? (h_side ? W : -1) : 0) * a.x_cs + 4 * s_q) * 4;
   const unsigned x_off = (unsigned)(s_p * a.x_cs + 4 * s_q) * 4u, x_st = (unsigned)(16 * a.x_cs) * 4u;
   const unsigned y_off = (unsigned)(s_p * a.y_cs + 4 * s_q) * 4u, y_st = (unsigned)(16 * a.y_cs) * 4u;
-  auto load_x = [&](int r, float4 (&raw)[NU]) {
+  auto load_x = [&](int r, float4 (&raw)[NU], float4& hraw) {
     const char* rowp = x_img + (size_t)((unsigned)r * x_row);
 #pragma unroll
     for (int i = 0; i < NU; ++i) raw[i] = *reinterpret_cast<const float4*>(rowp + (x_off + (unsigned)i * x_st));
+    if (h_on) hraw = *reinterpret_cast<const float4*>(rowp + h_off);
   };
   auto load_y = [&](int r, float4 (&raw)[NU]) {
     const char* rowp = y_img + (size_t)((unsigned)r * y_row);
@@ -89,13 +99,19 @@ __global__ __launch_bounds__(256) void wgrad_ws_f32_kernel(WwArgs a) {
     }
     return v;
   };
-  auto put_x = [&](int r, unsigned keep, const float4 (&raw)[NU]) {      // X row r -> ring slot (r + 1) & 3, columns 1 .. W
+  auto put_x = [&](int r, unsigned keep, const float4 (&raw)[NU], const float4& hraw) {      // X row r -> ring slot (r + 1) & 3, columns 1 .. W
     const int rr = (r + 1) & (WW_R - 1);
     auto m = [&](float f) { return __builtin_bit_cast(float, __builtin_bit_cast(unsigned, f) & keep); };
 #pragma unroll
     for (int i = 0; i < NU; ++i) {
       const float4 v = act4(raw[i]);
       xs[(rr * RPX + 1 + s_p + 16 * i) * 16 + s_q] = make_float4(m(v.x), m(v.y), m(v.z), m(v.w));
+    }
+    if (h_on) {
+      const float4 v = act4(hraw);
+      const unsigned k = keep & h_keep;
+      auto mh = [&](float f) { return __builtin_bit_cast(float, __builtin_bit_cast(unsigned, f) & k); };
+      xs[(rr * RPX + (h_side ? RPX - 1 : 0)) * 16 + s_q] = make_float4(mh(v.x), mh(v.y), mh(v.z), mh(v.w));
     }
   };
   auto put_y = [&](int r, const float4 (&raw)[NU]) {                     // dY row r -> buffer r & 1
@@ -105,7 +121,10 @@ __global__ __launch_bounds__(256) void wgrad_ws_f32_kernel(WwArgs a) {
 
   // ---- prologue
   float4 rx[NU], ry[NU];
-  if (tid < 128) {                                      // zero columns 0 and W + 1 of the four ring rows
+  float4 hx = make_float4(0.f, 0.f, 0.f, 0.f), hy = hx;
+  // (with strips those columns are the halo, written with every row by threads 0..31 -- zeros where the image ends: no
+  //  fill then, it would race with those writes)
+  if (a.strips == 1 && tid < 128) {                     // zero columns 0 and W + 1 of the four ring rows
     const int rr = tid >> 5, side = (tid >> 4) & 1, q = tid & 15;
     xs[(rr * RPX + (side ? RPX - 1 : 0)) * 16 + q] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
@@ -117,14 +136,14 @@ __global__ __launch_bounds__(256) void wgrad_ws_f32_kernel(WwArgs a) {
   }
   {
     const bool in0 = y0 - 1 >= 0, in2 = y0 + 1 < a.h;
-    load_x(in0 ? y0 - 1 : y0, rx);
+    load_x(in0 ? y0 - 1 : y0, rx, hx);
     load_y(y0, ry);
-    put_x(y0 - 1, in0 ? 0xffffffffu : 0u, rx);
+    put_x(y0 - 1, in0 ? 0xffffffffu : 0u, rx, hx);
     put_y(y0, ry);
-    load_x(y0, rx);
-    load_x(in2 ? y0 + 1 : y0, ry);                      // (ry as a second X buffer)
-    put_x(y0, 0xffffffffu, rx);
-    put_x(y0 + 1, in2 ? 0xffffffffu : 0u, ry);
+    load_x(y0, rx, hx);
+    load_x(in2 ? y0 + 1 : y0, ry, hy);                  // (ry as a second X buffer)
+    put_x(y0, 0xffffffffu, rx, hx);
+    put_x(y0 + 1, in2 ? 0xffffffffu : 0u, ry, hy);
   }
   __syncthreads();
 
@@ -138,7 +157,7 @@ __global__ __launch_bounds__(256) void wgrad_ws_f32_kernel(WwArgs a) {
   for (int y = y0; y < y1; ++y) {
     const bool more = y + 1 < y1;
     const bool in_next = y + 2 < a.h;
-    load_x(in_next ? y + 2 : a.h - 1, rx);
+    load_x(in_next ? y + 2 : a.h - 1, rx, hx);
     load_y(more ? y + 1 : y, ry);
     const unsigned keep = in_next ? 0xffffffffu : 0u;
     int xb[3];
@@ -159,7 +178,7 @@ __global__ __launch_bounds__(256) void wgrad_ws_f32_kernel(WwArgs a) {
       }
       // the next rows go to LDS in the middle of the row (their loads were issued at its top); slots nobody reads now
       if (ks == KS / 2) {
-        put_x(y + 2, keep, rx);
+        put_x(y + 2, keep, rx, hx);
         put_y(y + 1, ry);
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -194,11 +213,13 @@ bool ww_enabled() {
 }
 int g_ww_override = -1;
 
-int ww_G(int w) { return w == 64 ? 4 : w == 32 ? 2 : w == 16 ? 1 : 0; }
+// strip width / 16: the image itself up to 64 pixels, 64-pixel strips of wider images (multiples of 64)
+int ww_G(int w) { return w == 64 ? 4 : w == 32 ? 2 : w == 16 ? 1 : (w > 64 && w % 64 == 0) ? 4 : 0; }
+int ww_strips(int w) { return w > 64 ? w / 64 : 1; }
 
-void ww_bands(int n, int h, int* BR, int* bands) {      // ~256 workgroups = 64 splits x 4 channel-block pairs
+void ww_bands(int n, int h, int strips, int* BR, int* bands) {      // ~256 workgroups = 64 splits x 4 channel-block pairs
   int br = h;
-  while (br > 8 && (int64_t)n * bp_ceil_div(h, br) < 64) br = bp_ceil_div(br, 2);
+  while (br > 8 && (int64_t)n * strips * bp_ceil_div(h, br) < 64) br = bp_ceil_div(br, 2);
   *BR = br;
   *bands = bp_ceil_div(h, br);
 }
@@ -227,8 +248,9 @@ int bp_wgrad_ws_f32(const bp_conv* cv, const bp_view* X, const PW& pwx, const bp
   if ((int64_t)X->h * X->w * X->cstride * 4 >= (int64_t)1 << 31 || (int64_t)Y->h * Y->w * Y->cstride * 4 >= (int64_t)1 << 31)
     return BP_EUNSUPPORTED;
   WwArgs a{};
-  ww_bands(X->n, X->h, &a.BR, &a.bands);
-  const int64_t splits = (int64_t)X->n * a.bands;
+  a.iw = X->w; a.strips = ww_strips(X->w);
+  ww_bands(X->n, X->h, a.strips, &a.BR, &a.bands);
+  const int64_t splits = (int64_t)X->n * a.bands * a.strips;
   if (splits * 4 > 0x7fffffff) return BP_EUNSUPPORTED;
   *nsplit = (int)splits; *cxp = WW_C; *cyp = WW_C;
   *need = (size_t)splits * 9 * WW_C * WW_C * sizeof(float);

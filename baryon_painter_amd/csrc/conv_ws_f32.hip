@@ -28,6 +28,7 @@ struct WfArgs {
   const float* in; int in_cs, in_co;
   float* out; int out_cs, out_co;
   int n, h;
+  int iw, strips;                    // image width and column strips of W pixels per row (W = 16 G; iw = W * strips)
   const float* wp;                   // tiled image [tap 9][chunk 8][co 128][16]
   PW pw;
   int BR, bands;
@@ -41,7 +42,7 @@ template <int G> struct WfGeom {
   static constexpr size_t lds_bytes = img_bytes + 3 * WF_C * sizeof(float);
 };
 
-template <int G, bool ACT, bool STATS>
+template <int G, bool ACT, bool STATS, bool STRIPS = false>
 __global__ __launch_bounds__(256) void ws3_f32_kernel(WfArgs a) {
   using GM = WfGeom<G>;
   constexpr int W = GM::W, RP = GM::RP, PS = GM::PS;
@@ -54,28 +55,34 @@ __global__ __launch_bounds__(256) void ws3_f32_kernel(WfArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lm = lane & 15, kq = lane >> 4;
   const int half = blockIdx.x & 1, item = blockIdx.x >> 1;
-  const int n = item / a.bands, band = item % a.bands;
+  const int strip = item % a.strips, nb = item / a.strips;
+  const int n = nb / a.bands, band = nb % a.bands;
   const int y0 = band * a.BR;
   const int y1 = min(y0 + a.BR, a.h);
+  const int x0 = strip * W;          // images wider than a strip (the CGAN generator's 128-pixel trunk): the pad columns of
+                                     // the ring rows then hold the neighbouring strips' pixels instead of zeros
 
   // staging: unit i = 8 pixels x 8 quads per wave instruction: pixel (lane & 7) + 8 (ub >> 2), quad (lane >> 3) + 8 (ub & 3),
   // ub = wave + 4 i -- eight consecutive pixels of one plane per eight lanes (conflict-free ds_write_b128)
-  int s_slot[NU], s_q[NU];
-  unsigned s_off[NU];
-#pragma unroll
-  for (int i = 0; i < NU; ++i) {
-    const int ub = wave + 4 * i;
-    s_q[i] = (lane >> 3) + 8 * (ub & 3);
-    const int px = (lane & 7) + 8 * (ub >> 2);
-    s_slot[i] = s_q[i] * PS + 1 + px;
-    s_off[i] = (unsigned)(px * a.in_cs + s_q[i] * 4) * 4u;
-  }
-  const char* in_img = reinterpret_cast<const char*>(a.in + (int64_t)n * a.h * W * a.in_cs + a.in_co);
-  const unsigned in_row = (unsigned)(W * a.in_cs) * 4u;
-  auto load_row = [&](int r, float4 (&raw)[NU]) {
+  // (ub & 3 = wave, ub >> 2 = i: the quad is the same for every unit of a thread, the pixel advances by 8 -- one base and a
+  //  uniform stride instead of NU registers each)
+  const int s_q = (lane >> 3) + 8 * wave;
+  const int s_slot0 = s_q * PS + 1 + (lane & 7);
+  const unsigned s_off0 = (unsigned)((lane & 7) * a.in_cs + s_q * 4) * 4u;
+  const unsigned s_st = (unsigned)(8 * a.in_cs) * 4u;
+  const char* in_img = reinterpret_cast<const char*>(a.in + ((int64_t)n * a.h * a.iw + x0) * a.in_cs + a.in_co);
+  const unsigned in_row = (unsigned)(a.iw * a.in_cs) * 4u;
+  // halo columns x0 - 1 and x0 + W: wave 0, lane = (side, quad); outside the image they stay zero
+  const int h_q = lane & 31, h_side = lane >> 5;
+  const bool h_in = h_side ? x0 + W < a.iw : x0 > 0;
+  const int h_slot = h_q * PS + (h_side ? RP - 1 : 0);
+  const unsigned h_keep = h_in ? 0xffffffffu : 0u;
+  const int h_off = ((h_in ? (h_side ? W : -1) : 0) * a.in_cs + h_q * 4) * 4;
+  auto load_row = [&](int r, float4 (&raw)[NU], float4& hraw) {
     const char* rowp = in_img + (size_t)((unsigned)r * in_row);
 #pragma unroll
-    for (int i = 0; i < NU; ++i) raw[i] = *reinterpret_cast<const float4*>(rowp + s_off[i]);
+    for (int i = 0; i < NU; ++i) raw[i] = *reinterpret_cast<const float4*>(rowp + (size_t)((unsigned)i * s_st) + s_off0);
+    if (STRIPS && wave == 0) hraw = *reinterpret_cast<const float4*>(rowp + h_off);
   };
   auto act4 = [&](int q, float4 v) {
     if constexpr (ACT) {
@@ -90,21 +97,31 @@ __global__ __launch_bounds__(256) void ws3_f32_kernel(WfArgs a) {
     }
     return v;
   };
-  auto commit_row = [&](int r, bool inside, const float4 (&raw)[NU]) {
+  auto commit_halo = [&](int rr, unsigned keep, const float4& hraw) {
+    if (STRIPS && wave == 0) {
+      const float4 v = act4(h_q, hraw);
+      const unsigned k = keep & h_keep;
+      auto m = [&](float f) { return __builtin_bit_cast(float, __builtin_bit_cast(unsigned, f) & k); };
+      img[h_slot + rr * RP] = make_float4(m(v.x), m(v.y), m(v.z), m(v.w));
+    }
+  };
+  auto commit_row = [&](int r, bool inside, const float4 (&raw)[NU], const float4& hraw) {
     const int rr = (r + 1) & (WF_R - 1);
 #pragma unroll
     for (int i = 0; i < NU; ++i) {
-      float4 v = act4(s_q[i], raw[i]);
+      float4 v = act4(s_q, raw[i]);
       if (!inside) v = make_float4(0.f, 0.f, 0.f, 0.f);
-      img[s_slot[i] + rr * RP] = v;
+      img[s_slot0 + 8 * i + rr * RP] = v;
     }
+    commit_halo(rr, inside ? 0xffffffffu : 0u, hraw);
   };
 
   // ---- prologue
   float4 raw0[NU], raw1[NU];
+  float4 hraw0 = make_float4(0.f, 0.f, 0.f, 0.f), hraw1 = hraw0;
   const bool in0 = y0 - 1 >= 0, in2 = y0 + 1 < a.h;
-  load_row(in0 ? y0 - 1 : y0, raw0);
-  load_row(y0, raw1);
+  load_row(in0 ? y0 - 1 : y0, raw0, hraw0);
+  load_row(y0, raw1, hraw1);
   float wf[WF_NK];                                      // k-step (tap, chunk q, j): channels 16 q + 4 kq' + j of lane group kq'
   {
     const float4* wsrc = reinterpret_cast<const float4*>(a.wp) + (size_t)(64 * half + 16 * wave + lm) * 4 + kq;
@@ -120,7 +137,9 @@ __global__ __launch_bounds__(256) void ws3_f32_kernel(WfArgs a) {
       else asm volatile("" : "+a"(wf[s]));
     }
   }
-  if (tid < 256) {
+  // (with strips the pad columns are the halo, written by wave 0 with every row -- zeros where the image ends: no fill here,
+  //  it would race with those writes)
+  if (!STRIPS && tid < 256) {
     const int plane = tid >> 3, rr = (tid >> 1) & 3, side = tid & 1;
     img[plane * PS + rr * RP + (side ? RP - 1 : 0)] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
@@ -128,18 +147,18 @@ __global__ __launch_bounds__(256) void ws3_f32_kernel(WfArgs a) {
     for (int i = tid; i < WF_C; i += 256) { lpw[i] = a.pw.scale[i]; lpw[WF_C + i] = a.pw.shift[i]; lpw[2 * WF_C + i] = a.pw.slope[i]; }
     __syncthreads();
   }
-  commit_row(y0 - 1, in0, raw0);
-  commit_row(y0, true, raw1);
-  load_row(in2 ? y0 + 1 : y0, raw0);
-  commit_row(y0 + 1, in2, raw0);
+  commit_row(y0 - 1, in0, raw0, hraw0);
+  commit_row(y0, true, raw1, hraw1);
+  load_row(in2 ? y0 + 1 : y0, raw0, hraw0);
+  commit_row(y0 + 1, in2, raw0, hraw0);
   __syncthreads();
 
   double s1[4], s2[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) { s1[j] = 0.0; s2[j] = 0.0; }
   const int lbase = kq * PS + lm;
-  char* out_img = reinterpret_cast<char*>(a.out + (int64_t)n * a.h * W * a.out_cs + a.out_co);
-  const unsigned out_row = (unsigned)(W * a.out_cs) * 4u;
+  char* out_img = reinterpret_cast<char*>(a.out + ((int64_t)n * a.h * a.iw + x0) * a.out_cs + a.out_co);
+  const unsigned out_row = (unsigned)(a.iw * a.out_cs) * 4u;
   const unsigned o_off = (unsigned)(lm * a.out_cs + 64 * half + 16 * wave + 4 * kq) * 4u, o_g = (unsigned)(16 * a.out_cs) * 4u;
 
   v4f acc[2][G];
@@ -161,7 +180,7 @@ __global__ __launch_bounds__(256) void ws3_f32_kernel(WfArgs a) {
     constexpr int P = decltype(P_)::value;
     constexpr bool PREV = decltype(PREV_)::value;
     const bool in_next = y + 2 < a.h;
-    load_row(in_next ? y + 2 : a.h - 1, raw0);
+    load_row(in_next ? y + 2 : a.h - 1, raw0, hraw0);
     const int rr_next = (y + 3) & (WF_R - 1);
     const unsigned keep = in_next ? 0xffffffffu : 0u;   // rows below the image are zero (a mask: no branch, and no 0 * NaN)
     int rbase[3];
@@ -181,10 +200,11 @@ __global__ __launch_bounds__(256) void ws3_f32_kernel(WfArgs a) {
       }
       if (s >= 16 && s < 16 + NU) {
         const int i = s - 16;
-        float4 v = act4(s_q[i], raw0[i]);
+        float4 v = act4(s_q, raw0[i]);
         auto m = [&](float f) { return __builtin_bit_cast(float, __builtin_bit_cast(unsigned, f) & keep); };
-        img[s_slot[i] + rr_next * RP] = make_float4(m(v.x), m(v.y), m(v.z), m(v.w));
+        img[s_slot0 + 8 * i + rr_next * RP] = make_float4(m(v.x), m(v.y), m(v.z), m(v.w));
       }
+      if (s == 16 + NU) commit_halo(rr_next, keep, hraw0);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -251,29 +271,31 @@ bool wf_enabled() {
 }
 int g_wf_override = -1;
 
-int wf_G(int w) { return w == 64 ? 4 : w == 32 ? 2 : w == 16 ? 1 : 0; }
+// strip width / 16: the image itself up to 64 pixels, 64-pixel strips of wider images (multiples of 64)
+int wf_G(int w) { return w == 64 ? 4 : w == 32 ? 2 : w == 16 ? 1 : (w > 64 && w % 64 == 0) ? 4 : 0; }
+int wf_strips(int w) { return w > 64 ? w / 64 : 1; }
 
-// rows per band: ~256 workgroups (two per band: the channel halves), bands of >= 4 rows
-void wf_bands(int n, int h, int* BR, int* bands) {
+// rows per band: ~256 workgroups (two per band and strip: the channel halves), bands of >= 4 rows
+void wf_bands(int n, int h, int strips, int* BR, int* bands) {
   int br = h;
-  while (br > 4 && (int64_t)n * bp_ceil_div(h, br) * 2 < 256) br = bp_ceil_div(br, 2);
+  while (br > 4 && (int64_t)n * strips * bp_ceil_div(h, br) * 2 < 256) br = bp_ceil_div(br, 2);
   *BR = br;
   *bands = bp_ceil_div(h, br);
 }
 
-template <int G, bool ACT, bool STATS>
+template <int G, bool ACT, bool STATS, bool STRIPS>
 int wf_launch(const WfArgs& a, unsigned grid, hipStream_t st) {
-  static const hipError_t optin = hipFuncSetAttribute(reinterpret_cast<const void*>(&ws3_f32_kernel<G, ACT, STATS>),
+  static const hipError_t optin = hipFuncSetAttribute(reinterpret_cast<const void*>(&ws3_f32_kernel<G, ACT, STATS, STRIPS>),
                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)WfGeom<G>::lds_bytes);
   if (optin != hipSuccess) return BP_ELAUNCH;
-  hipLaunchKernelGGL((ws3_f32_kernel<G, ACT, STATS>), dim3(grid), dim3(256), WfGeom<G>::lds_bytes, st, a);
+  hipLaunchKernelGGL((ws3_f32_kernel<G, ACT, STATS, STRIPS>), dim3(grid), dim3(256), WfGeom<G>::lds_bytes, st, a);
   BP_CHECK_LAUNCH();
   return BP_OK;
 }
-template <int G>
+template <int G, bool STRIPS = false>
 int wf_launch_g(const WfArgs& a, bool act, bool stats, unsigned grid, hipStream_t st) {
-  if (act) return stats ? wf_launch<G, true, true>(a, grid, st) : wf_launch<G, true, false>(a, grid, st);
-  return stats ? wf_launch<G, false, true>(a, grid, st) : wf_launch<G, false, false>(a, grid, st);
+  if (act) return stats ? wf_launch<G, true, true, STRIPS>(a, grid, st) : wf_launch<G, true, false, STRIPS>(a, grid, st);
+  return stats ? wf_launch<G, false, true, STRIPS>(a, grid, st) : wf_launch<G, false, false, STRIPS>(a, grid, st);
 }
 
 }  // namespace
@@ -295,14 +317,14 @@ bool bp_f32_ws_ok(const ConvGeom& g, const bp_view* in, const bp_view* out, cons
   if ((int64_t)in->h * in->w * in->cstride * 4 >= (int64_t)1 << 31 || (int64_t)out->h * out->w * out->cstride * 4 >= (int64_t)1 << 31)
     return false;
   int BR, bands;
-  wf_bands(out->n, out->h, &BR, &bands);
-  return (int64_t)out->n * bands * 2 <= 0x7fffffff;
+  wf_bands(out->n, out->h, wf_strips(out->w), &BR, &bands);
+  return (int64_t)out->n * bands * wf_strips(out->w) * 2 <= 0x7fffffff;
 }
 
 size_t bp_f32_ws_stats_workspace(const ConvGeom& g, const bp_view* out) {
   int BR, bands;
-  wf_bands(out->n, out->h, &BR, &bands);
-  return bp_stats_rows_bytes((int64_t)out->n * bands, g.cout_g);
+  wf_bands(out->n, out->h, wf_strips(out->w), &BR, &bands);
+  return bp_stats_rows_bytes((int64_t)out->n * bands * wf_strips(out->w), g.cout_g);
 }
 
 int bp_f32_ws_run(const ConvGeom& g, const bp_view* in, const PW& pw, const float* packed_tiled, const bp_view* out,
@@ -311,8 +333,9 @@ int bp_f32_ws_run(const ConvGeom& g, const bp_view* in, const PW& pw, const floa
   a.in = in->ptr; a.in_cs = in->cstride; a.in_co = in->coff;
   a.out = out->ptr; a.out_cs = out->cstride; a.out_co = out->coff;
   a.n = out->n; a.h = out->h; a.wp = packed_tiled; a.pw = pw;
-  wf_bands(out->n, out->h, &a.BR, &a.bands);
-  const int64_t rows = (int64_t)out->n * a.bands;
+  a.iw = out->w; a.strips = wf_strips(out->w);
+  wf_bands(out->n, out->h, a.strips, &a.BR, &a.bands);
+  const int64_t rows = (int64_t)out->n * a.bands * a.strips;
   if (sr) {
     const size_t need = bp_stats_rows_bytes(rows, g.cout_g);
     if (sr->mode != 1 || !need) return BP_EUNSUPPORTED;
@@ -322,7 +345,9 @@ int bp_f32_ws_run(const ConvGeom& g, const bp_view* in, const PW& pw, const floa
   const bool act = pw.scale != nullptr;
   int rc;
   switch (wf_G(out->w)) {
-    case 4: rc = wf_launch_g<4>(a, act, sr != nullptr, (unsigned)(rows * 2), st); break;
+    case 4: rc = a.strips > 1 ? wf_launch_g<4, true>(a, act, sr != nullptr, (unsigned)(rows * 2), st)
+                              : wf_launch_g<4>(a, act, sr != nullptr, (unsigned)(rows * 2), st);
+            break;
     case 2: rc = wf_launch_g<2>(a, act, sr != nullptr, (unsigned)(rows * 2), st); break;
     default: rc = wf_launch_g<1>(a, act, sr != nullptr, (unsigned)(rows * 2), st); break;
   }

@@ -40,17 +40,29 @@ class _GanPlan:
         self.g_units, self.g_raw = gu, gs
         # discriminator input: [dm, z-1, pressure] for the real (first n) and the fake (last n) half
         self.d_in = Slot.new(2 * n, H, W, 3, dev, cstride=4)
+        # (the discriminator step needs no d(loss)/d(input): its first layer computes no data gradient)
         du, ds, tr = compile_sequential(self, "discriminator.", model.d_arch, model.discriminator, self.d_in,
-                                        need_input_grad=True)
+                                        need_input_grad=False)
         if [t[0] for t in tr] != ["sigmoid"]:
             raise NotImplementedError("the discriminator must end in conv + sigmoid")
         self.d_units, self.d_raw = du, ds
         if ds.c != 1 or ds.pw is not None:
             raise ValueError("discriminator head must be a single raw channel")
+        # The generator step goes through the discriminator for d(loss)/d(fake) only.  The discriminator has no batch-norm,
+        # so D(fake) does not depend on the real half and the real half's gradients are exactly zero: a second set of units
+        # over the FAKE half alone (same parameter holders, n images instead of 2n) does half the work of the full pass,
+        # and its first layer's data gradient is restricted to the generated channel.
+        self.d_in_fake = Slot(self.d_in.buf[n:], n, H, W, 3, 0)
+        du2, ds2, _ = compile_sequential(self, "discriminator.", model.d_arch, model.discriminator, self.d_in_fake,
+                                         need_input_grad=True)
+        du2[0].restrict_dgrad(2, 3)
+        self.d_units_fake, self.d_raw_fake = du2, ds2
         self.x_nchw = torch.zeros((n, 1, H, W), device=dev)
         self.sums = torch.zeros(4, device=dev, dtype=torch.float64)
         self.need_ws(256 * 8)
         for u in reversed(du):
+            u.prepare_backward()
+        for u in reversed(du2):
             u.prepare_backward()
         for u in reversed(gu):
             u.prepare_backward()
@@ -67,8 +79,8 @@ class _GanPlan:
         self.v_fake_cond = L.View(di.buf[n:].data_ptr(), n, h_, w_, 2, di.cstride, 0)
         self.v_real_x = L.View(di.buf.data_ptr(), n, h_, w_, 1, di.cstride, 2)
         self.v_fake_x = L.View(di.buf[n:].data_ptr(), n, h_, w_, 1, di.cstride, 2)
-        di.ensure_grad()
-        self.v_dfake = L.View(di.grad_buf[n:].data_ptr(), n, h_, w_, 1, di.cstride, 2)
+        self.d_in_fake.ensure_grad()
+        self.v_dfake = L.View(self.d_in_fake.grad_buf.data_ptr(), n, h_, w_, 1, di.cstride, 2)
         self.cnt_d = float(n * ds.h * ds.w)           # discriminator outputs per half
         self.cnt_px = float(n * H * W)
 
@@ -112,10 +124,10 @@ class _GanPlan:
             L.check(lib.bp_nchw_to_view(L.ptr(y), 1, L.ptr(zc), 1, C.byref(v), st), "condition planes")
         L.check(lib.bp_nchw_to_view(L.ptr(self.x_nchw), 1, None, 0, C.byref(self.v_real_x), st), "real field")
 
-    def discriminate(self, training):
+    def discriminate(self, training, fake_only=False):
         for h in self.model.sn_layers:
             h.refresh(training)
-        for u in self.d_units:
+        for u in (self.d_units_fake if fake_only else self.d_units):
             u.forward(training)
 
     def d_losses(self):
@@ -124,6 +136,19 @@ class _GanPlan:
         for k, (n0, n1, t) in enumerate(((0, n, 1.0), (n, 2 * n, 0.0), (n, 2 * n, 1.0))):
             L.check(lib.bp_bce_logits(C.byref(r.view), n0, n1, t, L.ptr(self.sums[k:]), L.ptr(self.ws), self.ws_bytes,
                                       st), "bce")
+
+    def g_adv_loss(self):
+        """sums[2] = sum BCE(D(fake), 1) from the fake-half units (generator step)."""
+        L.check(self.lib.bp_bce_logits(C.byref(self.d_raw_fake.view), 0, self.n, 1.0, L.ptr(self.sums[2:]), L.ptr(self.ws),
+                                       self.ws_bytes, _stream()), "bce")
+
+    def backward_d_fake(self, grads, scale):
+        """d(sum BCE(D(fake), 1) * scale)/d(fake) through the fake-half units (no parameter gradients: skip_wgrad)."""
+        r = self.d_raw_fake
+        L.check(self.lib.bp_bce_logits_grad(C.byref(r.view), 0, self.n, 1.0, scale, C.byref(r.grad), _stream()), "bce grad")
+        for u in reversed(self.d_units_fake):
+            u.backward(grads)
+        self._join_side()
 
     def backward_d(self, grads, seed_real, seed_fake_target, fake_scale):
         """Seed d(loss)/d(logits): real half scale*(sigmoid-1) or 0; fake half with the given target."""
@@ -273,14 +298,14 @@ class CGAN(torch.nn.Module):
                 capture["d"] = {k: p.grad.clone() for k, p in self.discriminator.named_parameters()}
             opt_d.step()
             # ---- generator step (same fake, updated discriminator)
-            plan.discriminate(self.training)
-            plan.d_losses()
+            plan.discriminate(self.training, fake_only=True)
+            plan.g_adv_loss()
             lib, st = self._lib, _stream()
             L.check(lib.bp_l1_sum(C.byref(plan.v_fake_x), L.ptr(plan.x_nchw), L.ptr(plan.sums[3:]), L.ptr(plan.ws),
                                   plan.ws_bytes, st), "l1")
             plan.skip_wgrad = True          # through D only for d(loss)/d(fake): its parameters do not step here
             try:
-                plan.backward_d(self._grads, 0.0, 1.0, 0.5 / plan.cnt_d)
+                plan.backward_d_fake(self._grads, 0.5 / plan.cnt_d)
             finally:
                 plan.skip_wgrad = False
             plan.backward_g(self._grads, self.lambda_perceptual / plan.cnt_px)

@@ -610,7 +610,8 @@ def test_auto_takes_the_direct_kernel_for_views_the_register_resident_kernels_re
 
 # ---- the weights-stationary fp32 kernel of the 128 -> 128 k3 trunk (csrc/conv_ws_f32.hip) against the tiled kernel
 @pytest.mark.parametrize("act", ["none", "relu", "leaky"])
-@pytest.mark.parametrize("shape", [(2, 9, 16), (3, 20, 32), (2, 64, 64), (70, 8, 16)], ids=lambda s: "%dx%dx%d" % s)
+@pytest.mark.parametrize("shape", [(2, 9, 16), (3, 20, 32), (2, 64, 64), (70, 8, 16), (2, 11, 128), (1, 6, 192)],
+                         ids=lambda s: "%dx%dx%d" % s)        # (128, 192: column strips of 64 pixels, the CGAN generator's trunk)
 def test_weights_stationary_fp32_trunk_kernel(shape, act):
     """Forward (+ the batch-norm sums from the epilogue) and data gradient of Conv2d(128, 128, 3, 1, 1) through both fp32
     kernels (bp_set_option("f32_ws", 1 / 0)): each within 2e-5 of the float64 convolution, the sums within 1e-10 of the sum of
@@ -695,7 +696,8 @@ def test_weights_stationary_fp32_trunk_kernel(shape, act):
 
 
 @pytest.mark.parametrize("act", ["none", "relu"])
-@pytest.mark.parametrize("shape", [(2, 9, 16), (3, 20, 32), (2, 64, 64), (70, 8, 16)], ids=lambda s: "%dx%dx%d" % s)
+@pytest.mark.parametrize("shape", [(2, 9, 16), (3, 20, 32), (2, 64, 64), (70, 8, 16), (2, 11, 128), (1, 6, 192), (2, 128, 128)],
+                         ids=lambda s: "%dx%dx%d" % s)
 def test_output_stationary_fp32_trunk_weight_gradient(shape, act):
     """bp_conv_backward_weight of Conv2d(128, 128, 3, 1, 1) through the output-stationary kernel (csrc/conv_wgrad_ws_f32.hip)
     and through the tap-blocked tiled kernel (bp_set_option("f32_wgrad_ws", 1 / 0)): both within 1e-4 of the float64
@@ -709,7 +711,7 @@ def test_output_stationary_fp32_trunk_weight_gradient(shape, act):
     dy = rng.standard_normal((n, co, h, w)).astype(np.float32)
     scale = rng.uniform(0.5, 1.5, ci).astype(np.float32)
     shift = rng.uniform(-0.3, 0.6, ci).astype(np.float32)
-    slope = np.zeros(ci, np.float32)
+    slope = np.zeros(ci, np.float32) if w < 128 else np.full(ci, 0.2, np.float32)      # (the CGAN trunk: LeakyReLU(0.2))
     if act == "none":
         xa = x.astype(np.float64)
     else:
