@@ -24,10 +24,13 @@ __global__ __launch_bounds__(RB) void paint_load_kernel(const float* src, int c,
                                                         int out2_cs, int out2_co, int64_t hw, int64_t total) {
   const int64_t i = (int64_t)blockIdx.x * RB + threadIdx.x;
   if (i >= total) return;
-  const int ct = c + caux;
-  const int ch = i % ct;
-  const int64_t p = i / ct;
-  const int64_t n = p / hw, yx = p % hw;
+  // (32-bit index arithmetic, shifts where the sizes are powers of two: four 64-bit divisions by run-time values per
+  //  element were what this kernel spent its time on -- the entry points check total < 2^31)
+  const unsigned ct = (unsigned)(c + caux), iu = (unsigned)i, hwu = (unsigned)hw;
+  const unsigned pu = ct == 2u ? iu >> 1 : iu / ct;
+  const int ch = (int)(iu - pu * ct);
+  const unsigned nu = (hwu & (hwu - 1u)) == 0u ? pu >> (__ffs((int)hwu) - 1) : pu / hwu;
+  const int64_t p = pu, n = nu, yx = pu - nu * hwu;
   float v;
   if (ch < c) {
     // np.log(x / std + 1) / k  with float32 x and float64 std: evaluated in double, stored as float32
@@ -47,9 +50,12 @@ __global__ __launch_bounds__(RB) void paint_store_kernel(const float* src, int s
                                                          int64_t total) {
   const int64_t i = (int64_t)blockIdx.x * RB + threadIdx.x;     // NCHW destination index (coalesced writes)
   if (i >= total) return;
-  const int64_t yx = i % hw;
-  const int ch = (i / hw) % c;
-  const int64_t n = i / (hw * c);
+  const unsigned iu = (unsigned)i, hwu = (unsigned)hw;          // (32-bit arithmetic: see paint_load_kernel)
+  const unsigned pl = (hwu & (hwu - 1u)) == 0u ? iu >> (__ffs((int)hwu) - 1) : iu / hwu;        // plane = n * c + ch
+  const int64_t yx = iu - pl * hwu;
+  const unsigned nu = c == 1 ? pl : pl / (unsigned)c;
+  const int ch = (int)(pl - nu * (unsigned)c);
+  const int64_t n = nu;
   float v = pw_apply(pw, ch, src[(n * hw + yx) * src_cs + src_co + ch]);
   if (softplus) v = softplus_f(v);
   // (np.exp(x * k) - 1) * std: float32 product, float32 exp, float32 subtraction, double product
@@ -113,6 +119,7 @@ int bp_paint_load(const float* raw_nchw, int32_t c, const double* sigma_k, const
   if (!raw_nchw || !sigma_k || !bp_view_ok(out) || c <= 0 || caux < 0 || out->c != c + caux || (caux > 0 && !aux))
     return BP_EINVAL;
   const int64_t hw = (int64_t)out->h * out->w, total = (int64_t)out->n * hw * (c + caux);
+  if (total >= (int64_t)1 << 31) return BP_EUNSUPPORTED;
   hipLaunchKernelGGL(paint_load_kernel, dim3(nblocks(total)), dim3(RB), 0, bp_stream(stream), raw_nchw, c, sigma_k, aux,
                      caux, out->ptr, out->cstride, out->coff, (float*)nullptr, 0, 0, hw, total);
   BP_CHECK_LAUNCH();
@@ -125,6 +132,7 @@ int bp_paint_load2(const float* raw_nchw, int32_t c, const double* sigma_k, cons
       out2->c != out->c || out2->n != out->n || out2->h != out->h || out2->w != out->w || (caux > 0 && !aux))
     return BP_EINVAL;
   const int64_t hw = (int64_t)out->h * out->w, total = (int64_t)out->n * hw * (c + caux);
+  if (total >= (int64_t)1 << 31) return BP_EUNSUPPORTED;
   hipLaunchKernelGGL(paint_load_kernel, dim3(nblocks(total)), dim3(RB), 0, bp_stream(stream), raw_nchw, c, sigma_k, aux,
                      caux, out->ptr, out->cstride, out->coff, out2->ptr, out2->cstride, out2->coff, hw, total);
   BP_CHECK_LAUNCH();
@@ -135,6 +143,7 @@ int bp_paint_store(const bp_view* src, const bp_pointwise* pw, int32_t softplus,
                    void* stream) {
   if (!bp_view_ok(src) || !k_sigma || !dst_nchw) return BP_EINVAL;
   const int64_t hw = (int64_t)src->h * src->w, total = (int64_t)src->n * hw * src->c;
+  if (total >= (int64_t)1 << 31) return BP_EUNSUPPORTED;
   hipLaunchKernelGGL(paint_store_kernel, dim3(nblocks(total)), dim3(RB), 0, bp_stream(stream), src->ptr, src->cstride,
                      src->coff, src->c, bp_pw(pw), softplus, k_sigma, dst_nchw, hw, total);
   BP_CHECK_LAUNCH();

@@ -689,7 +689,7 @@ def main():
         leg = _paint_leg(args, model, args.dtype, dev, world, rank, args.batch)
         if rank == 0:
             leg.update({"n_gpus": world, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
-                        "data": "synthetic",
+                        "data": "synthetic (8 distinct raw tiles per rank, repeated; random-init weights)",
                         "config": {"workload": f"paint_stream, {args.paint_tiles} raw {args.tile}x{args.tile} tiles per GPU through "
                                                "the CVAE fiducial prior + generator (random-init weights), batch "
                                                f"{min(args.batch, 64)}, host tile in -> host tile out"}})
@@ -725,7 +725,8 @@ def main():
     if rank == 0:
         out = {k: head[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step")}
         out.update({"higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": head["dtype"],
-                    "data": "synthetic", "config": head["config"]})
+                    "data": "synthetic (8 distinct log-normal field tiles per rank, repeated to fill the batch; random-init weights)",
+                    "config": head["config"]})
         other = {}
         if head.get("paint"):
             other["paint (configs[4] per GPU)"] = _compact(head["paint"])
