@@ -14,22 +14,21 @@
 //   * it polls the flags of all ranks in ITS OWN buffer (system-scope loads of local memory), then sums the world_size
 //     contributions in rank order -- the same order on every rank: results are bitwise identical across ranks, as an
 //     all-reduce must be for the replicas to stay in step;
-//   * slot reuse: a rank can only contribute to collective i + 1 after it has finished reading collective i, and it can
-//     only finish i + 1 once EVERY rank has contributed to it, i.e. finished i -- so slot (i + 2) % NSLOT is free by the
-//     time anyone writes it; NSLOT = 4 leaves a margin;
+//   * slot reuse: a ring of NSLOT slots that holds more than a whole step's collectives (peer_dev.hpp);
 //   * every spin is bounded: on a timeout the kernel records it in the communicator's status word and returns (the step's
 //     numbers are then wrong; the host checks the word after the step and raises).
 // The host side (baryon_painter_amd/dist.py) validates the path at start-up with known data on every rank and falls back
 // to RCCL for the whole run if any rank saw a wrong sum or a timeout.
-#include "common.hpp"
+//
+// Fused form (bp_peer_bind): while a communicator is bound to the calling thread, the kernels that finish a layer's
+// batch-norm statistics (pointwise.hip: sum_partials_bn_kernel, sum_partials_bnbwd_kernel -- one workgroup per channel)
+// exchange their channel's sums themselves (peer_dev.hpp: peer_exchange, one flag per channel) between summing the
+// partial rows and the finalize arithmetic: a data-parallel step then has the launch count of the single-device step.
+#include "peer_dev.hpp"
 #include <cstring>
 #include <new>
 
 namespace {
-
-constexpr int PC_NSLOT = 4;
-constexpr int PC_MAXN = 1024;            // doubles per contribution
-constexpr int PC_MAXW = 16;              // ranks
 
 struct PeerComm {
   int rank, world;
@@ -41,12 +40,7 @@ struct PeerComm {
   hipIpcMemHandle_t handle;
 };
 
-// buffer layout: data [NSLOT][world][MAXN] doubles, then flags [NSLOT][world] 64-bit words (one 128-byte line each)
-__host__ __device__ inline size_t pc_data_off(int world, int slot, int r) { return ((size_t)slot * world + r) * PC_MAXN * sizeof(double); }
-__host__ __device__ inline size_t pc_flag_off(int world, int slot, int r) {
-  return (size_t)PC_NSLOT * world * PC_MAXN * sizeof(double) + ((size_t)slot * world + r) * 128;
-}
-inline size_t pc_bytes(int world) { return pc_flag_off(world, PC_NSLOT, 0); }
+thread_local PeerComm* t_bound = nullptr;            // bp_peer_bind
 
 struct PcArgs {
   char* peer[PC_MAXW];
@@ -109,10 +103,29 @@ __global__ __launch_bounds__(256) void peer_all_reduce_kernel(PcArgs a) {
 
 }  // namespace
 
+bool bp_peer_next(PeerDev* out) {
+  PeerComm* c = t_bound;
+  if (!c) { out->world = 0; return false; }
+  for (int r = 0; r < PC_MAXW; ++r) out->peer[r] = r < c->world ? c->peer[r] : nullptr;
+  out->rank = c->rank; out->world = c->world; out->seq = ++c->seq; out->status = c->status;
+  out->spin_limit = 1ll << 22;
+  return true;
+}
+
 extern "C" {
+
+int bp_peer_bind(void* comm) {
+  PeerComm* c = reinterpret_cast<PeerComm*>(comm);
+  if (c)
+    for (int r = 0; r < c->world; ++r)
+      if (!c->peer[r]) return BP_EINVAL;
+  t_bound = c;
+  return BP_OK;
+}
 
 int bp_peer_handle_bytes(void) { return (int)sizeof(hipIpcMemHandle_t); }
 int bp_peer_max_doubles(void) { return PC_MAXN; }
+int bp_peer_slots(void) { return PC_NSLOT; }
 
 int bp_peer_create(int rank, int world, void** comm_out, void* handle_out) {
   if (!comm_out || !handle_out || world < 1 || world > PC_MAXW || rank < 0 || rank >= world) return BP_EINVAL;

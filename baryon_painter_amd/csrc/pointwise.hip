@@ -3,6 +3,7 @@
 // log-likelihood head and Adam.  All reductions are two-stage (per-block partials in a caller
 // workspace, then a fixed-order sum in double), so results are bitwise reproducible.
 #include "common.hpp"
+#include "peer_dev.hpp"
 #include <math.h>
 
 namespace {
@@ -901,8 +902,10 @@ __global__ __launch_bounds__(RB) void adam_dev_kernel(float* p, const float* g, 
 }  // namespace
 
 // sum_partials_wave_kernel for the two columns {c, C + c} of a channel (same order of additions: bitwise the same sums)
-// followed by bn_finalize_kernel's arithmetic for that channel
-__global__ __launch_bounds__(128) void sum_partials_bn_kernel(const double* partial, int nblk, int c, double* out, BnFin f) {
+// followed by bn_finalize_kernel's arithmetic for that channel.  Data parallel (pd.world > 0, peer_dev.hpp): the channel's
+// two sums are exchanged with the other ranks in between, so that the statistics are those of the global batch.
+__global__ __launch_bounds__(128) void sum_partials_bn_kernel(const double* partial, int nblk, int c, double* out, BnFin f,
+                                                              PeerDev pd) {
   __shared__ double sh[2];
   const int ch = blockIdx.x, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int col = w * c + ch;
@@ -913,6 +916,12 @@ __global__ __launch_bounds__(128) void sum_partials_bn_kernel(const double* part
   if (lane == 0) { out[col] = t; sh[w] = t; }
   __syncthreads();
   if (threadIdx.x != 0) return;
+  if (pd.world > 0) {
+    double v[2] = {sh[0], sh[1]};
+    peer_exchange<2>(pd, ch, c, v);
+    sh[0] = v[0]; sh[1] = v[1];
+    out[ch] = v[0]; out[c + ch] = v[1];
+  }
   if (ch == 0 && f.nbt) *f.nbt += 1;
   const double mean = sh[0] / f.count;
   double var = sh[1] / f.count - mean * mean;
@@ -932,7 +941,9 @@ __global__ __launch_bounds__(128) void sum_partials_bn_kernel(const double* part
 
 int bp_sum_partials_req(const double* partial, int nblk, int n, const IgemmStatsReq* sr, hipStream_t st) {
   if (!sr->fin) return bp_sum_partials(partial, nblk, n, sr->sums, st);
-  hipLaunchKernelGGL(sum_partials_bn_kernel, dim3(n / 2), dim3(128), 0, st, partial, nblk, n / 2, sr->sums, *sr->fin);
+  PeerDev pd;
+  if (bp_peer_next(&pd) && n > PC_MAXN) return BP_EUNSUPPORTED;        // (a bound communicator: the sums become global)
+  hipLaunchKernelGGL(sum_partials_bn_kernel, dim3(n / 2), dim3(128), 0, st, partial, nblk, n / 2, sr->sums, *sr->fin, pd);
   BP_CHECK_LAUNCH();
   return BP_OK;
 }
@@ -952,7 +963,8 @@ struct BnBwdFin {
   float pscale;
   float* dgamma; float* dbeta; double* coef;
 };
-__global__ __launch_bounds__(192) void sum_partials_bnbwd_kernel(const double* partial, int nblk, int c, double* sums, BnBwdFin f) {
+__global__ __launch_bounds__(192) void sum_partials_bnbwd_kernel(const double* partial, int nblk, int c, double* sums, BnBwdFin f,
+                                                                 PeerDev pd) {
   __shared__ double sh[3];
   const int ch = blockIdx.x, q = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int i = q * c + ch;
@@ -963,6 +975,12 @@ __global__ __launch_bounds__(192) void sum_partials_bnbwd_kernel(const double* p
   if (lane == 0) { sums[i] = t; sh[q] = t; }
   __syncthreads();
   if (threadIdx.x == 0) {
+    if (pd.world > 0) {        // data parallel: {sum g, sum g * raw} of the global batch (the third sum stays local)
+      double v[2] = {sh[0], sh[1]};
+      peer_exchange<2>(pd, ch, c, v);
+      sh[0] = v[0]; sh[1] = v[1];
+      sums[ch] = v[0]; sums[c + ch] = v[1];
+    }
     const double S0 = sh[0], S1 = sh[1];
     const double mean = f.smean[ch], inv = f.sinv[ch], g = f.gamma ? (double)f.gamma[ch] : 1.0;
     const double dg = inv * (S1 - mean * S0);
@@ -978,8 +996,11 @@ static thread_local const BnBwdFin* t_bnbwd = nullptr;       // set by bp_act_ba
 
 // the three sums of an activation backward, partial[nblk][3c] -> sums[3c] (+ the pending finalize)
 int bp_sum_partials3(const double* partial, int nblk, int c, double* sums, hipStream_t st) {
-  if (t_bnbwd) hipLaunchKernelGGL(sum_partials_bnbwd_kernel, dim3(c), dim3(192), 0, st, partial, nblk, c, sums, *t_bnbwd);
-  else hipLaunchKernelGGL(sum_partials_wave_kernel, dim3(3 * c), dim3(64), 0, st, partial, nblk, 3 * c, sums);
+  if (t_bnbwd) {
+    PeerDev pd;
+    if (bp_peer_next(&pd) && 2 * c > PC_MAXN) return BP_EUNSUPPORTED;
+    hipLaunchKernelGGL(sum_partials_bnbwd_kernel, dim3(c), dim3(192), 0, st, partial, nblk, c, sums, *t_bnbwd, pd);
+  } else hipLaunchKernelGGL(sum_partials_wave_kernel, dim3(3 * c), dim3(64), 0, st, partial, nblk, 3 * c, sums);
   BP_CHECK_LAUNCH();
   return BP_OK;
 }

@@ -28,6 +28,7 @@ class PeerAllReduce:
     def __init__(self, lib, comm, rank, world):
         self.lib, self.comm, self.rank, self.world = lib, comm, rank, world
         self.max_doubles = int(lib.bp_peer_max_doubles())
+        self.slots = int(lib.bp_peer_slots())
 
     @staticmethod
     def create(group, device):
@@ -64,8 +65,9 @@ class PeerAllReduce:
                 return None
         return peer
 
-    def _self_test(self, device, rounds=8):
-        """Known contributions, several rounds (every slot of the ring twice): the sum must be exact on this rank."""
+    def _self_test(self, device, rounds=None):
+        """Known contributions, once around the ring of slots and a little further: the sum must be exact on this rank."""
+        rounds = self.slots + 8 if rounds is None else rounds
         n = 257
         j = torch.arange(n, dtype=torch.float64, device=device)
         for r in range(rounds):
@@ -84,6 +86,12 @@ class PeerAllReduce:
 
     def usable(self, t):
         return t.is_cuda and t.dtype == torch.float64 and t.is_contiguous() and 0 < t.numel() <= self.max_doubles
+
+    def bind(self, on):
+        """Bind (unbind) the communicator to this host thread: the fused batch-norm finalize launches issued while it is
+        bound exchange their channel sums with the other ranks themselves (``bp_peer_bind``)."""
+        from . import _lib as L
+        L.check(self.lib.bp_peer_bind(self.comm if on else None), "peer bind")
 
     def timeouts(self):
         return int(self.lib.bp_peer_status(self.comm))
@@ -121,7 +129,7 @@ class Sync:
         self.grad_group = dist.new_group() if (grad_group == "new" and self.active) else \
             (group if grad_group in ("new", None) else grad_group)
         self.overlap = self.grad_group is not group and self.active
-        self.n_small = self.n_grad = 0
+        self.n_small = self.n_grad = self.n_fused = 0
         self.bytes_grad = 0
         self.timing = None           # bench.py: list of (start event, end event, kind) while enabled
         # batch-norm statistics over peer memory (one kernel per collective) where that path validates itself at start-up
@@ -136,6 +144,17 @@ class Sync:
             if t.is_cuda:
                 self.peer = PeerAllReduce.create(self.group, t.device)
         return self.peer if self.peer is not None and self.peer.usable(t) else None
+
+    def fused(self, device):
+        """True when batch-norm statistics are exchanged INSIDE the kernels that finalize them (peer memory validated on
+        every rank, BP_PEER_FUSED != 0): such layers issue no separate collective.  Collective at its first call (sets up
+        the peer path): every rank calls it at the same point of the program (the first batch-norm layer of a step)."""
+        if not (self.sync_bn and self.active):
+            return False
+        if not self._peer_tried:
+            self._peer_tried = True
+            self.peer = PeerAllReduce.create(self.group, torch.device(device))
+        return self.peer is not None and os.environ.get("BP_PEER_FUSED", "1") != "0"
 
     def check(self):
         """After a step (synchronises): raise if a peer-memory collective timed out (its sums were then wrong)."""
@@ -164,6 +183,11 @@ class Sync:
         """Batch-norm statistics (float64 vector of 2*C entries per layer of a level)."""
         if self.sync_bn and self.active:
             peer = self._peer_for(t)
+            if peer is None and self.peer is not None and os.environ.get("BP_PEER_FUSED", "1") != "0":
+                # (the plan put independent branches on streams of their own because statistics travel over peer memory:
+                #  a process-group collective from there would break the communicator's ordering)
+                raise RuntimeError("batch-norm statistics that the peer-memory all-reduce cannot carry "
+                                   f"({tuple(t.shape)} {t.dtype}): set BP_PEER_SYNC=0")
             with self._timed("bn"):
                 if peer is not None:
                     peer.all_reduce_sum(t)
@@ -173,6 +197,13 @@ class Sync:
 
     def all_reduce_mean(self, flat):
         """A gradient buffer (or a contiguous slice of one), on the CURRENT stream."""
+        if self.peer is not None:
+            # once per step: the peer-memory ring must hold more than a step's statistics exchanges (csrc/peer_dev.hpp)
+            done = self.n_small + self.n_fused
+            if done - getattr(self, "_stats_mark", done) >= self.peer.slots // 2:
+                raise RuntimeError("more batch-norm statistics exchanges per step than the peer-memory ring allows: "
+                                   "set BP_PEER_SYNC=0")
+            self._stats_mark = done
         if self.active:
             with self._timed("grad"):
                 dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.grad_group)

@@ -185,16 +185,20 @@ class _Plan:
         self.pack_batch = PackBatch(self, [u for u in all_units if isinstance(u, ConvUnit)])
         # Under data parallelism the recognition branches and the prior network advance level by level and share ONE
         # all-reduce of batch-norm sums per level (forward and backward): 14 fewer latency-bound collectives per step.
+        # Where the statistics travel over peer memory (dist.Sync.fused: exchanged inside the kernels that finalize them, or
+        # by the one-kernel all-reduce -- both on whatever stream the layer runs on, ordered by the ring of slots and not by
+        # a communicator) the branches keep their own streams instead, as on a single device.
+        sync_bn = model.sync is not None and model.sync.sync_bn
+        peer_stats = sync_bn and model.sync.fused(dev)
         self.levels = None
-        if model.sync is not None and model.sync.sync_bn and self.q_units and self.p_units \
-                and os.environ.get("BP_LEVEL_SYNC", "1") != "0":
+        if sync_bn and not peer_stats and self.q_units and self.p_units and os.environ.get("BP_LEVEL_SYNC", "1") != "0":
             self.levels = self._build_levels()
         self.branch = self._branch_streams = None
-        # (not with global batch-norm statistics: every batch-norm layer then all-reduces its sums, and collectives of
-        #  one communicator must not be in flight on several streams at once; with local statistics -- throughput mode --
-        #  the only collective is the gradient all-reduce after the joins)
+        # (not with global batch-norm statistics through a process group: every batch-norm layer then all-reduces its
+        #  sums, and collectives of one communicator must not be in flight on several streams at once; with local
+        #  statistics -- throughput mode -- the only collective is the gradient all-reduce after the joins)
         if os.environ.get("BP_BRANCH_STREAMS", "1") != "0" and self.q_units and self.p_units \
-                and (model.sync is None or not model.sync.sync_bn):
+                and (not sync_bn or peer_stats):
             self.branch = self._branch_streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
             self.ws_b, self.ws_c = torch.zeros_like(self.ws), torch.zeros_like(self.ws)
             for u in self._flat(self.q_units[1]):

@@ -472,20 +472,30 @@ class ConvUnit:
             # (running statistics and this unit's pending scale / shift are about to change: eval-mode users recompute)
             plan.model._bn_epoch = getattr(plan.model, "_bn_epoch", 0) + 1
         # single device: the batch-norm finalize rides on the launch that sums the epilogue's partial rows
-        fused_bn = fused and self.bn is not None and FUSED_FINALIZE \
-            and not (plan.sync is not None and plan.sync.sync_bn)
+        # ... and under data parallelism too where the finalize kernel exchanges the channel sums itself (dist.Sync.fused:
+        # peer memory; `count` is then the global pixel count)
+        sync_bn = plan.sync is not None and plan.sync.sync_bn
+        peer_fused = sync_bn and fused and self.bn is not None and FUSED_FINALIZE and plan.sync.fused(plan.device)
+        fused_bn = fused and self.bn is not None and FUSED_FINALIZE and (not sync_bn or peer_fused)
         t0 = plan.prof_begin()
         if fused_bn:
             bn = self.bn
-            self.count = float(self.out.n * self.out.h * self.out.w)
+            self.count = float(self.out.n * self.out.h * self.out.w) * (plan.sync.world_size if peer_fused else 1)
             dp = lambda t: None if t is None else t.data_ptr()
             bt = L.BnTrain(self.count, dp(bn.weight), dp(bn.bias), float(bn.eps), float(bn.momentum),
                            dp(bn.running_mean), dp(bn.running_var), dp(bn.num_batches_tracked),
                            dp(self.out_pw.scale), dp(self.out_pw.shift), dp(self.save_mean), dp(self.save_invstd))
-            L.check(lib.bp_conv_forward_bn(C.byref(self.cv), C.byref(self.inp.view), self.inp.pw_struct(),
-                                           L.ptr(self.packed_fwd), C.byref(self.out.view), L.ptr(self.sums),
-                                           C.byref(bt), L.ptr(self._ws()), plan.ws_bytes, self._stats_impl, st),
-                    f"{self.name} forward + bn stats + finalize")
+            if peer_fused:
+                plan.sync.peer.bind(True)
+                plan.sync.n_fused += 1
+            try:
+                L.check(lib.bp_conv_forward_bn(C.byref(self.cv), C.byref(self.inp.view), self.inp.pw_struct(),
+                                               L.ptr(self.packed_fwd), C.byref(self.out.view), L.ptr(self.sums),
+                                               C.byref(bt), L.ptr(self._ws()), plan.ws_bytes, self._stats_impl, st),
+                        f"{self.name} forward + bn stats + finalize")
+            finally:
+                if peer_fused:
+                    plan.sync.peer.bind(False)
         elif fused:
             L.check(lib.bp_conv_forward_stats(C.byref(self.cv), C.byref(self.inp.view), self.inp.pw_struct(),
                                               L.ptr(self.packed_fwd), C.byref(self.out.view), L.ptr(self.sums),
@@ -616,15 +626,26 @@ class ConvUnit:
             if self._sums_ready:
                 raise RuntimeError(f"{self.name}: fused statistics do not match this activation backward")
             t0 = plan.prof_begin()
-            if bn is not None and not (plan.sync is not None and plan.sync.sync_bn) and FUSE_BN_BWD_FINALIZE:
-                # single device: the batch-norm backward finalize rides on the launch that adds the partial sums
+            sync_bn = plan.sync is not None and plan.sync.sync_bn
+            peer_fused = sync_bn and bn is not None and FUSE_BN_BWD_FINALIZE and plan.sync.fused(plan.device)
+            if bn is not None and (not sync_bn or peer_fused) and FUSE_BN_BWD_FINALIZE:
+                # the batch-norm backward finalize rides on the launch that adds the partial sums; data parallel over peer
+                # memory: that launch also exchanges the channel sums (count is global, losses are per-rank means)
                 dp = lambda t: None if t is None else t.data_ptr()
-                fin = L.BnBackwardFin(self.count, dp(bn.weight), dp(self.save_mean), dp(self.save_invstd), 1.0,
+                pscale = 1.0 / plan.sync.world_size if peer_fused else 1.0
+                fin = L.BnBackwardFin(self.count, dp(bn.weight), dp(self.save_mean), dp(self.save_invstd), pscale,
                                       dp(grads[id(bn.weight)]), dp(grads[id(bn.bias)]), dp(self.abc))
-                L.check(lib.bp_act_backward_bn(C.byref(dout), d2, C.byref(self.out.view), pw, aout,
-                                               None if g_out is None else C.byref(g_out), L.ptr(self.sums),
-                                               C.byref(fin), L.ptr(self._ws()), plan.ws_bytes, st),
-                        f"{self.name} act backward + bn backward finalize")
+                if peer_fused:
+                    plan.sync.peer.bind(True)
+                    plan.sync.n_fused += 1
+                try:
+                    L.check(lib.bp_act_backward_bn(C.byref(dout), d2, C.byref(self.out.view), pw, aout,
+                                                   None if g_out is None else C.byref(g_out), L.ptr(self.sums),
+                                                   C.byref(fin), L.ptr(self._ws()), plan.ws_bytes, st),
+                            f"{self.name} act backward + bn backward finalize")
+                finally:
+                    if peer_fused:
+                        plan.sync.peer.bind(False)
                 finalized = True
             else:
                 L.check(lib.bp_act_backward(C.byref(dout), d2, C.byref(self.out.view), pw, aout,
@@ -636,7 +657,7 @@ class ConvUnit:
                     f"{self.name} prelu grad")
         if bn is not None:
             pscale = 1.0
-            if plan.sync is not None and plan.sync.sync_bn:
+            if plan.sync is not None and plan.sync.sync_bn and not finalized:
                 yield self.sums[:2 * c]
                 pscale = 1.0 / plan.sync.world_size       # sums are global, losses are per-rank means
             if not finalized:

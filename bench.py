@@ -252,7 +252,7 @@ def _traffic(kernel, dtype):
 
 def _collective_report(sync, step):
     """Two further steps of the timed schedule with HIP events around every all-reduce."""
-    n0, g0, b0 = sync.n_small, sync.n_grad, sync.bytes_grad
+    n0, g0, b0, f0 = sync.n_small, sync.n_grad, sync.bytes_grad, getattr(sync, "n_fused", 0)
     sync.timing = []
     for _ in range(2):
         step()
@@ -265,7 +265,9 @@ def _collective_report(sync, step):
                  "median_us": round(float(np.median(v)), 1), "max_us": round(max(v), 1)} for k, v in per.items()}
     sync.check()                                  # (a timed-out peer-memory collective would have corrupted the steps)
     n_grad = (sync.n_grad - g0) // 2
-    return {"collectives_per_step": {"batch_norm_statistics": (sync.n_small - n0) // 2, "gradient_buffers": n_grad},
+    return {"collectives_per_step": {"batch_norm_statistics": (sync.n_small - n0) // 2, "gradient_buffers": n_grad,
+                                     # exchanged inside the kernels that finalize the statistics: no launch of their own
+                                     "batch_norm_statistics_fused_into_finalize": (getattr(sync, "n_fused", 0) - f0) // 2},
             "gradient_bytes_per_step": (sync.bytes_grad - b0) // 2,
             "inside_collectives": stats,
             # (what RAN, from the count of gradient collectives: BP_GRAD_COMM=1 alone selects a second communicator but
@@ -273,7 +275,8 @@ def _collective_report(sync, step):
             "gradient_all_reduce": "generator trunk + heads (97 % of the bytes) early on the weight-gradient stream, own "
                                    "communicator (BP_EARLY_ALLREDUCE=1); the rest after the backward pass"
                                    if n_grad > 1 else "one flat buffer after the backward pass",
-            "statistics_transport": "one kernel per collective over IPC-mapped peer memory (csrc/peer_comm.hip)"
+            "statistics_transport": "IPC-mapped peer memory (csrc/peer_comm.hip): inside the finalize kernels where a layer has "
+                                    "one, else one kernel per collective"
                                     if getattr(sync, "peer", None) is not None else "process group",
             "backend": torch.distributed.get_backend()}
 

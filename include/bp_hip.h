@@ -427,10 +427,18 @@ int bp_adam_step_dev(float* param, const float* grad, float* exp_avg, float* exp
  * communicator's status word (bp_peer_status, synchronising) and the call's result is then undefined. */
 int bp_peer_handle_bytes(void);
 int bp_peer_max_doubles(void);
+int bp_peer_slots(void);                 /* slots of the exchange ring: a step must issue fewer than half as many collectives */
 int bp_peer_create(int rank, int world, void** comm_out, void* handle_out);
 int bp_peer_open(void* comm, const void* handles);
 int bp_peer_all_reduce(void* comm, double* data, int n, int64_t spin_limit, void* stream);
 int64_t bp_peer_status(void* comm);
+/* Bind `comm` (NULL: unbind) to the CALLING host thread.  While bound, every launch that finishes a layer's batch-norm
+ * statistics together with the finalize arithmetic -- bp_conv_forward_bn (the `count` of bp_bn_train is then the GLOBAL
+ * pixel count) and bp_act_backward_bn (`count` global, `pscale` = 1 / world size) -- exchanges each channel's two sums with
+ * the other ranks inside that kernel, in place of a separate all-reduce: the collective number advances as in
+ * bp_peer_all_reduce, so every rank must issue the same sequence of both kinds of call (cvae.py:224 semantics: the
+ * statistics of the global batch, as one nn.BatchNorm2d over the whole minibatch computes them). */
+int bp_peer_bind(void* comm);
 int bp_peer_destroy(void* comm);
 
 #ifdef __cplusplus
