@@ -5,12 +5,13 @@
 //
 // Matrix form: the layer gathers ONE channel, so the K index of an MFMA carries the tap window instead of channels:
 //     K = (tap-row slot kg = 0..3, window column j = 0..7)      B[(kg, j), pixel x] = dy[r0 + kg, x - 2 + j]
-//     M = (output row r = 0..3, channel cc = 0..3 of a half)    A[(r, cc), (kg, j)] = w[4 half + cc][4 - tap row][4 - j]
+//     M = (output row select rs = 0, 1; produced channel c)     A[(rs, c), (kg, j)] = w[c][4 - tap row][4 - j]
 // (taps reversed: the data gradient of a correlation; j = 5..7 and tap rows outside 0..4 carry zeros).  Two K-steps cover
-// exactly the eight gradient rows under FOUR output rows, two M tiles the two channel halves: 4 MFMAs per 16 pixels x
-// 4 rows x 8 channels, 7 us of matrix time for the whole tensor: the kernel is one read of dy, one read of the slot's raw
-// values and one bf16 store.  Lane (pixel, kg) ends up with row kg's channels 0..3 from one tile and 4..7 from the other:
-// all 8 channels of one pixel -- 16-byte loads of the raw values, 16-byte stores.
+// the six gradient rows under a PAIR of output rows: 2 MFMAs per 16 pixels x 2 rows x 8 channels, 7 us of matrix time
+// for the whole tensor: the kernel is one read of dy, one read of the slot's raw values and one bf16 store.
+// A lane ends up with 4 consecutive channels of one pixel: 8-byte loads of the raw values, 8-byte stores.  (A variant with
+// four output rows per pass -- two M tiles = the two channel halves, no dead K rows, 16-byte loads / stores -- measured
+// 0.23 ms against this one's 0.18.)
 // The window of a pixel starts at ANY 2-byte offset of the staged gradient row, so a fragment is five 2-byte LDS reads
 // (the tile is 3 KB; the reads are a few per cent of the kernel).
 #include "conv_bf16.hpp"
@@ -25,7 +26,7 @@ int bp_stats_rows_finish_n(double* ws, int64_t rows, int n, const IgemmStatsReq*
 namespace {
 
 constexpr int HD_K = 5, HD_C = 8, HD_TW = 64, HD_TH = 16, HD_LW = HD_TW + 8, HD_LH = HD_TH + HD_K - 1;
-constexpr int HD_PACKED = 4 * 64 * 8;
+constexpr int HD_PACKED = 2 * 64 * 8;
 
 struct HdArgs {
   const float* in; int h, w, in_cs, in_co;        // dy: one channel
@@ -40,15 +41,15 @@ struct HdArgs {
 
 struct HdPackArgs { const float* w; u16* dst; int64_t sa, sb; };
 
-// [channel half][K-step t][lane (row = lane & 15, kg = lane >> 4)][j]: row = (r, cc); gradient row r0 + 4 t + kg is tap
-// row 4 t + kg - r of output row r0 + 2 + r, i.e. weight row 4 - (4 t + kg - r)
+// [K-step t][lane (row = lane & 15, kg = lane >> 4)][j]: row = (rs, c); gradient row r0 + 4 t + kg is tap row
+// 4 t + kg - rs of output row r0 + 2 + rs, i.e. weight row 4 - (4 t + kg - rs)
 __global__ __launch_bounds__(256) void head_dgrad_pack_kernel(HdPackArgs a) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= HD_PACKED) return;
-  const int j = i & 7, lane = (i >> 3) & 63, t = (i >> 9) & 1, half = i >> 10;
+  const int j = i & 7, lane = (i >> 3) & 63, t = i >> 9;
   const int row = lane & 15, kg = lane >> 4;
-  const int r = row >> 2, c = 4 * half + (row & 3);
-  const int ky = 4 - (4 * t + kg - r), kx = 4 - j;
+  const int rs = row >> 3, c = row & 7;
+  const int ky = 4 - (4 * t + kg - rs), kx = 4 - j;
   float v = 0.f;
   if (ky >= 0 && ky < HD_K && kx >= 0) v = a.w[c * a.sb + ky * HD_K + kx];      // (gathered channel 0)
   a.dst[i] = f2bf(v);
@@ -86,80 +87,84 @@ __global__ __launch_bounds__(256) void head_dgrad_kernel(HdArgs a) {
       if (e < NE) tile[e] = f2bf(v[i]);
     }
   }
-  bf8 wf[2][2];
+  bf8 wf[2];
 #pragma unroll
-  for (int hf = 0; hf < 2; ++hf)
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-      wf[hf][t] = __builtin_bit_cast(bf8, *reinterpret_cast<const uint4*>(a.wp + ((hf * 2 + t) * 64 + lane) * 8));
+  for (int t = 0; t < 2; ++t) wf[t] = __builtin_bit_cast(bf8, *reinterpret_cast<const uint4*>(a.wp + (t * 64 + lane) * 8));
   __syncthreads();
 
   const int x0 = wave * 16;
   const int ox = tx0 + x0 + lj, oxc = min(ox, a.w - 1);
-  float es[3][HD_C];
-#pragma unroll
-  for (int q = 0; q < 3; ++q)
-#pragma unroll
-    for (int r = 0; r < HD_C; ++r) es[q][r] = 0.f;
-  // the slot's activation parameters: once, into registers (a load under a condition inside the row loop is waited for
-  // on the spot: 24 round trips per pass)
-  float psc[HD_C], psf[HD_C], psl[HD_C];
-#pragma unroll
-  for (int r = 0; r < HD_C; ++r) { psc[r] = 1.f; psf[r] = 0.f; psl[r] = 1.f; }
+  const int rs = kg >> 1, c0 = 4 * (kg & 1);
+  float psc[4] = {1.f, 1.f, 1.f, 1.f}, psf[4] = {0.f, 0.f, 0.f, 0.f}, psl[4] = {1.f, 1.f, 1.f, 1.f};
   if constexpr (ACT) {
     if (a.spw.scale) {
 #pragma unroll
-      for (int r = 0; r < HD_C; ++r) { psc[r] = a.spw.scale[r]; psf[r] = a.spw.shift[r]; psl[r] = a.spw.slope[r]; }
+      for (int r = 0; r < 4; ++r) { psc[r] = a.spw.scale[c0 + r]; psf[r] = a.spw.shift[c0 + r]; psl[r] = a.spw.slope[c0 + r]; }
     }
   }
+  float es[3][4];
+#pragma unroll
+  for (int q = 0; q < 3; ++q)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) es[q][r] = 0.f;
 
-#pragma unroll 1
-  for (int ps = 0; ps < HD_TH / 4; ++ps) {          // output rows ty0 + 4 ps + kg
-    const int oy = ty0 + 4 * ps + kg, oyc = min(oy, a.h - 1);
-    uint4 rw = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll 2
+  for (int pr = 0; pr < HD_TH / 2; ++pr) {          // pairs of output rows ty0 + 2 pr, + 1
+    const int oy = ty0 + 2 * pr + rs, oyc = min(oy, a.h - 1);
+    uint2 rw = make_uint2(0u, 0u);
     if constexpr (ACT)
-      rw = *reinterpret_cast<const uint4*>(a.raw + ((int64_t)(n * a.h + oyc) * a.w + oxc) * a.raw_cs + a.raw_co);
-    v4f acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+      rw = *reinterpret_cast<const uint2*>(a.raw + ((int64_t)(n * a.h + oyc) * a.w + oxc) * a.raw_cs + a.raw_co + c0);
+    v4f acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-      const u16* p = tile + (4 * ps + 4 * t + kg) * HD_LW + x0 + lj;
+      // (slots 6, 7 of the eight rows lie outside the pair's window: zero DATA as well as zero weights -- a NaN of
+      //  a gradient row must not reach pixels whose window does not hold it -- and no read past the tile)
+      const bool dead = t == 1 && kg >= 2;
+      const u16* p = tile + (dead ? 0 : 2 * pr + 4 * t + kg) * HD_LW + x0 + lj;
+      const unsigned keep = dead ? 0u : 0xffffffffu;
       const unsigned e0 = p[0], e1 = p[1], e2 = p[2], e3 = p[3], e4 = p[4];
-      const bf8 xf = __builtin_bit_cast(bf8, make_uint4(e0 | (e1 << 16), e2 | (e3 << 16), e4, 0u));
-      acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0][t], xf, acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[1][t], xf, acc[1], 0, 0, 0);
+      const bf8 xf = __builtin_bit_cast(bf8, make_uint4((e0 | (e1 << 16)) & keep, (e2 | (e3 << 16)) & keep, e4 & keep, 0u));
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[t], xf, acc, 0, 0, 0);
     }
-    float g[HD_C] = {acc[0][0], acc[0][1], acc[0][2], acc[0][3], acc[1][0], acc[1][1], acc[1][2], acc[1][3]};
+    float g[4] = {acc[0], acc[1], acc[2], acc[3]};
     if constexpr (ACT) {
-      const unsigned w4[4] = {rw.x, rw.y, rw.z, rw.w};
+      const float rv[4] = {bf2f((u16)(rw.x & 0xffffu)), bf2f((u16)(rw.x >> 16)), bf2f((u16)(rw.y & 0xffffu)),
+                           bf2f((u16)(rw.y >> 16))};
       const bool live = oy < a.h && ox < a.w;
 #pragma unroll
-      for (int r = 0; r < HD_C; ++r) {
-        const float rv = bf2f((u16)((r & 1) ? (w4[r >> 1] >> 16) : (w4[r >> 1] & 0xffffu)));
-        const float d = live ? g[r] : 0.f;
-        const float t = fmaf(rv, psc[r], psf[r]);
+      for (int r = 0; r < 4; ++r) {
+        const float d = live ? acc[r] : 0.f;
+        const float t = fmaf(rv[r], psc[r], psf[r]);
         const bool pos = t > 0.f;
         g[r] = pos ? d : d * psl[r];
         es[0][r] += g[r];
-        es[1][r] = fmaf(g[r], rv, es[1][r]);
+        es[1][r] = fmaf(g[r], rv[r], es[1][r]);
         if (!pos) es[2][r] = fmaf(d, t, es[2][r]);
       }
     }
     if (oy < a.h && ox < a.w)
-      *reinterpret_cast<uint4*>(a.out + ((int64_t)(n * a.h + oy) * a.w + ox) * a.out_cs + a.out_co) =
-          make_uint4(pack2(g[0], g[1]), pack2(g[2], g[3]), pack2(g[4], g[5]), pack2(g[6], g[7]));
+      *reinterpret_cast<uint2*>(a.out + ((int64_t)(n * a.h + oy) * a.w + ox) * a.out_cs + a.out_co + c0) =
+          make_uint2(pack2(g[0], g[1]), pack2(g[2], g[3]));
   }
   if constexpr (ACT) {
-    // a lane's 4 pixels and the wave's 64 lanes in fp32 (256 terms), waves and workgroups in double, fixed order (the
-    // scheme of small_conv_kernel)
+    // a lane's 8 pixels and the 32 lanes that share its channel quad in fp32 (256 terms), waves and workgroups in
+    // double, fixed order (the scheme of small_conv_kernel)
 #pragma unroll
     for (int q = 0; q < 3; ++q)
 #pragma unroll
-      for (int r = 0; r < HD_C; ++r) {
+      for (int r = 0; r < 4; ++r) {
         float v = es[q][r];
 #pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-        if (lane == 0) ered[wave][q * HD_C + r] = v;
+        for (int m = 8; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+        v += __shfl_xor(v, 32, 64);
+        es[q][r] = v;
       }
+    if (lj == 0 && kg < 2) {
+#pragma unroll
+      for (int q = 0; q < 3; ++q)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ered[wave][q * HD_C + c0 + r] = es[q][r];
+    }
     __syncthreads();
     if (tid < a.stat_stride)
       a.stat[(int64_t)blockIdx.x * a.stat_stride + tid] =
@@ -192,7 +197,7 @@ bool bp_bf16_head_ok(const ConvGeom& g, const bp_view* in, const bp_view* out, c
   if (!hd_geom(g) || bias || !in || !out || (mode != 0 && mode != 3)) return false;
   if (in->dtype != BP_F32 || out->dtype != BP_BF16 || in->c != 1 || out->c != HD_C) return false;
   if (in->n != out->n || in->h != out->h || in->w != out->w) return false;
-  if (out->cstride % 8 || out->coff % 8 || reinterpret_cast<uintptr_t>(out->ptr) % 16) return false;
+  if (out->cstride % 4 || out->coff % 4 || reinterpret_cast<uintptr_t>(out->ptr) % 8) return false;
   return hd_rows(out) < (1ll << 31);
 }
 
@@ -218,7 +223,7 @@ int bp_bf16_head_run(const ConvGeom& g, const bp_view* in, const u16* packed_hea
   const bp_view* r = sr->raw;
   if (sr->mode != 3) return BP_EUNSUPPORTED;
   if (!r || r->n != out->n || r->h != out->h || r->w != out->w || r->c != out->c || !sr->sums) return BP_EINVAL;
-  if (r->dtype != BP_BF16 || r->cstride % 8 || r->coff % 8 || reinterpret_cast<uintptr_t>(r->ptr) % 16) return BP_EUNSUPPORTED;
+  if (r->dtype != BP_BF16 || r->cstride % 4 || r->coff % 4 || reinterpret_cast<uintptr_t>(r->ptr) % 8) return BP_EUNSUPPORTED;
   const int ns = 3 * HD_C;
   if (!sr->ws || sr->ws_bytes < bp_stats_rows_bytes_n(rows, ns)) return BP_EWORKSPACE;
   a.raw = reinterpret_cast<const u16*>(r->ptr); a.raw_cs = r->cstride; a.raw_co = r->coff;
