@@ -95,6 +95,7 @@ SIGNATURES = {
     "bp_peer_status": (C.c_int64, [_P]),
     "bp_peer_bind": (C.c_int, [_P]),
     "bp_peer_slots": (C.c_int, []),
+    "bp_peer_exchange_check": (C.c_int, [_P, _P, C.c_int, _P]),
     "bp_peer_destroy": (C.c_int, [_P]),
     "bp_channel_sums_workspace": (C.c_size_t, [_VP]),
     "bp_channel_sums": (C.c_int, [_VP, _P, _P, C.c_size_t, _P]),

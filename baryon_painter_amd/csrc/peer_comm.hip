@@ -101,6 +101,15 @@ __global__ __launch_bounds__(256) void peer_all_reduce_kernel(PcArgs a) {
   }
 }
 
+// the per-channel exchange on its own (start-up self-test of the fused path): workgroup ch sums {data[ch], data[c + ch]} over the ranks
+__global__ __launch_bounds__(64) void peer_exchange_check_kernel(PeerDev pd, double* data, int c) {
+  if (threadIdx.x != 0) return;
+  const int ch = blockIdx.x;
+  double v[2] = {data[ch], data[c + ch]};
+  peer_exchange<2>(pd, ch, c, v);
+  data[ch] = v[0]; data[c + ch] = v[1];
+}
+
 }  // namespace
 
 bool bp_peer_next(PeerDev* out) {
@@ -120,6 +129,19 @@ int bp_peer_bind(void* comm) {
     for (int r = 0; r < c->world; ++r)
       if (!c->peer[r]) return BP_EINVAL;
   t_bound = c;
+  return BP_OK;
+}
+
+int bp_peer_exchange_check(void* comm, double* data, int c, void* stream) {
+  PeerComm* cm = reinterpret_cast<PeerComm*>(comm);
+  if (!cm || !data || c < 1 || 2 * c > PC_MAXN) return BP_EINVAL;
+  PeerComm* keep = t_bound;
+  t_bound = cm;
+  PeerDev pd;
+  (void)bp_peer_next(&pd);
+  t_bound = keep;
+  hipLaunchKernelGGL(peer_exchange_check_kernel, dim3(c), dim3(64), 0, bp_stream(stream), pd, data, c);
+  BP_CHECK_LAUNCH();
   return BP_OK;
 }
 

@@ -76,6 +76,17 @@ class PeerAllReduce:
             want = (self.world * (self.world + 1) / 2.0) * (j + 1.0) + r * self.world
             if not torch.equal(t, want):
                 return False
+        # ... and the per-channel exchange that the batch-norm finalize kernels run (bp_peer_bind): 128 channels x 2 sums
+        from . import _lib as L
+        c = 128
+        j = torch.arange(2 * c, dtype=torch.float64, device=device)
+        for r in range(4):
+            t = (self.rank + 1.0) * (j + 1.0) - r
+            L.check(self.lib.bp_peer_exchange_check(self.comm, t.data_ptr(), c,
+                                                    C.c_void_p(torch.cuda.current_stream(device).cuda_stream)), "peer exchange check")
+            want = (self.world * (self.world + 1) / 2.0) * (j + 1.0) - r * self.world
+            if not torch.equal(t, want):
+                return False
         return self.timeouts() == 0
 
     def all_reduce_sum(self, t):

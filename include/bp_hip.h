@@ -439,6 +439,9 @@ int64_t bp_peer_status(void* comm);
  * bp_peer_all_reduce, so every rank must issue the same sequence of both kinds of call (cvae.py:224 semantics: the
  * statistics of the global batch, as one nn.BatchNorm2d over the whole minibatch computes them). */
 int bp_peer_bind(void* comm);
+/* The per-channel exchange of the bound form on its own, one collective: data[ch] and data[c + ch] (2 c <=
+ * bp_peer_max_doubles()) summed over the ranks by workgroup ch -- the start-up self-test of that path (dist.py). */
+int bp_peer_exchange_check(void* comm, double* data, int c, void* stream);
 int bp_peer_destroy(void* comm);
 
 #ifdef __cplusplus

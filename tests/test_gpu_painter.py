@@ -110,7 +110,11 @@ if early == "1":
 dp, e_dp = run(sync, slice(r * h, (r + 1) * h))
 assert sync.n_grad == (3 if early == "1" else 1), sync.n_grad
 # the batch-norm statistics travelled through the peer-memory kernel (csrc/peer_comm.hip), not the process group
-assert sync.peer is not None and sync.peer.world == w, "peer-memory all-reduce was not set up"
+if os.environ.get("BP_PEER_SYNC", "1") != "0":
+    assert sync.peer is not None and sync.peer.world == w, "peer-memory all-reduce was not set up"
+    assert (sync.n_fused > 0) == (os.environ.get("BP_PEER_FUSED", "1") != "0"), sync.n_fused
+else:
+    assert sync.peer is None and sync.n_fused == 0
 sync.check()
 t = torch.tensor([e_dp], dtype=torch.float64, device=dev if backend == "nccl" else "cpu"); dist.all_reduce(t); e_mean = t.item() / w
 if r == 0:
@@ -135,7 +139,7 @@ dist.destroy_process_group()
 """
 
 
-def _run_dp_worker(tmp_path, backend, dtype, early):
+def _run_dp_worker(tmp_path, backend, dtype, early, transport="peer"):
     import socket
     script = tmp_path / "dp_worker.py"
     script.write_text(_DP_WORKER)
@@ -144,6 +148,13 @@ def _run_dp_worker(tmp_path, backend, dtype, early):
         port = sk.getsockname()[1]
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     env.pop("BP_EARLY_ALLREDUCE", None)
+    # batch-norm statistics: inside the finalize kernels over peer memory (default) / one peer-memory kernel per
+    # collective (BP_PEER_FUSED=0) / the process group's all-reduce with the branch networks in lock step (BP_PEER_SYNC=0)
+    env.pop("BP_PEER_SYNC", None); env.pop("BP_PEER_FUSED", None)
+    if transport == "peer-unfused":
+        env["BP_PEER_FUSED"] = "0"
+    elif transport == "group":
+        env["BP_PEER_SYNC"] = "0"
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
                           "--master-addr", "127.0.0.1", "--master-port", str(port), str(script), ROOT, str(tmp_path),
                           backend, dtype, early],
@@ -152,13 +163,15 @@ def _run_dp_worker(tmp_path, backend, dtype, early):
     assert (tmp_path / "dp.ok").exists()
 
 
-@pytest.mark.parametrize("dtype,early", [("f32", "0"), ("f32", "1"), ("bf16", "0")])
-def test_two_rank_data_parallel_equals_single_device(tmp_path, dtype, early):
-    """Sharded batch + all-reduced batch-norm statistics + averaged gradients == the single-device global batch (the
-    reference's arithmetic); gloo collectives, both ranks on this GPU.  ``early``: the opt-in schedule with the
+@pytest.mark.parametrize("dtype,early,transport", [("f32", "0", "peer"), ("f32", "1", "peer"), ("bf16", "0", "peer"),
+                                                   ("f32", "0", "group"), ("bf16", "0", "peer-unfused")])
+def test_two_rank_data_parallel_equals_single_device(tmp_path, dtype, early, transport):
+    """Sharded batch + global batch-norm statistics + averaged gradients == the single-device global batch (the
+    reference's arithmetic); gloo process group, both ranks on this GPU.  ``early``: the opt-in schedule with the
     trunk's gradients reduced on the weight-gradient stream through a second communicator.  bf16: the data-parallel
-    + bf16 combination of BASELINE.json configs[3]."""
-    _run_dp_worker(tmp_path, "gloo", dtype, early)
+    + bf16 combination of BASELINE.json configs[3].  ``transport``: how the statistics travel (see _run_dp_worker): the
+    fallbacks stay covered."""
+    _run_dp_worker(tmp_path, "gloo", dtype, early, transport)
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: RCCL wants one device per rank")
