@@ -30,6 +30,7 @@ struct WwArgs {
   PW pwx;                            // pending activation of X (this layer's input) or nullptr
   float* ws;                         // [split][tap 9][co 128][ci 128]
   int BR, bands;
+  int nsplit;                        // images x bands x strips
 };
 
 template <int G> struct WwGeom {
@@ -54,7 +55,10 @@ __global__ __launch_bounds__(256) void wgrad_ws_f32_kernel(WwArgs a) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lm = lane & 15, kq = lane >> 4;
-  const int pair = blockIdx.x & 3, split = blockIdx.x >> 2;
+  // block id = split_lo + 8 * (pair + 4 * split_hi): workgroups go to the XCDs round-robin by id, so the four channel-block
+  // pairs of a split -- which read the same X and dY rows -- share an XCD's L2 (577 -> ~300 MB of HBM per launch)
+  const int split = (int)(blockIdx.x & 7) + 8 * (int)(blockIdx.x >> 5), pair = (blockIdx.x >> 3) & 3;
+  if (split >= a.nsplit) return;
   const int cib = pair & 1, cob = pair >> 1;
   const int strip = split % a.strips, nbd = split / a.strips;
   const int n = nbd / a.bands, band = nbd % a.bands;
@@ -259,8 +263,9 @@ int bp_wgrad_ws_f32(const bp_conv* cv, const bp_view* X, const PW& pwx, const bp
   a.X = X->ptr; a.x_cs = X->cstride; a.x_co = X->coff;
   a.Y = Y->ptr; a.y_cs = Y->cstride; a.y_co = Y->coff;
   a.n = X->n; a.h = X->h; a.pwx = pwx; a.ws = ws;
+  a.nsplit = (int)splits;
   const bool act = pwx.scale != nullptr;
-  const unsigned grid = (unsigned)(splits * 4);
+  const unsigned grid = (unsigned)(bp_ceil_div((int)splits, 8) * 32);          // (split_lo 8) x (pair 4) x split_hi
   switch (ww_G(X->w)) {
     case 4: return act ? ww_launch<4, true>(a, grid, st) : ww_launch<4, false>(a, grid, st);
     case 2: return act ? ww_launch<2, true>(a, grid, st) : ww_launch<2, false>(a, grid, st);

@@ -29,6 +29,7 @@ struct WfArgs {
   float* out; int out_cs, out_co;
   int n, h;
   int iw, strips;                    // image width and column strips of W pixels per row (W = 16 G; iw = W * strips)
+  int items;                         // images x bands x strips
   const float* wp;                   // tiled image [tap 9][chunk 8][co 128][16]
   PW pw;
   int BR, bands;
@@ -54,7 +55,10 @@ __global__ __launch_bounds__(256) void ws3_f32_kernel(WfArgs a) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lm = lane & 15, kq = lane >> 4;
-  const int half = blockIdx.x & 1, item = blockIdx.x >> 1;
+  // block id = item_lo + 8 * (half + 2 * item_hi): the two channel halves of a band read the same input rows -- on the same
+  // XCD (workgroups go to the XCDs round-robin by id) the second read is an L2 hit (419 -> ~290 MB of HBM per launch)
+  const int half = (blockIdx.x >> 3) & 1, item = (int)(blockIdx.x & 7) + 8 * (int)(blockIdx.x >> 4);
+  if (item >= a.items) return;
   const int strip = item % a.strips, nb = item / a.strips;
   const int n = nb / a.bands, band = nb % a.bands;
   const int y0 = band * a.BR;
@@ -336,6 +340,7 @@ int bp_f32_ws_run(const ConvGeom& g, const bp_view* in, const PW& pw, const floa
   a.iw = out->w; a.strips = wf_strips(out->w);
   wf_bands(out->n, out->h, a.strips, &a.BR, &a.bands);
   const int64_t rows = (int64_t)out->n * a.bands * a.strips;
+  a.items = (int)rows;
   if (sr) {
     const size_t need = bp_stats_rows_bytes(rows, g.cout_g);
     if (sr->mode != 1 || !need) return BP_EUNSUPPORTED;
@@ -345,11 +350,11 @@ int bp_f32_ws_run(const ConvGeom& g, const bp_view* in, const PW& pw, const floa
   const bool act = pw.scale != nullptr;
   int rc;
   switch (wf_G(out->w)) {
-    case 4: rc = a.strips > 1 ? wf_launch_g<4, true>(a, act, sr != nullptr, (unsigned)(rows * 2), st)
-                              : wf_launch_g<4>(a, act, sr != nullptr, (unsigned)(rows * 2), st);
+    case 4: rc = a.strips > 1 ? wf_launch_g<4, true>(a, act, sr != nullptr, (unsigned)(bp_ceil_div((int)rows, 8) * 16), st)
+                              : wf_launch_g<4>(a, act, sr != nullptr, (unsigned)(bp_ceil_div((int)rows, 8) * 16), st);
             break;
-    case 2: rc = wf_launch_g<2>(a, act, sr != nullptr, (unsigned)(rows * 2), st); break;
-    default: rc = wf_launch_g<1>(a, act, sr != nullptr, (unsigned)(rows * 2), st); break;
+    case 2: rc = wf_launch_g<2>(a, act, sr != nullptr, (unsigned)(bp_ceil_div((int)rows, 8) * 16), st); break;
+    default: rc = wf_launch_g<1>(a, act, sr != nullptr, (unsigned)(bp_ceil_div((int)rows, 8) * 16), st); break;
   }
   if (rc != BP_OK || !sr) return rc;
   return bp_stats_rows_finish(a.stat, rows, g.cout_g, sr, st);
