@@ -55,7 +55,11 @@ class PeerAllReduce:
                 blob = b"".join(bytes(g[:-1].tolist()) for g in gathered)
                 if lib.bp_peer_open(comm, blob) == L.BP_OK:
                     peer = PeerAllReduce(lib, comm, rank, world)
-            good = peer is not None and peer._self_test(device)
+            # (any exception of the self-test counts as a failed test on this rank: every rank must reach the vote below)
+            try:
+                good = peer is not None and peer._self_test(device)
+            except Exception:
+                good = False
             flag = torch.tensor([1 if good else 0], dtype=torch.int32, device=device if backend == "nccl" else "cpu")
             dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
             if int(flag.item()) != 1:
