@@ -448,7 +448,8 @@ def _paint_leg(args, model, dtype, dev, world, rank, n):
     pt.model, pt.compute_device, pt.sync = model, dev, None
     pt.input_field, pt.label_fields = ds.input_field, ds.label_fields
     pt.transform, pt.inverse_transform = ds.transform, ds.inverse_transform
-    n_paint = args.paint_tiles
+    # (per rank; under N > 1 every rank pins its own in / out buffers: 2 x 2 GB instead of 2 x 4 GB)
+    n_paint = args.paint_tiles if world == 1 else min(args.paint_tiles, 2048)
     raw = np.stack([ds.raw_fields(i)[0] for i in range(8)])
     zs = np.array([ds.raw_fields(i)[2] for i in range(8)])
     reps_p = (n_paint + 7) // 8
