@@ -535,8 +535,11 @@ class _Plan:
             u.backward(grads)
         self.mark("trunk bwd")
         early = self._reduce_trunk_gradients()
+        fine = self.marks is not None and os.environ.get("BP_PHASE_EVENTS_FINE") == "1"     # (tools/phase_times.py)
         for u in reversed(self.g_units[0]):              # p_z_in
             u.backward(grads)
+            if fine:
+                self.mark(f"  bwd {u.name}")
         L.check(lib.bp_latent_backward(C.byref(self.lat), C.byref(self.z.grad), L.ptr(self.stats4),
                                        L.ptr(self.eps), L.ptr(self.seed), float(self.model.beta_KL),
                                        C.byref(self.q_head.grad),
@@ -554,19 +557,28 @@ class _Plan:
             main = torch.cuda.current_stream(self.device)
             sy, sp = self.branch
             ux, uy, uo = self.q_units
+            if fine:
+                self.mark("  latent bwd")
             sp.wait_stream(main)                                    # fork: d(loss)/d(prior head) is written
             with torch.cuda.stream(sp):
                 for u in reversed(self.p_units):
                     u.backward(grads)
             for u in reversed(uo):
                 u.backward(grads)
+                if fine:
+                    self.mark(f"  bwd {u.name}")
             sy.wait_stream(main)                                    # fork: d/d[q_x_in | q_y_in] is written
             with torch.cuda.stream(sy):
                 for u in reversed(uy):
                     u.backward(grads)
             for u in reversed(ux):
                 u.backward(grads)
-            main.wait_stream(sy); main.wait_stream(sp)
+                if fine:
+                    self.mark(f"  bwd {u.name}")
+            main.wait_stream(sy)
+            if fine:
+                self.mark("  join q_y_in")
+            main.wait_stream(sp)
         self.mark("p_z_in + latent + encoders bwd")
         self._flush_reductions(end=True)
         if self.side is not None:
