@@ -287,6 +287,159 @@ __global__ __launch_bounds__(256, FB_R > 4 ? 2 : 3) void flatb_kernel(FbArgs a) 
   }
 }
 
+// ---------------------------------------------------------------------------------------------- k7 16 -> 8, row ring
+// The heads' first layer again (forward, bf16 in, bf16 / fp32 out), as a ROW WALKER: the tile kernel above stages a halo
+// tile, loads 32 weight fragments, multiplies and stores, phase after phase -- 0.36 of the matrix pipe busy, 22 / 16 of
+// the rows and the weights re-fetched per tile.  Here a workgroup owns a strip of 64 columns of one image and walks it top
+// to bottom in steps of eight output rows: a ring of 24 input rows in LDS ([row][pixel + 6][16] bf16), the weights once
+// per workgroup, the next step's eight rows requested from HBM before the step's 128 MFMAs per wave and committed
+// (activation, bf16) after them into ring slots nobody reads, one barrier per step.  An input-row fragment feeds up to four
+// row pairs (0.44 LDS reads per MFMA; the 4-row passes of the tile kernel: 0.63).  Same packed weights, same MFMA row /
+// column meaning as flatb_kernel<7, 16, 8>.  Measured 0.29 ms against the tile kernel's 0.34-0.35 (not the 0.17 the HBM
+// bytes allow: at 256 registers -- 128 of them weights -- two waves per SIMD is all the latency hiding there is; a second
+// staging register set, i.e. a whole step of lead for the row loads, spilled and was slower: 0.36 ms).
+struct FrArgs {
+  const u16* in; int h, w, in_cs, in_co;
+  void* out; int out_cs, out_co;
+  const u16* wp;
+  PW pw;
+  int strips, n;
+};
+
+constexpr int FR_KS = 7, FR_CIN = 16, FR_TW = 64, FR_LW = FR_TW + FR_KS - 1, FR_ROWE = FR_LW * FR_CIN;
+constexpr int FR_STEP = 8, FR_WIN = FR_STEP + FR_KS - 1, FR_NR = 24;          // rows per step, window rows, ring rows
+constexpr int FR_KB = 4, FR_NP = 8;
+constexpr size_t FR_LDS = ((size_t)FR_NR * FR_ROWE + 32) * 2 + 3 * 16 * sizeof(float);
+
+template <bool OUT_BF16>
+__global__ __launch_bounds__(256, 2) void flatr_k7_kernel(FrArgs a) {
+  constexpr int UPR = FR_LW * 2;                        // 8-channel units per row
+  constexpr int NU = FR_STEP * UPR, SLOTS = (NU + 255) / 256;
+  extern __shared__ __attribute__((aligned(16))) u16 smem_fb[];
+  u16* lds = smem_fb;
+  float* lpw = reinterpret_cast<float*>(lds + FR_NR * FR_ROWE + 32);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lj = lane & 15, kg = lane >> 4;
+  const int n = blockIdx.x / a.strips, strip = blockIdx.x - n * a.strips;
+  const int tx0 = strip * FR_TW;
+
+  const bool on = a.pw.scale != nullptr;
+  if (tid < 16) {
+    lpw[tid] = on ? a.pw.scale[tid] : 1.f; lpw[16 + tid] = on ? a.pw.shift[tid] : 0.f; lpw[32 + tid] = on ? a.pw.slope[tid] : 1.f;
+  }
+  if (tid < 4) *reinterpret_cast<uint4*>(lds + FR_NR * FR_ROWE + tid * 8) = make_uint4(0u, 0u, 0u, 0u);     // slack behind the ring
+  __syncthreads();
+  const int c0 = (tid & 1) * 8;                         // (256 is even: a thread always stages the same channel octet)
+  float sc[8], sf[8], sl[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { sc[j] = lpw[c0 + j]; sf[j] = lpw[16 + c0 + j]; sl[j] = lpw[32 + c0 + j]; }
+
+  const u16* img = a.in + (int64_t)n * a.h * a.w * a.in_cs + a.in_co + c0;
+  // rows r0 .. r0 + 7 of the image (zero outside) -> registers; then -> ring slots (row mod 24)
+  uint4 stage[SLOTS];
+  unsigned inside = 0;
+  auto fetch = [&](int r0) {
+    inside = 0;
+#pragma unroll
+    for (int i = 0; i < SLOTS; ++i) {
+      const int e = tid + i * 256;
+      const int row = e / UPR, u = e - row * UPR;
+      const int gy = r0 + row, gx = tx0 - 3 + (u >> 1);
+      if (e < NU && gy >= 0 && gy < a.h && gx >= 0 && gx < a.w) inside |= 1u << i;
+      const int cy = min(max(gy, 0), a.h - 1), cx = min(max(gx, 0), a.w - 1);
+      stage[i] = *reinterpret_cast<const uint4*>(img + ((int64_t)cy * a.w + cx) * a.in_cs);
+    }
+  };
+  auto commit = [&](int r0) {
+#pragma unroll
+    for (int i = 0; i < SLOTS; ++i) {
+      const int e = tid + i * 256;
+      if (e >= NU) continue;
+      const int row = e / UPR, u = e - row * UPR;
+      const unsigned w[4] = {stage[i].x, stage[i].y, stage[i].z, stage[i].w};
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { v[2 * j] = bf2f((u16)(w[j] & 0xffffu)); v[2 * j + 1] = bf2f((u16)(w[j] >> 16)); }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float x = v[j];
+        if (on) { x = fmaf(x, sc[j], sf[j]); x = x > 0.f ? x : x * sl[j]; }
+        v[j] = ((inside >> i) & 1u) ? x : 0.f;
+      }
+      int rr = (r0 + row) % FR_NR;
+      if (rr < 0) rr += FR_NR;
+      lds_store_unit<8>(lds + rr * FR_ROWE + u * 8, v);
+    }
+  };
+
+  // prologue: the first window, rows -3 .. 10 (two fetches of eight rows: -3 .. 4 and 5 .. 12)
+  fetch(-3); commit(-3);
+  fetch(5); commit(5);
+  bf8 wf[FR_NP][FR_KB];
+#pragma unroll
+  for (int p = 0; p < FR_NP; ++p)
+#pragma unroll
+    for (int kb = 0; kb < FR_KB; ++kb)
+      wf[p][kb] = __builtin_bit_cast(bf8, *reinterpret_cast<const uint4*>(a.wp + ((p * FR_KB + kb) * 64 + lane) * 8));
+  __syncthreads();
+
+  const int x0 = wave * 16;
+  const int fbase = (x0 + lj) * FR_CIN + kg * 8;
+  const int ox = tx0 + x0 + lj;
+  const int rs_l = kg >> 1, co_l = 4 * (kg & 1);        // this lane's row of a pair and its 4 channels
+  for (int y0 = 0; y0 < a.h; y0 += FR_STEP) {
+    // rows y0 + 13 .. y0 + 20: the part of the NEXT window that is not in LDS yet (rows up to y0 + 12 are)
+    const bool more = y0 + FR_STEP < a.h;
+    if (more) fetch(y0 + 13);
+    __builtin_amdgcn_sched_barrier(0);                  // (the loads stay in front of the MFMA chain: left alone they sink to commit())
+    v4f acc[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) acc[s] = v4f{0.f, 0.f, 0.f, 0.f};
+    int rr = (y0 - 3) % FR_NR;
+    if (rr < 0) rr += FR_NR;
+    // the fragments of input row jr + 1 are read while row jr multiplies (two register sets, the stages fenced: left alone
+    // the compiler reads a fragment right before its first MFMA -- 56 exposed LDS latencies per step at two waves per SIMD)
+    bf8 xf[2][FR_KB];
+    {
+      const u16* rowp = lds + rr * FR_ROWE + fbase;
+#pragma unroll
+      for (int kb = 0; kb < FR_KB; ++kb) xf[0][kb] = lds_frag<32>(rowp + kb * 32);
+    }
+#pragma unroll
+    for (int jr = 0; jr < FR_WIN; ++jr) {               // input row y0 - 3 + jr
+      rr = rr + 1 == FR_NR ? 0 : rr + 1;
+      if (jr + 1 < FR_WIN) {
+        const u16* rowp = lds + rr * FR_ROWE + fbase;
+#pragma unroll
+        for (int kb = 0; kb < FR_KB; ++kb) xf[(jr + 1) & 1][kb] = lds_frag<32>(rowp + kb * 32);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int kb = 0; kb < FR_KB; ++kb) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {                   // row pair s: output rows y0 + 2 s, + 1; tap-row slot p = jr - 2 s
+          const int p = jr - 2 * s;
+          if (p >= 0 && p < FR_NP) acc[s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[p][kb], xf[jr & 1][kb], acc[s], 0, 0, 0);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int oy = y0 + 2 * s + rs_l;
+      if (oy >= a.h || ox >= a.w) continue;
+      const int64_t o = ((int64_t)(n * a.h + oy) * a.w + ox) * a.out_cs + a.out_co + co_l;
+      if constexpr (OUT_BF16)
+        *reinterpret_cast<uint2*>(reinterpret_cast<u16*>(a.out) + o) = make_uint2(pack2(acc[s][0], acc[s][1]), pack2(acc[s][2], acc[s][3]));
+      else
+        *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.out) + o) = make_float4(acc[s][0], acc[s][1], acc[s][2], acc[s][3]);
+    }
+    if (more) commit(y0 + 13);                          // slots of rows y0 - 11 .. y0 - 4: outside this step's window
+    __syncthreads();
+  }
+}
+
 // ---------------------------------------------------------------------------------------------- stride 2, k4, p1
 // The two thin stride-2 layers at the full / half resolution boundary (p_y_z_in.3: Conv 16 -> 32, p_y_z_in.22:
 // ConvTranspose 32 -> 16) and each other's data gradients, in the same scheme.
@@ -1271,6 +1424,24 @@ int bp_bf16_flat_run(const ConvGeom& g, const bp_view* in, const PW& pw, const u
   const bool ib = in->dtype == BP_BF16, ob = out->dtype == BP_BF16;
   switch (f.kind) {
     case 1: {
+      // the row walker where there are enough strips to fill the GPU (the training batch, the paint sub-batches)
+      static const bool no_ring = getenv("BP_FLATR") && atoi(getenv("BP_FLATR")) == 0;
+      const int strips = bp_ceil_div(out->w, FR_TW);
+      if (!no_ring && (int64_t)in->n * strips >= 128 && (int64_t)in->n * strips < (1ll << 31) && (ob ? out->cstride % 4 == 0 : true)) {
+        FrArgs r{};
+        r.in = reinterpret_cast<const u16*>(in->ptr); r.h = in->h; r.w = in->w; r.in_cs = in->cstride; r.in_co = in->coff;
+        r.out = out->ptr; r.out_cs = out->cstride; r.out_co = out->coff; r.wp = packed_flat; r.pw = pw;
+        r.strips = strips; r.n = in->n;
+        static const int once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(flatr_k7_kernel<true>),
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)FR_LDS),
+                                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(flatr_k7_kernel<false>),
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)FR_LDS), 0);
+        (void)once;
+        const dim3 rgrid((unsigned)(in->n * strips));
+        if (ob) hipLaunchKernelGGL(flatr_k7_kernel<true>, rgrid, dim3(256), FR_LDS, st, r);
+        else hipLaunchKernelGGL(flatr_k7_kernel<false>, rgrid, dim3(256), FR_LDS, st, r);
+        break;
+      }
       static const int rr = getenv("BP_FLAT_R") ? atoi(getenv("BP_FLAT_R")) : 4;
       if (ob && rr == 8) fb_launch<7, 16, 8, true, true, 0, 8>(a, grid, st);
       else if (ob && rr == 16) fb_launch<7, 16, 8, true, true, 0, 16>(a, grid, st);

@@ -60,6 +60,8 @@ CASES = [
     (0, 16, 8, 7, 1, 3, (2, 19, 35), None),         # p_mu_out.0 (data gradient gathers 8 channels: CC = 8)
     (0, 16, 8, 7, 1, 3, (3, 37, 150), None),        # ... several 64 x 16 tiles of the flattened-K kernel (conv_bf16_flat.hip:
     #                                                 bf16 -> fp32 / bf16 forward, fp32 / bf16 -> bf16 data gradient), ragged both ways
+    (0, 16, 8, 7, 1, 3, (66, 19, 130), None),       # ... and enough 64-column strips for the row-walking forward (flatr_k7_kernel):
+    #                                                 ragged last strip, a height that is not a multiple of its 8-row step
     # (p_mu_out.2, 8 -> 1 k5, exists with one element-type pattern only: test_head_tail_layer_on_matrix_cores)
 ]
 
