@@ -484,7 +484,8 @@ def test_bench_two_ranks_rehearsal():
     out = json.loads(line)
     assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 4 and out["value"] > 0 and out["dtype"] == "f32"
     assert out["config"]["batch_norm"].startswith("global")
-    assert out["roofline"]["achieved"] > 0
+    # (at 64 x 64 tiles the launch with the largest time may be one of micro-FLOP size: its rate can round to 0.00 TFLOP/s)
+    assert out["roofline"]["achieved"] >= 0 and out["roofline"]["kernel"] and out["roofline"]["avg_launch_ms"] > 0
     c = out["config"]["collectives_per_step"]
     # (44 separate statistics collectives, or 1 + 57 exchanges inside the finalize kernels over peer memory)
     assert (c["batch_norm_statistics"], c["batch_norm_statistics_fused_into_finalize"]) in ((44, 0), (1, 57))
