@@ -303,7 +303,7 @@ def test_head_tail_layer_on_matrix_cores(shape):
 
 WS_LAYERS = {
     # (transposed, cin, cout, k, stride, pad), input shapes (n, h, w) the stationary kernel takes in at least one direction
-    "k3": ((0, 128, 128, 3, 1, 1), [(2, 9, 16), (3, 20, 32), (2, 64, 64), (5, 16, 64), (70, 8, 16)]),
+    "k3": ((0, 128, 128, 3, 1, 1), [(2, 9, 16), (3, 20, 32), (1, 64, 64), (5, 16, 64), (70, 8, 16)]),
     # forward: the strided gather (kind 4), data gradient: the transposed gather (kind 5)
     "k4s2": ((0, 64, 128, 4, 2, 1), [(2, 16, 32), (3, 12, 64), (2, 40, 128), (66, 8, 32)]),
     # forward: the transposed gather, data gradient: the strided one
